@@ -1,0 +1,180 @@
+"""ctypes binding of include/abismal_amd.h (names and argument meaning as there)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SE_T_RICH, SE_A_RICH, SE_RANDOM = 0, 1, 2
+PE_NORMAL, PE_PBAT, PE_RANDOM = 0, 1, 2
+
+HIT_DTYPE = np.dtype([("diffs", "<i2"), ("flags", "<u2"), ("pos", "<u4")])
+PAIR_DTYPE = np.dtype([("aln_score", "<i2"), ("reserved", "<i2"), ("r1", HIT_DTYPE), ("r2", HIT_DTYPE)])
+
+EXPORTED_SYMBOLS = [
+    "abm_last_error", "abm_default_params", "abm_index_open", "abm_index_close",
+    "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
+    "abm_index_chrom_starts", "abm_index_bytes", "abm_ctx_create", "abm_ctx_destroy",
+    "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
+    "abm_max_read_length", "abm_ctx_take_work", "abm_stats_allreduce",
+]
+
+
+class AbismalAmdError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("max_candidates", C.c_uint32), ("valid_frac", C.c_double), ("min_frag", C.c_uint32),
+                ("max_frag", C.c_uint32), ("allow_ambig", C.c_int32)]
+
+    def __init__(self, max_candidates=0, valid_frac=0.1, min_frag=32, max_frag=3000, allow_ambig=0):
+        super().__init__(max_candidates, valid_frac, min_frag, max_frag, allow_ambig)
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libabismal_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the product library; there is no fallback when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise AbismalAmdError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(p)
+    lib.abm_last_error.restype = C.c_char_p
+    lib.abm_index_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.abm_index_close.argtypes = [C.c_void_p]
+    lib.abm_index_max_candidates.argtypes = [C.c_void_p]
+    lib.abm_index_max_candidates.restype = C.c_uint32
+    lib.abm_index_n_chroms.argtypes = [C.c_void_p]
+    lib.abm_index_n_chroms.restype = C.c_uint32
+    lib.abm_index_chrom_name.argtypes = [C.c_void_p, C.c_uint32]
+    lib.abm_index_chrom_name.restype = C.c_char_p
+    lib.abm_index_chrom_starts.argtypes = [C.c_void_p]
+    lib.abm_index_chrom_starts.restype = C.POINTER(C.c_uint32)
+    lib.abm_index_bytes.argtypes = [C.c_void_p]
+    lib.abm_index_bytes.restype = C.c_uint64
+    lib.abm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.abm_ctx_destroy.argtypes = [C.c_void_p]
+    lib.abm_max_read_length.restype = C.c_uint32
+    lib.abm_ctx_take_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    vp = C.c_void_p
+    lib.abm_map_se_batch.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp]
+    lib.abm_map_se_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, C.c_uint32, vp, vp,
+                                      C.c_uint32, vp, vp, vp]
+    lib.abm_map_pe_batch.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, vp, vp, vp,
+                                     vp, vp, vp, vp, C.c_uint64]
+    lib.abm_map_pe_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, C.c_uint32,
+                                      vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise AbismalAmdError(load_library().abm_last_error().decode(errors="replace"))
+
+
+def blob_and_offsets(reads):
+    """list[str|bytes] -> (uint8 blob, uint64 offsets[n+1]) as the C ABI takes them."""
+    bs = [r if isinstance(r, bytes) else r.encode() for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return blob, off
+
+
+class Index:
+    """abm_index_open / abm_index_close."""
+
+    def __init__(self, path):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.abm_index_open(os.fsencode(path), C.byref(h)))
+        self.handle = h
+        n = self._lib.abm_index_n_chroms(h)
+        self.chrom_names = [self._lib.abm_index_chrom_name(h, i).decode() for i in range(n)]
+        st = self._lib.abm_index_chrom_starts(h)
+        self.chrom_starts = np.array([st[i] for i in range(n + 1)], dtype=np.uint32)
+        self.max_candidates = self._lib.abm_index_max_candidates(h)
+        self.device_bytes = self._lib.abm_index_bytes(h)
+
+    def close(self):
+        if self.handle:
+            self._lib.abm_index_close(self.handle)
+            self.handle = None
+
+
+class Context:
+    """abm_ctx_create / abm_ctx_destroy + the batch entry points."""
+
+    def __init__(self, index: Index, device: int = 0):
+        self._lib = load_library()
+        self.index = index
+        h = C.c_void_p()
+        _check(self._lib.abm_ctx_create(index.handle, device, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self._lib.abm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def map_se(self, reads, mode=SE_T_RICH, params=None):
+        """abm_map_se_batch.  Returns (hits[HIT_DTYPE], cigar_blob[u32], cigar_off[u64])."""
+        params = params or Params()
+        blob, off = blob_and_offsets(reads)
+        n = len(off) - 1
+        res = np.zeros(n, dtype=HIT_DTYPE)
+        max_len = int((off[1:] - off[:-1]).max()) if n else 0
+        cap = max(1, n * (max_len + 2))
+        cig = np.zeros(cap, dtype=np.uint32)
+        cig_off = np.zeros(n + 1, dtype=np.uint64)
+        _check(self._lib.abm_map_se_batch(self.handle, mode, C.byref(params), n, blob.ctypes.data,
+                                          off.ctypes.data, res.ctypes.data, cig.ctypes.data, cap,
+                                          cig_off.ctypes.data))
+        return res, cig[: int(cig_off[-1])], cig_off
+
+    def map_se_device(self, mode, params, n, d_blob, d_off, max_len, d_res, d_cig, cig_stride, d_cig_n,
+                      d_status, stream=0):
+        """abm_map_se_device: all d_* are integer device addresses (e.g. tensor.data_ptr())."""
+        _check(self._lib.abm_map_se_device(self.handle, mode, C.byref(params), n, d_blob, d_off, max_len,
+                                           d_res, d_cig, cig_stride, d_cig_n, d_status, stream))
+
+    def map_pe(self, reads1, reads2, mode=PE_NORMAL, params=None):
+        """abm_map_pe_batch.  Returns (pairs, se1, se2, (cig1, off1), (cig2, off2))."""
+        params = params or Params()
+        b1, o1 = blob_and_offsets(reads1)
+        b2, o2 = blob_and_offsets(reads2)
+        n = len(o1) - 1
+        if len(o2) - 1 != n:
+            raise ValueError("paired-end batch sizes differ")
+        pairs = np.zeros(n, dtype=PAIR_DTYPE)
+        se1 = np.zeros(n, dtype=HIT_DTYPE)
+        se2 = np.zeros(n, dtype=HIT_DTYPE)
+        ml = max(int((o1[1:] - o1[:-1]).max()) if n else 0, int((o2[1:] - o2[:-1]).max()) if n else 0)
+        cap = max(1, n * (ml + 2))
+        c1 = np.zeros(cap, dtype=np.uint32)
+        c2 = np.zeros(cap, dtype=np.uint32)
+        co1 = np.zeros(n + 1, dtype=np.uint64)
+        co2 = np.zeros(n + 1, dtype=np.uint64)
+        _check(self._lib.abm_map_pe_batch(self.handle, mode, C.byref(params), n, b1.ctypes.data, o1.ctypes.data,
+                                          b2.ctypes.data, o2.ctypes.data, pairs.ctypes.data, se1.ctypes.data,
+                                          se2.ctypes.data, c1.ctypes.data, co1.ctypes.data, c2.ctypes.data,
+                                          co2.ctypes.data, cap))
+        return pairs, se1, se2, (c1[: int(co1[-1])], co1), (c2[: int(co2[-1])], co2)
+
+    def take_work(self):
+        out = (C.c_uint64 * 8)()
+        _check(self._lib.abm_ctx_take_work(self.handle, out))
+        keys = ["seed_offsets", "search_probes", "candidates", "read_words", "set_updates", "alignments"]
+        return dict(zip(keys, [int(x) for x in out[:6]]))

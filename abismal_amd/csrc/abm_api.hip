@@ -1,0 +1,302 @@
+// abismal_amd: C ABI (include/abismal_amd.h) over the HIP kernels.
+#include "../../include/abismal_amd.h"
+#include "abm_index_file.hpp"
+#include "abm_kernels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+struct HipFail : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+void hip_check(hipError_t e, const char *what) {
+  if (e != hipSuccess)
+    throw HipFail(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(x) hip_check((x), #x)
+
+template <class F> int guarded(F &&f) {
+  try { f(); return 0; }
+  catch (const std::exception &e) { g_error = e.what(); return -1; }
+  catch (...) { g_error = "unknown error"; return -1; }
+}
+
+template <class T> struct DevBuf {  // grow-only device allocation
+  T *p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr; cap = 0;
+    HIPCHK(hipMalloc(&p, n * sizeof(T)));
+    cap = n;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct abm_index {
+  abm::HostIndex h;
+};
+
+struct abm_ctx {
+  int device = 0;
+  const abm_index *ix = nullptr;
+  abm::DevIndex dix{};
+  void *arena = nullptr;  // one allocation holding the seven index arrays
+  // per-batch workspaces (grow-only; sized by the largest batch seen)
+  DevBuf<abm::u64> packed;
+  DevBuf<abm::u32> lens;
+  DevBuf<unsigned long long> work;
+  // staging for the host-buffer entry points
+  DevBuf<char> blob;
+  DevBuf<abm::u64> off;
+  DevBuf<abm::Hit> res;
+  DevBuf<abm::u32> cig, cig_n, status;
+  std::mutex mu;
+};
+
+namespace {
+
+abm::u32 words_for(abm::u32 max_len) { return std::max(1u, (max_len + 15) / 16); }
+abm::u32 bitwords_for(abm::u32 max_len) { return (max_len + 63) / 64 + 1; }
+
+void check_params(const abm_params *p) {
+  if (!p) throw std::invalid_argument("params is null");
+  if (!(p->valid_frac >= 0.0 && p->valid_frac <= 1.0)) throw std::invalid_argument("valid_frac out of range");
+}
+
+void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob,
+               const uint64_t *d_off, uint32_t max_len, abm_hit *d_res, uint32_t *d_cig,
+               uint32_t cig_stride, uint32_t *d_cig_n, uint32_t *d_status, hipStream_t st) {
+  check_params(params);
+  if (mode < 0 || mode > 2) throw std::invalid_argument("bad single-end mode");
+  if (cig_stride == 0) throw std::invalid_argument("cig_stride must be > 0");
+  if (n == 0) return;
+  HIPCHK(hipSetDevice(ctx->device));
+  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kMaxReadLen);
+  const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
+  ctx->packed.reserve(n * 4 * W);
+  ctx->lens.reserve(n);
+  ctx->work.reserve(8);
+  HIPCHK(abm::launch_pack_reads(d_blob, reinterpret_cast<const abm::u64 *>(d_off), n, W, ctx->packed.p,
+                                ctx->lens.p, st));
+  abm::SeArgs a{};
+  a.ix = ctx->dix;
+  if (params->max_candidates) a.ix.max_candidates = params->max_candidates;
+  a.packed = ctx->packed.p;
+  a.lens = ctx->lens.p;
+  a.n_reads = n;
+  a.W = W;
+  a.WB = WB;
+  a.mode = mode;
+  a.valid_frac = params->valid_frac;
+  a.res = reinterpret_cast<abm::Hit *>(d_res);
+  a.cig = d_cig;
+  a.cig_stride = cig_stride;
+  a.cig_n = d_cig_n;
+  a.status = d_status;
+  a.work = ctx->work.p;
+  int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, params->valid_frac);
+  if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
+  HIPCHK(abm::launch_map_se(a, eff_len, static_cast<abm::u32>(waves) * 8u, st));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *abm_last_error(void) { return g_error.c_str(); }
+
+void abm_default_params(abm_params *p) {
+  if (!p) return;
+  p->max_candidates = 0;
+  p->valid_frac = 0.1;
+  p->min_frag = 32;
+  p->max_frag = 3000;
+  p->allow_ambig = 0;
+}
+
+uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
+
+int abm_index_open(const char *path, abm_index **out) {
+  return guarded([&] {
+    if (!path || !out) throw std::invalid_argument("null argument");
+    auto *ix = new abm_index;
+    try { ix->h.load(path); }
+    catch (...) { delete ix; throw; }
+    *out = ix;
+  });
+}
+void abm_index_close(abm_index *ix) { delete ix; }
+uint32_t abm_index_max_candidates(const abm_index *ix) { return ix->h.max_candidates; }
+uint32_t abm_index_n_chroms(const abm_index *ix) { return static_cast<uint32_t>(ix->h.chrom_names.size()); }
+const char *abm_index_chrom_name(const abm_index *ix, uint32_t i) {
+  return i < ix->h.chrom_names.size() ? ix->h.chrom_names[i].c_str() : nullptr;
+}
+const uint32_t *abm_index_chrom_starts(const abm_index *ix) { return ix->h.chrom_starts.data(); }
+uint64_t abm_index_bytes(const abm_index *ix) { return ix->h.device_bytes(); }
+
+int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
+  return guarded([&] {
+    if (!ix || !out) throw std::invalid_argument("null argument");
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) throw HipFail("no HIP device present: the mapping path has no CPU fallback");
+    if (device < 0 || device >= n_dev) throw std::invalid_argument("device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    auto *c = new abm_ctx;
+    try {
+      c->device = device;
+      c->ix = ix;
+      const abm::HostIndex &h = ix->h;
+      // one arena, 256-byte aligned sub-arrays: genome first (u64), then the u32 tables
+      auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+      const size_t sz[7] = {h.genome.size() * 8,  h.counter.size() * 4, h.counter_t.size() * 4,
+                            h.counter_a.size() * 4, h.index.size() * 4, h.index_t.size() * 4,
+                            h.index_a.size() * 4};
+      const void *src[7] = {h.genome.data(),    h.counter.data(), h.counter_t.data(), h.counter_a.data(),
+                            h.index.data(),     h.index_t.data(), h.index_a.data()};
+      size_t offs[7], total = 0;
+      for (int k = 0; k < 7; ++k) { offs[k] = total; total += up(sz[k] + 64); }
+      HIPCHK(hipMalloc(&c->arena, total));
+      HIPCHK(hipMemset(c->arena, 0, total));
+      char *base = static_cast<char *>(c->arena);
+      for (int k = 0; k < 7; ++k)
+        if (sz[k]) HIPCHK(hipMemcpy(base + offs[k], src[k], sz[k], hipMemcpyHostToDevice));
+      c->dix.genome = reinterpret_cast<const abm::u64 *>(base + offs[0]);
+      c->dix.counter = reinterpret_cast<const abm::u32 *>(base + offs[1]);
+      c->dix.counter_t = reinterpret_cast<const abm::u32 *>(base + offs[2]);
+      c->dix.counter_a = reinterpret_cast<const abm::u32 *>(base + offs[3]);
+      c->dix.index = reinterpret_cast<const abm::u32 *>(base + offs[4]);
+      c->dix.index_t = reinterpret_cast<const abm::u32 *>(base + offs[5]);
+      c->dix.index_a = reinterpret_cast<const abm::u32 *>(base + offs[6]);
+      c->dix.max_candidates = h.max_candidates;
+      c->work.reserve(8);
+      HIPCHK(hipMemset(c->work.p, 0, 8 * sizeof(unsigned long long)));
+    }
+    catch (...) { abm_ctx_destroy(c); throw; }
+    *out = c;
+  });
+}
+
+void abm_ctx_destroy(abm_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->arena) (void)hipFree(c->arena);
+  c->packed.release(); c->lens.release(); c->work.release(); c->blob.release(); c->off.release();
+  c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
+  delete c;
+}
+
+// work tallies accumulated by every launch since the last read (reset on read):
+// seed_iters, search probes, candidates, read words compared, set updates, alignments
+int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[8]) {
+  return guarded([&] {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long tmp[8];
+    HIPCHK(hipMemcpy(tmp, ctx->work.p, sizeof(tmp), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(ctx->work.p, 0, sizeof(tmp)));
+    for (int k = 0; k < 8; ++k) out[k] = tmp[k];
+  });
+}
+
+int abm_map_se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                      const char *d_seq_blob, const uint64_t *d_seq_off, uint32_t max_len,
+                      abm_hit *d_res, uint32_t *d_cig, uint32_t cig_stride, uint32_t *d_cig_n,
+                      uint32_t *d_status, void *stream) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    se_device(ctx, mode, params, n, d_seq_blob, d_seq_off, max_len, d_res, d_cig, cig_stride, d_cig_n,
+              d_status, static_cast<hipStream_t>(stream));
+  });
+}
+
+int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                     const char *seq_blob, const uint64_t *seq_off, abm_hit *out_res,
+                     uint32_t *out_cig_blob, uint64_t cig_capacity, uint64_t *out_cig_off) {
+  return guarded([&] {
+    if (!ctx || !seq_off || !out_res || !out_cig_off) throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    out_cig_off[0] = 0;
+    if (n == 0) return;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t base = seq_off[0], bytes = seq_off[n] - base;
+    uint32_t max_len = 0;
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) rel[i] = seq_off[i] - base;
+    for (uint64_t i = 0; i < n; ++i) {
+      if (seq_off[i + 1] < seq_off[i]) throw std::invalid_argument("seq_off not monotone");
+      max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off[i + 1] - seq_off[i]));
+    }
+    if (max_len > abm::kMaxReadLen)
+      throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
+                                  std::to_string(abm::kMaxReadLen));
+    ctx->blob.reserve(std::max<uint64_t>(bytes, 1));
+    ctx->off.reserve(n + 1);
+    ctx->res.reserve(n);
+    ctx->cig_n.reserve(n);
+    ctx->status.reserve(1);
+    if (bytes) HIPCHK(hipMemcpy(ctx->blob.p, seq_blob + base, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+
+    std::vector<uint32_t> cig, cig_n(n);
+    uint32_t stride = 8;
+    for (;;) {  // a CIGAR longer than the slot triggers one rerun with full-size slots
+      ctx->cig.reserve(n * stride);
+      HIPCHK(hipMemset(ctx->status.p, 0, 4));
+      se_device(ctx, mode, params, n, ctx->blob.p, ctx->off.p, max_len, reinterpret_cast<abm_hit *>(ctx->res.p),
+                ctx->cig.p, stride, ctx->cig_n.p, ctx->status.p, nullptr);
+      HIPCHK(hipDeviceSynchronize());
+      uint32_t status = 0;
+      HIPCHK(hipMemcpy(&status, ctx->status.p, 4, hipMemcpyDeviceToHost));
+      if ((status & ABM_STATUS_CIGAR_OVERFLOW) && stride < max_len + 2) { stride = max_len + 2; continue; }
+      if (status) throw std::runtime_error("kernel reported status " + std::to_string(status));
+      break;
+    }
+    HIPCHK(hipMemcpy(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
+    cig.resize(n * stride);
+    HIPCHK(hipMemcpy(cig.data(), ctx->cig.p, cig.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cig_n.data(), ctx->cig_n.p, n * 4, hipMemcpyDeviceToHost));
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t k = out_res[i].pos ? cig_n[i] : 0;
+      if (at + k > cig_capacity) throw std::length_error("cig_capacity too small");
+      if (k) std::memcpy(out_cig_blob + at, cig.data() + i * stride, k * 4ull);
+      at += k;
+      out_cig_off[i + 1] = at;
+    }
+  });
+}
+
+int abm_map_pe_device(abm_ctx *, int, const abm_params *, uint64_t, const char *, const uint64_t *,
+                      const char *, const uint64_t *, uint32_t, abm_pair *, abm_hit *, abm_hit *,
+                      uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, void *) {
+  g_error = "paired-end kernels are not built yet";
+  return -2;
+}
+
+int abm_map_pe_batch(abm_ctx *, int, const abm_params *, uint64_t, const char *, const uint64_t *,
+                     const char *, const uint64_t *, abm_pair *, abm_hit *, abm_hit *, uint32_t *,
+                     uint64_t *, uint32_t *, uint64_t *, uint64_t) {
+  g_error = "paired-end kernels are not built yet";
+  return -2;
+}
+
+int abm_stats_allreduce(abm_ctx *const *, int, uint64_t *const *) {
+  g_error = "abm_stats_allreduce: not built yet";
+  return -2;
+}
+
+}  // extern "C"

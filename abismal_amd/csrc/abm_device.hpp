@@ -1,0 +1,118 @@
+// abismal_amd device-side primitives (gfx950, wave64).
+//
+// Everything here runs with ONE wavefront per workgroup (64 threads): a read is
+// mapped by one wave, so workgroup barriers degenerate to wave-level ordering
+// and per-read state that is uniform across the wave lives in SGPRs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace abm {
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i16 = int16_t;
+using i32 = int32_t;
+
+constexpr u32 kKeyWeight = 25;   // src/AbismalIndex.hpp:68
+constexpr u32 kKeyWeight3 = 16;  // src/AbismalIndex.hpp:69
+constexpr u32 kWindow = 20;      // src/AbismalIndex.hpp:76
+constexpr u32 kHashMod3 = 43046721u;
+constexpr u32 kMinReadLen = 44;  // src/abismal.cpp:212-213
+constexpr u32 kMaxReadLen = 512; // kernel cap (LDS-resident traceback)
+constexpr u32 kMaxBand = 61;     // src/AbismalAlign.hpp:108,133
+constexpr u32 kSeCap = 50;       // src/abismal.cpp:448
+constexpr u32 kPeCapSmall = 32, kPeCapLarge = 32u << 10;  // src/abismal.cpp:861-862
+
+constexpr u32 kFlagRC = 0x10, kFlagAmbig = 0x100, kFlagARich = 0x1000;
+
+struct DevIndex {
+  const u64 *genome;
+  const u32 *counter, *counter_t, *counter_a;
+  const u32 *index, *index_t, *index_a;
+  u32 max_candidates;
+};
+
+struct Hit {  // == abm_hit
+  i16 diffs;
+  u16 flags;
+  u32 pos;
+};
+
+// ---- lane helpers -----------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x); }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int rdlane(int v, int l) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
+}
+__device__ __forceinline__ u32 rdlane(u32 v, int l) {
+  return static_cast<u32>(rdlane(static_cast<int>(v), l));
+}
+__device__ __forceinline__ u64 rdlane(u64 v, int l) {
+  const u32 lo = rdlane(static_cast<u32>(v), l), hi = rdlane(static_cast<u32>(v >> 32), l);
+  return (static_cast<u64>(hi) << 32) | lo;
+}
+// v_writelane: one lane of a wave-resident array takes a uniform value
+__device__ __forceinline__ void wrlane(int &v, int l, int x) { v = (lane_id() == l) ? x : v; }
+__device__ __forceinline__ void wrlane(u32 &v, int l, u32 x) { v = (lane_id() == l) ? x : v; }
+
+__device__ __forceinline__ u32 wave_excl_sum(u32 x, u32 &total) {
+  u32 inc = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 y = __shfl_up(inc, d);
+    if (lane_id() >= d) inc += y;
+  }
+  total = rdlane(inc, 63);
+  return inc - x;
+}
+
+__device__ __forceinline__ int wave_incl_max(int x) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d);
+    if (lane_id() >= d) x = max(x, y);
+  }
+  return x;
+}
+
+__device__ __forceinline__ u64 wave_max_u64(u64 x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const u64 y = __shfl_xor(x, d);
+    x = y > x ? y : x;
+  }
+  return x;
+}
+
+// ---- sequence primitives ------------------------------------------------------
+// read nibble: src/dna_four_bit_bisulfite.hpp:26-57
+__device__ __forceinline__ u32 read_nibble(u32 c, bool a_alphabet) {
+  c &= 0xDFu;  // fold case
+  return c == 'A' ? (a_alphabet ? 5u : 1u)
+       : c == 'C' ? 2u
+       : c == 'G' ? 4u
+       : c == 'T' ? (a_alphabet ? 8u : 10u)
+                  : 0u;
+}
+// complement as the mapper does it (src/common.hpp:28-44): non-ACGT -> N
+__device__ __forceinline__ u32 comp_base(u32 c) {
+  return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+}
+__device__ __forceinline__ u32 gnib(const u64 *__restrict__ g, u64 k) {
+  return static_cast<u32>(g[k >> 4] >> ((k & 15u) << 2)) & 15u;
+}
+// src/AbismalIndex.hpp:255-269, src/abismal.cpp:1196-1203
+__device__ __forceinline__ u32 bit2(u32 nt) { return (nt & 5u) == 0u; }
+__device__ __forceinline__ u32 trit(u32 nt, bool g_to_a) {
+  return g_to_a ? ((((nt & 8u) != 0u) << 1) | ((nt & 2u) != 0u))
+                : ((((nt & 4u) != 0u) << 1) | ((nt & 1u) != 0u));
+}
+__device__ __forceinline__ u32 sortsym3(u32 nt, bool g_to_a) { return g_to_a ? (nt & 10u) : (nt & 5u); }
+
+}  // namespace abm

@@ -1,0 +1,126 @@
+/* abismal_amd — C ABI of the MI355X-native mapping path.
+ *
+ * The reference (smithlabcode/abismal v3.3.0) has no FFI; its seam for this
+ * path is the body of the per-read loops in src/abismal.cpp — everything
+ * between ReadLoader::load_reads (:1545) and format_se / select_output
+ * (:1577, :2000).  Each entry point below names the reference code it
+ * replaces.  All functions return 0 on success, <0 on error (text via
+ * abm_last_error()); no ownership is transferred; plain pointers and sizes
+ * only.
+ */
+#ifndef ABISMAL_AMD_H
+#define ABISMAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct abm_index abm_index; /* host copy of an AbismalIndex file */
+typedef struct abm_ctx abm_ctx;     /* one GPU: index in HBM + workspaces */
+
+/* se_element, src/abismal.cpp:224-297.  pos is the absolute position in the
+ * padded concatenated genome; pos == 0 means "no hit" (flags/diffs are then
+ * unspecified).  flags: 0x10 reverse strand, 0x100 ambiguous, 0x1000 A-rich. */
+typedef struct { int16_t diffs; uint16_t flags; uint32_t pos; } abm_hit;
+
+/* pe_element, src/abismal.cpp:547-619 (aln_score + both ends) */
+typedef struct { int16_t aln_score; int16_t reserved; abm_hit r1, r2; } abm_pair;
+
+/* the tunables the path reads: src/abismal.cpp:2329-2337, :2448-2452 */
+typedef struct {
+  uint32_t max_candidates; /* 0 = value stored in the index (-c) */
+  double valid_frac;       /* -m, default 0.1 */
+  uint32_t min_frag;       /* -l, default 32 (PE) */
+  uint32_t max_frag;       /* -L, default 3000 (PE) */
+  int32_t allow_ambig;     /* -a: only steers the PE single-end fallback */
+} abm_params;
+
+/* conversion modes = which per-read body runs */
+enum { ABM_SE_T_RICH = 0, ABM_SE_A_RICH = 1, ABM_SE_RANDOM = 2 }; /* :1552-1581, -A/-P, :1645-1685 */
+enum { ABM_PE_NORMAL = 0, ABM_PE_PBAT = 1, ABM_PE_RANDOM = 2 };   /* :1950-2002, -P, :2094-2158 */
+
+const char *abm_last_error(void);
+void abm_default_params(abm_params *p);
+
+/* AbismalIndex::read, src/AbismalIndex.cpp:1082-1146 (+ seed::read :988-1024,
+ * ChromLookup::read :1225-1258).  Rejects files whose identifier or seed
+ * constants (25 / 20 / 256) differ, with the reference's messages. */
+int abm_index_open(const char *path, abm_index **out);
+void abm_index_close(abm_index *ix);
+uint32_t abm_index_max_candidates(const abm_index *ix);
+uint32_t abm_index_n_chroms(const abm_index *ix);              /* incl. pad_start/pad_end */
+const char *abm_index_chrom_name(const abm_index *ix, uint32_t i);
+const uint32_t *abm_index_chrom_starts(const abm_index *ix);    /* n_chroms+1 entries */
+uint64_t abm_index_bytes(const abm_index *ix);                  /* bytes resident in HBM after upload */
+
+/* Replicates the index into the HBM of `device` (hipSetDevice ordinal) and
+ * allocates per-GPU workspaces.  The index is immutable afterwards and may be
+ * shared by any number of streams. */
+int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out);
+void abm_ctx_destroy(abm_ctx *ctx);
+
+/* Single-end batch, host buffers.  Replaces the loop body of
+ * map_single_ended / map_single_ended_rand (src/abismal.cpp:1552-1576,
+ * :1645-1680): reads are the strings ReadLoader would hand over (already
+ * N-trimmed; empty = skipped), concatenated in seq_blob with n+1 offsets.
+ * out_res[i] equals bests[i] and the CIGAR equals r[i].cig just before
+ * format_se; CIGAR ops are BAM-encoded (len<<4|op) in out_cig_blob with n+1
+ * offsets in out_cig_off (reads without a hit get an empty CIGAR). */
+int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                     const char *seq_blob, const uint64_t *seq_off, abm_hit *out_res,
+                     uint32_t *out_cig_blob, uint64_t cig_capacity, uint64_t *out_cig_off);
+
+/* Same computation with every buffer already resident in HBM (d_* are device
+ * pointers), enqueued on `stream` (a hipStream_t; NULL = default stream) and
+ * not synchronised.  CIGARs land in fixed slots of cig_stride ops per read,
+ * their lengths in d_cig_n.  d_status (one uint32) is OR-ed with
+ * ABM_STATUS_* bits. max_len = longest read in the batch. */
+int abm_map_se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                      const char *d_seq_blob, const uint64_t *d_seq_off, uint32_t max_len,
+                      abm_hit *d_res, uint32_t *d_cig, uint32_t cig_stride, uint32_t *d_cig_n,
+                      uint32_t *d_status, void *stream);
+
+/* Paired-end batch.  Replaces the loop body of map_paired_ended /
+ * map_paired_ended_rand (src/abismal.cpp:1950-1999, :2094-2155): out_pair[i],
+ * out_se1[i], out_se2[i] and the two CIGARs equal bests[i], bests_se1[i],
+ * bests_se2[i], r1[i].cig, r2[i].cig just before select_output. */
+int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                     const char *seq_blob1, const uint64_t *seq_off1, const char *seq_blob2,
+                     const uint64_t *seq_off2, abm_pair *out_pair, abm_hit *out_se1,
+                     abm_hit *out_se2, uint32_t *out_cig_blob1, uint64_t *out_cig_off1,
+                     uint32_t *out_cig_blob2, uint64_t *out_cig_off2, uint64_t cig_capacity);
+
+int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                      const char *d_seq_blob1, const uint64_t *d_seq_off1, const char *d_seq_blob2,
+                      const uint64_t *d_seq_off2, uint32_t max_len, abm_pair *d_pair,
+                      abm_hit *d_se1, abm_hit *d_se2, uint32_t *d_cig1, uint32_t *d_cig2,
+                      uint32_t cig_stride, uint32_t *d_cig_n1, uint32_t *d_cig_n2,
+                      uint32_t *d_status, void *stream);
+
+enum {
+  ABM_STATUS_CIGAR_OVERFLOW = 1u, /* a CIGAR needed more than cig_stride ops */
+  ABM_STATUS_READ_TOO_LONG = 2u,  /* a read exceeded the kernel's length cap */
+  ABM_STATUS_SET_OVERFLOW = 4u    /* PE candidate set outgrew its workspace */
+};
+uint32_t abm_max_read_length(void); /* longest read the kernels accept */
+
+/* Measurement hook (no reference counterpart): exact work tallies accumulated
+ * by every launch on this context since the previous call, then reset:
+ * [0] seed offsets probed, [1] bucket-narrowing search probes, [2] candidates
+ * compared, [3] read words compared, [4] candidate-set updates, [5] alignments.
+ * Feeds the algorithmic-bytes model of SURVEY.md section 8(d). */
+int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[8]);
+
+/* Mapping statistics are six counters per struct (src/abismal.cpp:865-895) in
+ * up to three structs (pairs, read1, read2: :1034-1037) = 18 x u64.  Sums them
+ * over every context in ctxs[] with one RCCL all-reduce (ncclSum over xGMI);
+ * counters[k] points at the 18 host values of context k and receives the sum. */
+int abm_stats_allreduce(abm_ctx *const *ctxs, int n_ctx, uint64_t *const *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABISMAL_AMD_H */

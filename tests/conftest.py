@@ -1,0 +1,34 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement (oracle/), built on demand.  Test infrastructure only."""
+    from tests import oracle_binding
+    return oracle_binding.load(build=True)
+
+
+@pytest.fixture(scope="session")
+def workdir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("abismal"))
+
+
+@pytest.fixture(scope="session")
+def trex_index(oracle, workdir):
+    """tRex1.idx built by the oracle's indexer from the committed tRex1.fa fixture."""
+    fa = os.path.join(ROOT, "tests", "golden", "tRex1.fa")
+    out = os.path.join(workdir, "tRex1.idx")
+    oracle.index_build(fa, out, threads=4)
+    return out

@@ -7,7 +7,7 @@ tests and by ``bench.py``; it never computes anything itself and raises if the
 library is missing.
 """
 from .api import (  # noqa: F401
-    AbismalAmdError, Index, Context, Params, lib_path, load_library,
+    AbismalAmdError, Index, index_build, Context, Params, lib_path, load_library,
     SE_T_RICH, SE_A_RICH, SE_RANDOM, PE_NORMAL, PE_PBAT, PE_RANDOM,
     HIT_DTYPE, PAIR_DTYPE, EXPORTED_SYMBOLS,
 )

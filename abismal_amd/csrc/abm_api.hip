@@ -1,6 +1,7 @@
 // abismal_amd: C ABI (include/abismal_amd.h) over the HIP kernels.
 #include "../../include/abismal_amd.h"
 #include "abm_index_file.hpp"
+#include "abm_index_build.hpp"
 #include "abm_kernels.hpp"
 
 #include <algorithm>
@@ -145,6 +146,19 @@ const char *abm_index_chrom_name(const abm_index *ix, uint32_t i) {
 }
 const uint32_t *abm_index_chrom_starts(const abm_index *ix) { return ix->h.chrom_starts.data(); }
 uint64_t abm_index_bytes(const abm_index *ix) { return ix->h.device_bytes(); }
+
+int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_threads) {
+  return guarded([&] {
+    if (!fasta_path || !out_path) throw std::invalid_argument("null argument");
+    std::string text;
+    std::vector<std::string> names;
+    std::vector<uint32_t> starts;
+    abm::load_fasta(fasta_path, text, names, starts);
+    abm::HostIndex h;
+    abm::build_index(text, names, starts, n_threads ? n_threads : 1u, h);
+    abm::write_index(h, out_path);
+  });
+}
 
 int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
   return guarded([&] {

@@ -56,6 +56,11 @@ const char *abm_index_chrom_name(const abm_index *ix, uint32_t i);
 const uint32_t *abm_index_chrom_starts(const abm_index *ix);    /* n_chroms+1 entries */
 uint64_t abm_index_bytes(const abm_index *ix);                  /* bytes resident in HBM after upload */
 
+/* `abismal idx <genome.fa> <out.idx>` (src/abismalidx.cpp:35-115 ->
+ * AbismalIndex::create_index + write, src/AbismalIndex.cpp:281-331, :1037-1072).
+ * Host-side, multi-threaded; the file is byte-identical to the reference's. */
+int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_threads);
+
 /* Replicates the index into the HBM of `device` (hipSetDevice ordinal) and
  * allocates per-GPU workspaces.  The index is immutable afterwards and may be
  * shared by any number of streams. */

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_ctx_create", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
-    "abm_max_read_length", "abm_ctx_take_work", "abm_stats_allreduce",
+    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_stats_allreduce",
 ]
 
 
@@ -67,6 +67,8 @@ def load_library():
     lib.abm_ctx_destroy.argtypes = [C.c_void_p]
     lib.abm_max_read_length.restype = C.c_uint32
     lib.abm_ctx_take_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.abm_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.abm_ctx_take_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     vp = C.c_void_p
     lib.abm_map_se_batch.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp]
     lib.abm_map_se_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, C.c_uint32, vp, vp,
@@ -179,6 +181,15 @@ class Context:
                                           se2.ctypes.data, c1.ctypes.data, co1.ctypes.data, c2.ctypes.data,
                                           co2.ctypes.data, cap))
         return pairs, se1, se2, (c1[: int(co1[-1])], co1), (c2[: int(co2[-1])], co2)
+
+    def set_timing(self, on=True):
+        _check(self._lib.abm_ctx_set_timing(self.handle, int(on)))
+
+    def take_kernel_time(self):
+        """(launches, total_ms) of the mapping kernel since the last call (HIP events)."""
+        n, ms = C.c_uint64(), C.c_double()
+        _check(self._lib.abm_ctx_take_kernel_time(self.handle, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
 
     def take_work(self):
         out = (C.c_uint64 * 8)()

@@ -63,6 +63,10 @@ struct abm_ctx {
   DevBuf<abm::u64> off;
   DevBuf<abm::Hit> res;
   DevBuf<abm::u32> cig, cig_n, status;
+  // optional HIP-event timing of the mapping kernel (abm_ctx_set_timing)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
   std::mutex mu;
 };
 
@@ -109,7 +113,21 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.work = ctx->work.p;
   int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, params->valid_frac);
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->timing) {
+    if (ctx->events_used == ctx->events.size()) {
+      hipEvent_t x, y;
+      HIPCHK(hipEventCreate(&x));
+      HIPCHK(hipEventCreate(&y));
+      ctx->events.emplace_back(x, y);
+    }
+    e0 = ctx->events[ctx->events_used].first;
+    e1 = ctx->events[ctx->events_used].second;
+    ++ctx->events_used;
+    HIPCHK(hipEventRecord(e0, st));
+  }
   HIPCHK(abm::launch_map_se(a, eff_len, static_cast<abm::u32>(waves) * 8u, st));
+  if (e1) HIPCHK(hipEventRecord(e1, st));
 }
 
 }  // namespace
@@ -209,6 +227,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (c->arena) (void)hipFree(c->arena);
   c->packed.release(); c->lens.release(); c->work.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
+  for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
 }
 
@@ -222,6 +241,32 @@ int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[8]) {
     HIPCHK(hipMemcpy(tmp, ctx->work.p, sizeof(tmp), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(ctx->work.p, 0, sizeof(tmp)));
     for (int k = 0; k < 8; ++k) out[k] = tmp[k];
+  });
+}
+
+int abm_ctx_set_timing(abm_ctx *ctx, int enable) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->timing = enable != 0;
+  });
+}
+
+int abm_ctx_take_kernel_time(abm_ctx *ctx, uint64_t *launches, double *total_ms) {
+  return guarded([&] {
+    if (!ctx || !launches || !total_ms) throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    double sum = 0;
+    for (size_t k = 0; k < ctx->events_used; ++k) {
+      HIPCHK(hipEventSynchronize(ctx->events[k].second));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->events[k].first, ctx->events[k].second));
+      sum += ms;
+    }
+    *launches = ctx->events_used;
+    *total_ms = sum;
+    ctx->events_used = 0;
   });
 }
 

@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X-native abismal mapping path.
+
+Metric (BASELINE.json): mapped reads/sec, whole node, 100 bp single-end reads on
+an hg38-scale index.  hg38 itself is not available offline, so the workload is a
+synthetic hg38-*shaped* genome (24 chromosomes, interspersed repeat families,
+low-complexity tracts, N gaps; size --genome-mbp, default 3100 Mbp) indexed by
+the product's own `abm_index_build`, and reads drawn from it the way
+`abismal sim` draws them (uniform position and strand, 1 % mutations split over
+substitution/insertion/deletion, 98 % bisulfite conversion).
+
+One "step" = one pass of the hot path (pack + map kernels, via
+abm_map_se_device) over one batch of --reads reads already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+
+For N > 1 launch with torch.distributed.run (one rank per GPU); reads shard
+across ranks with the index replicated per GPU; the only collective is the
+end-of-run RCCL all-reduce of the mapping statistics.
+"""
+import argparse
+import json
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HG38_FRACTIONS = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59,
+                  64, 47, 51, 156, 57]  # chr1..22, X, Y in Mbp
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ----------------------------------------------------------------------------- genome
+def synth_genome_fasta(path, total_mbp, seed, device):
+    """hg38-shaped synthetic genome written as FASTA (generated with torch on the GPU)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    total = int(total_mbp * 1_000_000)
+    sizes = [max(200_000, int(total * f / sum(HG38_FRACTIONS))) for f in HG38_FRACTIONS]
+    lut = torch.tensor([ord(c) for c in "A" * 75 + "C" * 53 + "G" * 52 + "T" * 76], dtype=torch.uint8, device=device)
+    acgt = torch.tensor([ord(c) for c in "ACGT"], dtype=torch.uint8, device=device)
+
+    def rand_seq(n):
+        return lut[torch.randint(0, 256, (n,), generator=g, device=device)]
+
+    # repeat families: (consensus length, piece length, fraction of genome, divergence)
+    families = [(300, 300, 0.10, 0.12), (6000, 900, 0.15, 0.08), (2000, 400, 0.04, 0.15)]
+    cons = [rand_seq(c) for c, _, _, _ in families]
+    with open(path, "wb") as f:
+        for ci, n in enumerate(sizes):
+            seq = rand_seq(n)
+            for (clen, plen, frac, div), con in zip(families, cons):
+                k = int(n * frac / plen)
+                if k == 0 or n <= plen + 1:
+                    continue
+                at = torch.randint(0, n - plen, (k,), generator=g, device=device)
+                src0 = torch.randint(0, clen - plen + 1, (k,), generator=g, device=device)
+                ar = torch.arange(plen, device=device)
+                piece = con[(src0[:, None] + ar[None, :])]
+                mut = torch.rand((k, plen), generator=g, device=device) < div
+                rnd = acgt[torch.randint(0, 4, (k, plen), generator=g, device=device)]
+                piece = torch.where(mut, rnd, piece)
+                seq[(at[:, None] + ar[None, :]).reshape(-1)] = piece.reshape(-1)
+            # low-complexity tracts (~1 %): motifs of 1-4 bases repeated over 256 bp
+            n_tr = max(1, int(n * 0.01 / 256))
+            if n > 1000:
+                at = torch.randint(0, n - 256, (n_tr,), generator=g, device=device)
+                ml = torch.randint(1, 5, (n_tr,), generator=g, device=device)
+                motif = lut[torch.randint(0, 256, (n_tr, 4), generator=g, device=device)]
+                ar = torch.arange(256, device=device)
+                tract = torch.gather(motif, 1, ar[None, :] % ml[:, None])
+                seq[(at[:, None] + ar[None, :]).reshape(-1)] = tract.reshape(-1)
+            # one long N gap (centromere-like) and a short N run per chromosome
+            if n > 4_000_000:
+                seq[n // 3: n // 3 + min(1_000_000, n // 50)] = ord("N")
+                seq[n // 2: n // 2 + 100] = ord("N")
+            host = seq.cpu().numpy()
+            f.write(f">chrS{ci + 1}\n".encode())
+            w = 100
+            full = (n // w) * w
+            lines = np.empty((full // w, w + 1), dtype=np.uint8)
+            lines[:, :w] = host[:full].reshape(-1, w)
+            lines[:, w] = 10
+            f.write(lines.tobytes())
+            if full < n:
+                f.write(host[full:].tobytes() + b"\n")
+
+
+def read_index_genome(path):
+    """Parse an AbismalIndex file far enough to get the chromosome table and the
+    4-bit genome (layout: src/AbismalIndex.cpp:1037-1072)."""
+    with open(path, "rb") as f:
+        assert f.read(12) == b"AbismalIndex"
+        f.read(12)
+        (n_chroms,) = struct.unpack("<I", f.read(4))
+        names = []
+        for _ in range(n_chroms):
+            (ln,) = struct.unpack("<I", f.read(4))
+            names.append(f.read(ln).decode())
+        starts = np.frombuffer(f.read(4 * (n_chroms + 1)), dtype=np.uint32)
+        n_words = (int(starts[-1]) + 15) // 16
+        genome = np.fromfile(f, dtype=np.uint64, count=n_words)
+    return names, starts, genome
+
+
+# ------------------------------------------------------------------------------ reads
+def sample_reads(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, chunk=1_000_000):
+    """simreads-equivalent sampler on the GPU: returns uint8 blob [n*L] of ASCII reads."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    gw = torch.from_numpy(genome_words.view(np.int64)).to(device)
+    dec = torch.tensor([ord(c) for c in "NACNGNNNTNNNNNNN"], dtype=torch.uint8, device=device)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip("ACGTN", "TGCAN"):
+        comp[ord(a)] = ord(b)
+    acgt = torch.tensor([ord(c) for c in "ACGT"], dtype=torch.uint8, device=device)
+    G = int(starts[-1])
+    span = L + 16
+    out = torch.empty((n, L), dtype=torch.uint8, device=device)
+    ar = torch.arange(span, device=device)
+    for a in range(0, n, chunk):
+        m = min(chunk, n - a)
+        pos = torch.randint(0, G - span, (m,), generator=g, device=device)
+        for _ in range(8):  # fragments touching an N run are redrawn (keeps the batch rectangular)
+            idx = pos[:, None] + ar[None, :]
+            nib = (gw[idx >> 4] >> ((idx & 15) << 2)) & 15
+            bad = (nib == 0).any(1)
+            nb = int(bad.sum())
+            if nb == 0:
+                break
+            pos[bad] = torch.randint(0, G - span, (nb,), generator=g, device=device)
+        frag = dec[nib]
+        minus = torch.rand((m,), generator=g, device=device) < 0.5
+        rc = comp[frag.flip(1).long()]
+        frag = torch.where(minus[:, None], rc, frag)
+        # mutations: step 1 normally, 2 after a deletion, 0 at an insertion
+        u = torch.rand((m, L), generator=g, device=device)
+        kind = torch.randint(0, 3, (m, L), generator=g, device=device)
+        is_mut = u < mut
+        step = torch.ones((m, L), dtype=torch.int64, device=device)
+        step[is_mut & (kind == 1)] = 0
+        step[is_mut & (kind == 2)] = 2
+        src = (torch.cumsum(step, 1) - step).clamp_(0, span - 1)
+        reads = torch.gather(frag, 1, src)
+        rnd = acgt[torch.randint(0, 4, (m, L), generator=g, device=device)]
+        reads = torch.where(is_mut & (kind != 2), rnd, reads)
+        conv = (reads == ord("C")) & (torch.rand((m, L), generator=g, device=device) < bis)
+        reads = torch.where(conv, torch.full_like(reads, ord("T")), reads)
+        out[a:a + m] = reads
+    # ReadLoader rules (src/abismal.cpp:187-195): <44 informative bases -> skipped.
+    # Such reads (N-gap overlaps) are kept as all-N records of length L so that the
+    # batch stays rectangular; the mapper treats them exactly like the reference
+    # treats a read it cannot seed (no hit).  Count them for the report.
+    n_skipped = int(((out != ord("N")).sum(1) < 44).sum())
+    return out.reshape(-1), n_skipped
+
+
+# ------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("ABM_BENCH_GENOME_MBP", 3100)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("ABM_BENCH_READS", 10_000_000)),
+                    help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ABM_BENCH_CPU_SAMPLE", 1_000_000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("ABM_BENCH_DIR", "/tmp/abismal_bench"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import abismal_amd as A
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the mapping path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    os.makedirs(args.workdir, exist_ok=True)
+    tag = f"g{int(args.genome_mbp)}"
+    fasta = os.path.join(args.workdir, tag + ".fa")
+    idx = os.path.join(args.workdir, tag + ".idx")
+    t_build = 0.0
+    if rank == 0 and not os.path.exists(idx):
+        t0 = time.time()
+        synth_genome_fasta(fasta, args.genome_mbp, 1234, dev)
+        log(f"synthetic genome written in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        A.index_build(fasta, idx + ".tmp", os.cpu_count() or 1)
+        os.replace(idx + ".tmp", idx)
+        t_build = time.time() - t0
+        log(f"index built in {t_build:.1f}s ({os.path.getsize(idx) / 1e9:.2f} GB)")
+        os.remove(fasta)
+    barrier()
+
+    t0 = time.time()
+    index = A.Index(idx)
+    ctx = A.Context(index, local_rank)
+    t_load = time.time() - t0
+    log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident)")
+
+    names, starts, genome_words = read_index_genome(idx)
+    n, L = args.reads, args.read_len
+    t0 = time.time()
+    blob, n_skipped = sample_reads(genome_words, starts, n, L, 1000 + rank, dev)
+    off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    log(f"{n} reads sampled on GPU in {time.time() - t0:.1f}s ({n_skipped} unseedable)")
+    del genome_words
+
+    stride = 8
+    res = torch.zeros((n, 2), dtype=torch.int32, device=dev)  # abm_hit = 8 bytes
+    cig = torch.zeros((n, stride), dtype=torch.int32, device=dev)
+    cig_n = torch.zeros((n,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    params = A.Params()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.map_se_device(A.SE_T_RICH, params, n, blob.data_ptr(), off.data_ptr(), L, res.data_ptr(),
+                          cig.data_ptr(), stride, cig_n.data_ptr(), status.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.take_work()
+    ctx.set_timing(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.take_kernel_time()
+    work = ctx.take_work()
+    ctx.set_timing(False)
+
+    # mapping statistics (six counters, src/abismal.cpp:865-895) reduced over ranks
+    pos = res[:, 1]
+    flags = (res[:, 0] >> 16) & 0xFFFF
+    diffs = res[:, 0] & 0xFFFF
+    mapped = pos != 0
+    ambig = mapped & ((flags & 0x100) != 0)
+    uniq = mapped & ~ambig
+    ops = cig.clamp(min=0)
+    ref_consuming = ((ops & 15) == 0) | ((ops & 15) == 2)
+    valid_op = torch.arange(stride, device=dev)[None, :] < cig_n[:, None]
+    bases = ((ops >> 4) * (ref_consuming & valid_op)).sum(1)
+    stats = torch.tensor([n, int(uniq.sum()), int(ambig.sum()), n_skipped, int(diffs[uniq].sum()),
+                          int(bases[uniq].sum())], dtype=torch.int64, device=dev)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # the path's single collective (RCCL)
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+    st_host = int(status.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_reads = n * args.steps * world
+    value = total_reads / elapsed
+    # algorithmic bytes per read:
+    #   L + S*16 + P*4.5 + C*4 + (W+C)*8 + A*(L+bw)/2 + 8*(1+ops/2)
+    per_launch = {k: v / max(1, launches) for k, v in work.items()}
+    bw_band = 2 * int(0.1 * L) + 1
+    tot_ops = float(cig_n[mapped].sum().item())
+    alg_bytes = (n * L + per_launch["seed_offsets"] * 16 + per_launch["search_probes"] * 4.5 +
+                 per_launch["candidates"] * 4 + (per_launch["read_words"] + per_launch["candidates"]) * 8 +
+                 per_launch["alignments"] * (L + bw_band) / 2 + 8 * (n + tot_ops / 2))
+    avg_ms = kernel_ms / max(1, launches)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "map_se_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "avg_kernel_ms": round(avg_ms, 3), "alg_bytes_per_read": round(alg_bytes / n, 1),
+                "gathers_per_s": round((per_launch["seed_offsets"] * 2 + per_launch["candidates"] * 2 +
+                                        per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        from tests import oracle_binding as ob  # cpu_baseline leg: the oracle is the thing timed here
+        o = ob.load(build=not os.path.exists(ob.LIB))
+        ns = min(n, args.cpu_sample)
+        host_reads = blob[: ns * L].cpu().numpy().reshape(ns, L)
+        seqs = [bytes(r) for r in host_reads]
+        seqs = [b"" if s.count(b"N") > L - 44 else s for s in seqs]
+        oix = o.index_load(idx)
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        o_res, o_cig, o_cn, _ = o.map_se(oix, seqs, mode=0, threads=cores, cig_stride=L + 2)
+        t_cpu = time.perf_counter() - t0
+        o.index_free(oix)
+        g_res = res[:ns].cpu().numpy().view(np.uint32)
+        same = int((g_res[:, 1] == o_res["pos"]).sum())
+        cpu = {"value": round(ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {ns} reads of rank 0's batch, oracle restatement, {cores} threads, {t_cpu:.1f}s",
+               "positions_identical_to_gpu": f"{same}/{ns}"}
+
+    line = {
+        "metric": "mapped reads/sec (whole node), 100 bp SE on hg38-scale index",
+        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp (hg38 unavailable offline), "
+                               f"{n} sim-like reads x {L} bp SE per GPU per step, T-rich mode",
+                   "reads_per_step_per_gpu": n, "read_len": L, "index_gb": round(index.device_bytes / 1e9, 2),
+                   "parallelism": f"reads sharded over {world} GPU(s), index replicated"},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
+                    "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])},
+        "kernel_status": st_host, "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,12 @@ uint32_t abm_max_read_length(void); /* longest read the kernels accept */
  * Feeds the algorithmic-bytes model of SURVEY.md section 8(d). */
 int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[8]);
 
+/* Measurement hook: when enabled, every mapping-kernel launch is bracketed by
+ * HIP events recorded on the stream it is launched on; take_kernel_time waits
+ * for them and returns the number of launches and their summed duration. */
+int abm_ctx_set_timing(abm_ctx *ctx, int enable);
+int abm_ctx_take_kernel_time(abm_ctx *ctx, uint64_t *launches, double *total_ms);
+
 /* Mapping statistics are six counters per struct (src/abismal.cpp:865-895) in
  * up to three structs (pairs, read1, read2: :1034-1037) = 18 x u64.  Sums them
  * over every context in ctxs[] with one RCCL all-reduce (ncclSum over xGMI);

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_ctx_create", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
-    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_stats_allreduce",
+    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_stats_allreduce",
 ]
 
 
@@ -68,6 +68,7 @@ def load_library():
     lib.abm_max_read_length.restype = C.c_uint32
     lib.abm_ctx_take_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.abm_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.abm_ctx_set_phase_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.abm_ctx_take_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     vp = C.c_void_p
     lib.abm_map_se_batch.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp]
@@ -192,7 +193,14 @@ class Context:
         return int(n.value), float(ms.value)
 
     def take_work(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         _check(self._lib.abm_ctx_take_work(self.handle, out))
         keys = ["seed_offsets", "search_probes", "candidates", "read_words", "set_updates", "alignments"]
-        return dict(zip(keys, [int(x) for x in out[:6]]))
+        d = dict(zip(keys, [int(x) for x in out[:6]]))
+        if out[10]:
+            d["phase_cycles"] = dict(zip(["probe_narrow", "gather_hamming", "replay", "align", "total"],
+                                         [int(x) for x in out[6:11]]))
+        return d
+
+    def set_phase_stamps(self, on=True):
+        _check(self._lib.abm_ctx_set_phase_stamps(self.handle, int(on)))

@@ -65,6 +65,7 @@ struct abm_ctx {
   DevBuf<abm::u32> cig, cig_n, status;
   // optional HIP-event timing of the mapping kernel (abm_ctx_set_timing)
   bool timing = false;
+  bool phase_stamps = false;  // launch the diagnostic kernel variant with in-kernel phase stamps
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   std::mutex mu;
@@ -92,7 +93,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
   ctx->packed.reserve(n * 4 * W);
   ctx->lens.reserve(n);
-  ctx->work.reserve(8);
+  ctx->work.reserve(16);
   HIPCHK(abm::launch_pack_reads(d_blob, reinterpret_cast<const abm::u64 *>(d_off), n, W, ctx->packed.p,
                                 ctx->lens.p, st));
   abm::SeArgs a{};
@@ -103,6 +104,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.n_reads = n;
   a.W = W;
   a.WB = WB;
+  a.GW = abm::se_window_words(eff_len, params->valid_frac);
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.res = reinterpret_cast<abm::Hit *>(d_res);
@@ -126,7 +128,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     ++ctx->events_used;
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(abm::launch_map_se(a, eff_len, static_cast<abm::u32>(waves) * 8u, st));
+  HIPCHK(abm::launch_map_se(a, eff_len, static_cast<abm::u32>(waves) * 8u, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
 }
 
@@ -213,8 +215,8 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
       c->dix.index_t = reinterpret_cast<const abm::u32 *>(base + offs[5]);
       c->dix.index_a = reinterpret_cast<const abm::u32 *>(base + offs[6]);
       c->dix.max_candidates = h.max_candidates;
-      c->work.reserve(8);
-      HIPCHK(hipMemset(c->work.p, 0, 8 * sizeof(unsigned long long)));
+      c->work.reserve(16);
+      HIPCHK(hipMemset(c->work.p, 0, 16 * sizeof(unsigned long long)));
     }
     catch (...) { abm_ctx_destroy(c); throw; }
     *out = c;
@@ -233,14 +235,22 @@ void abm_ctx_destroy(abm_ctx *c) {
 
 // work tallies accumulated by every launch since the last read (reset on read):
 // seed_iters, search probes, candidates, read words compared, set updates, alignments
-int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[8]) {
+int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->phase_stamps = enable != 0;
+  });
+}
+
+int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[16]) {
   return guarded([&] {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
-    unsigned long long tmp[8];
+    unsigned long long tmp[16];
     HIPCHK(hipMemcpy(tmp, ctx->work.p, sizeof(tmp), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(ctx->work.p, 0, sizeof(tmp)));
-    for (int k = 0; k < 8; ++k) out[k] = tmp[k];
+    for (int k = 0; k < 16; ++k) out[k] = tmp[k];
   });
 }
 

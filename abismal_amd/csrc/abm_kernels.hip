@@ -55,64 +55,65 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 
 // =============================================================================
 // Wave-resident single-end candidate set (se_candidates, src/abismal.cpp:334-449).
-// Heap slot k lives in lane k (k < 50); everything else is wave-uniform.
+// The heap array lives across lanes: lane k holds heap slot k as one packed key
+// diffs*256 + payload_slot; (flags,pos) payloads never move -- lane p holds the
+// payload whose slot number is p.  A sift step therefore moves one register.
 // =============================================================================
 struct SeSet {
-  int hd;   // per lane: diffs of slot
-  u32 hf;   // per lane: flags of slot
-  u32 hp;   // per lane: pos of slot
+  int hk;   // per lane k: heap[k] = diffs*256 + payload slot
+  u32 pf;   // per lane p: flags of payload p
+  u32 pp;   // per lane p: pos of payload p
   int sz, cutoff, good_cutoff;
   int best_d;
   u32 best_f, best_p;
   bool sure_ambig;
 
+  __device__ __forceinline__ static int key_d(int k) { return k >> 8; }
   __device__ __forceinline__ void begin_read(u32 readlen) {
     const int worst = static_cast<i16>(0.4 * readlen);  // se_element::reset(readlen), :292-296
-    hd = worst; hf = 0; hp = 0;
+    hk = worst * 256; pf = 0; pp = 0;  // sentinel: heap[0] -> payload 0 = {pos 0}
     sz = 1;
     cutoff = worst;
     good_cutoff = static_cast<i16>(readlen / 10u);
     best_d = worst; best_f = 0; best_p = 0;
     sure_ambig = false;
   }
-  __device__ __forceinline__ void move_slot(int dst, int src) {
-    const int d = rdlane(hd, src);
-    const u32 f = rdlane(hf, src), p = rdlane(hp, src);
-    wrlane(hd, dst, d); wrlane(hf, dst, f); wrlane(hp, dst, p);
-  }
-  __device__ __forceinline__ void put_slot(int dst, int d, u32 f, u32 p) {
-    wrlane(hd, dst, d); wrlane(hf, dst, f); wrlane(hp, dst, p);
-  }
-  // libstdc++ __push_heap with value (d,f,p) entering at `hole`, comparator diffs<
-  __device__ __forceinline__ void sift_up(int hole, int d, u32 f, u32 p) {
+  __device__ __forceinline__ int top_d() const { return key_d(rdlane(hk, 0)); }
+  // libstdc++ __push_heap with `key` entering at `hole`, comparator diffs<
+  __device__ __forceinline__ void sift_up(int hole, int key) {
     int parent = (hole - 1) / 2;
-    while (hole > 0 && rdlane(hd, parent) < d) {
-      move_slot(hole, parent);
+    while (hole > 0) {
+      const int pk = rdlane(hk, parent);
+      if (!(key_d(pk) < key_d(key))) break;
+      wrlane(hk, hole, pk);
       hole = parent;
       parent = (hole - 1) / 2;
     }
-    put_slot(hole, d, f, p);
+    wrlane(hk, hole, key);
   }
-  // libstdc++ pop_heap on [0,n) followed by overwriting slot n-1 and push_heap:
-  // only the __adjust_heap of the displaced last element matters here
-  __device__ __forceinline__ void pop_max(int n) {
+  // libstdc++ pop_heap on [0,n): returns the payload slot of the evicted maximum;
+  // the caller overwrites heap[n-1] and pushes, so only __adjust_heap of the
+  // displaced last element is performed here
+  __device__ __forceinline__ int pop_max(int n) {
     const int len = n - 1;
-    const int vd = rdlane(hd, len);
-    const u32 vf = rdlane(hf, len), vp = rdlane(hp, len);
+    const int freed = rdlane(hk, 0) & 255;
+    const int vk = rdlane(hk, len);
     int hole = 0, second = 0;
     while (second < (len - 1) / 2) {
       second = 2 * (second + 1);
-      if (rdlane(hd, second) < rdlane(hd, second - 1))
-        --second;
-      move_slot(hole, second);
+      int sk = rdlane(hk, second);
+      const int lk = rdlane(hk, second - 1);
+      if (key_d(sk) < key_d(lk)) { --second; sk = lk; }
+      wrlane(hk, hole, sk);
       hole = second;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
       second = 2 * (second + 1);
-      move_slot(hole, second - 1);
+      wrlane(hk, hole, rdlane(hk, second - 1));
       hole = second - 1;
     }
-    sift_up(hole, vd, vf, vp);
+    sift_up(hole, vk);
+    return freed;
   }
   // se_candidates::update, :394-404
   __device__ __forceinline__ void admit(bool specific, int d, u32 f, u32 p) {
@@ -121,12 +122,15 @@ struct SeSet {
       else if (p != best_p || f != best_f) best_f |= kFlagAmbig;
     }
     else {
-      if (sz == static_cast<int>(kSeCap)) pop_max(sz);
-      else ++sz;
-      sift_up(sz - 1, d, f, p);
+      int slot;
+      if (sz == static_cast<int>(kSeCap)) slot = pop_max(sz);
+      else slot = sz++;
+      wrlane(pf, slot, f);
+      wrlane(pp, slot, p);
+      sift_up(sz - 1, d * 256 + slot);
     }
     sure_ambig = (best_f & kFlagAmbig) && best_d == 0;
-    const int top = rdlane(hd, 0);
+    const int top = top_d();
     cutoff = specific ? min(cutoff, top) : top;
   }
 };
@@ -138,8 +142,13 @@ struct WaveLds {
   u16 *mark;   // [64]
   u32 *ctmp;   // [cig_stride] reversed CIGAR scratch
   u8 *tb;      // traceback bytes
-  u32 W, WB;
+  u64 *gwin;   // [kMaxJobs][GW] genome windows of the alignments in flight
+  u32 *jpos;   // [kSeCap] alignment job list: position
+  u32 *jdf;    // [kSeCap] alignment job list: diffs<<16 | flags
+  int *lbest;  // [64]
+  u32 W, WB, GW;
 };
+constexpr u32 kMaxJobs = 21;  // 64 lanes / narrowest band (3)
 
 __device__ __forceinline__ u32 q_nibble(const u64 *qpk, u32 k) {
   return static_cast<u32>(qpk[k >> 4] >> ((k & 15u) << 2)) & 15u;
@@ -229,9 +238,14 @@ __device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
 // candidates (all checked buckets of 64 offsets flattened in reference order)
 // for the Hamming filter; survivors are replayed in order into the set.
-struct WorkTally { u32 seed_iters, probes, cands, words, updates; };
+struct WorkTally {
+  u32 seed_iters, probes, cands, words, updates;
+  // diagnostic build only (TIMED): shader cycles per phase, from s_memtime
+  long long t_probe, t_stream, t_replay, t_align, t_total;
+};
+#define ABM_STAMP(var) do { if (TIMED) var = clock64(); } while (0)
 
-template <bool SPECIFIC>
+template <bool SPECIFIC, bool TIMED>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
                                           u32 flags, u32 L, SeSet &S, WorkTally &wt) {
   const int lane = lane_id();
@@ -244,7 +258,9 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   const u32 spec_len = min(L - kWindow, L >> 1);
   const u32 n_off = SPECIFIC ? max(kWindow, L >> 1) : L - kKeyWeight + 1;
 
+  long long ta = 0, tb_ = 0, tc = 0, td = 0;
   for (u32 g0 = 0; g0 < n_off && !S.sure_ambig; g0 += 64) {
+    ABM_STAMP(ta);
     const u32 i = g0 + lane;
     const bool live = i < n_off;
     u32 lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0;
@@ -281,10 +297,13 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     const u32 na = chk2 ? hi2 - lo2 : 0u, nb = chk3 ? hi3 - lo3 : 0u;
     u32 total;
     const u32 start_a = wave_excl_sum(na + nb, total), start_b = start_a + na;
+    ABM_STAMP(tb_);
+    if (TIMED) wt.t_probe += tb_ - ta;
 
     int carry = 0;
     for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 64) {
       // which (offset, table) segment does each of these 64 candidates belong to
+      ABM_STAMP(tc);
       lds.mark[lane] = 0;
       __syncthreads();
       if (na && start_a - c0 < 64u) lds.mark[start_a - c0] = static_cast<u16>(2 * lane + 1);
@@ -310,6 +329,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       }
       // ordered replay (check_hits + se_candidates::update, :1133-1149, :394-404)
       u64 todo = __ballot(valid && h <= S.cutoff);
+      ABM_STAMP(td);
+      if (TIMED) wt.t_stream += td - tc;
       while (todo && !S.sure_ambig) {
         const int l = __builtin_ctzll(todo);
         const int before = S.cutoff;
@@ -318,89 +339,121 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         todo &= ~(((1ull << l) << 1) - 1);
         if (S.cutoff < before) todo &= __ballot(valid && h <= S.cutoff);
       }
+      ABM_STAMP(tc);
+      if (TIMED) wt.t_replay += tc - td;
     }
   }
 }
 
 // =============================================================================
-// Banded local alignment on a wave (AbismalAlign::align, src/AbismalAlign.hpp:320-386).
-// Lane j is band column j; rows advance serially; the in-row insertion chain
-// (from_left) is a max-plus prefix scan.  With TB the arrows go to LDS and the
-// first maximum in row-major order is returned in (best_r, best_c).
+// Banded local alignment (AbismalAlign::align, src/AbismalAlign.hpp:320-386) as
+// an anti-diagonal wavefront.  Cell (i,j) of the reference's band table (row i =
+// target base t_beg+i-1, column j, read index q = i+j-bw) depends on (i-1,j)
+// [substitution], (i-1,j+1) [from_above] and (i,j-1) [from_left]; on the
+// anti-diagonal t = 2i+j all three are already known, from the same lane two
+// steps ago and from the two neighbouring lanes one step ago.  So lane = band
+// column, one DPP move per neighbour per step, and no in-row scan.  A band is
+// at most 61 lanes wide and usually ~21 (2*min(diffs,max_diffs)+1), so several
+// candidate alignments ("jobs") share one wave side by side.
+// Cell validity (left/right of the reference's row loop) reduces to 0 <= q < L;
+// invalid cells read as 0, exactly like the zero-filled table.
 // =============================================================================
 __device__ __forceinline__ int band_for(int diffs, int max_diffs) {
   const int v = 2 * min(diffs, max_diffs) + 1;
   return v < 0 ? static_cast<int>(kMaxBand) : min(static_cast<int>(kMaxBand), v);
 }
+__device__ __forceinline__ int from_prev_lane(int v) {  // lane j <- lane j-1 (lane 0 <- 0)
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int from_next_lane(int v) {  // lane j <- lane j+1 (lane 63 <- 0)
+  return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+}
 
+// 16 nibbles starting at nibble index `start` of an LDS word array; nibbles
+// outside [0, 16*nwords) read as 0 (they only ever feed invalid cells)
+__device__ __forceinline__ u64 nibbles16(const u64 *words, int nwords, int start) {
+  if (start <= -16 || start >= 16 * nwords)
+    return 0ull;
+  if (start < 0)
+    return words[0] << ((-start) << 2);
+  const int w = start >> 4, s = (start & 15) << 2;
+  u64 x = words[w] >> s;
+  if (s && w + 1 < nwords) x |= words[w + 1] << (64 - s);
+  return x;
+}
+
+struct AlnJob {  // per lane: the job whose band column this lane is
+  int bw;        // 0 = lane unassigned
+  int jl;        // column within the band
+  int qoff;      // word offset of the query encoding in lds.qpk
+  int g;         // genome-window slot in lds.gwin
+  int t0nib;     // t_beg & 15: nibble offset of row 1's target base inside the window
+};
+
+// Runs every job assigned in `job` to completion.  Returns, per lane, the best
+// cell value of its own column (and its first row); with TB also stores one
+// byte per cell: arrow (0 M, 1 I, 2 D, 3 none) | 4 if the cell's score is > 0.
 template <bool TB>
-__device__ __forceinline__ int wave_align(const u64 *__restrict__ genome, const u64 *qpk, u32 W, int L,
-                                          int diffs, int max_diffs, u32 t_pos, u8 *tb, int &best_r,
-                                          int &best_c) {
-  const int lane = lane_id();
-  best_r = best_c = 0;
-  if (diffs == 0)
-    return static_cast<i16>(2 * L);
-  const int bw = band_for(diffs, max_diffs);
-  const int rows = L + bw;
-  const u64 t0 = static_cast<u64>(t_pos) - static_cast<u64>((bw - 1) / 2);
-  const u64 gw0 = t0 >> 4;
-  const int ngw = static_cast<int>(((t0 + rows - 2) >> 4) - gw0) + 1;  // <= 64 for L <= kMaxReadLen
-  const u64 gw = lane < ngw ? genome[gw0 + lane] : 0ull;
-  const u64 qw = lane < static_cast<int>(W) ? qpk[lane] : 0ull;
-  constexpr int NEG = -(1 << 20);
-
-  if (TB && lane < bw) tb[lane] = 3;  // row 0: no arrow, score 0
-  int prev = 0, qv = 0, bestv = 0, bestrow = 0;
-  for (int i = 1; i < rows; ++i) {
-    const u64 tk = t0 + static_cast<u64>(i - 1);
-    const int t = static_cast<int>(rdlane(gw, static_cast<int>((tk >> 4) - gw0)) >> ((tk & 15u) << 2)) & 15;
-    const int qi = i - 1;  // read base entering the band at its last column
-    const int qn = qi < L ? static_cast<int>(rdlane(qw, qi >> 4) >> ((qi & 15) << 2)) & 15 : 0;
-    qv = __shfl_down(qv, 1);
-    if (lane == bw - 1) qv = qn;
-    const int left = i < bw ? bw - i : 0, right = min(bw, rows - i);
-    const bool valid = lane >= left && lane < right;
-    const int up = __shfl_down(prev, 1);
-    const int sdiag = prev + ((qv & t) ? 2 : -3);
+__device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job, int L, int bw_min,
+                                          int bw_max, int &bestv, int &bestrow) {
+  const int jl = job.jl, bw = job.bw;
+  const bool assigned = bw != 0;
+  const u64 *qw = lds.qpk + job.qoff;
+  const u64 *gw = lds.gwin + job.g * lds.GW;
+  const int t_start = max(0, bw_min - 1), t_end = 2 * (L - 1 + bw_max);
+  int cur = 0;
+  u64 M = 0;
+  bestv = 0; bestrow = 0;
+  for (int t = t_start; t <= t_end; ++t) {
+    if (((t - t_start) & 31) == 0) {
+      // match bits for this lane's next 16 cells: nibble k set <=> q[i0+k+jl-bw] & T[i0+k-1] != 0
+      const int ta = t + ((t - jl) & 1);
+      const int i0 = (ta - jl) >> 1;
+      u64 x = 0;
+      if (assigned)
+        x = nibbles16(qw, static_cast<int>(lds.W), i0 + jl - bw) &
+            nibbles16(gw, static_cast<int>(lds.GW), job.t0nib + i0 - 1);
+      x |= x >> 1;
+      x |= x >> 2;
+      M = x & 0x1111111111111111ull;
+    }
+    const int dlt = t - jl;
+    const bool active = assigned && (dlt & 1) == 0;
+    const int i = dlt >> 1;
+    const int q = i + jl - bw;
+    const bool valid = active && q >= 0 && q < L;
+    const int lf = from_prev_lane(cur), up = from_next_lane(cur);
+    const int sdiag = cur + ((static_cast<u32>(M) & 1u) ? 2 : -3);
     int c = max(sdiag, 0);
     int arrow = (c == sdiag) ? 0 : 3;
-    const int sabove = up - 4;
-    if (lane + 1 < right) {
-      c = max(c, sabove);
-      if (c == sabove) arrow = 2;
+    if (jl < bw - 1 && q < L - 1) {   // from_above: j in [left, right-1)
+      const int s = up - 4;
+      c = max(c, s);
+      if (TB && c == s) arrow = 2;
     }
-    // from_left: cur[j] = max(cur[j], cur[j-1]-4) sequentially == prefix max of c[k]+4k
-    int u = valid ? c + 4 * lane : NEG;
-    u = wave_incl_max(u);
-    const int f = u - 4 * lane;
-    const int cur = valid ? f : 0;
-    if (TB) {
-      const int lf = __shfl_up(cur, 1) - 4;
-      if (lane > left && cur == lf) arrow = 1;
-      if (lane < bw) tb[i * bw + lane] = static_cast<u8>(valid ? (arrow | (cur > 0 ? 4 : 0)) : 3);
+    if (jl > 0 && q > 0) {            // from_left: j in [left+1, right)
+      const int s = lf - 4;
+      c = max(c, s);
+      if (TB && c == s) arrow = 1;
     }
-    if (cur > bestv) { bestv = cur; bestrow = i; }
-    prev = cur;
+    if (active) {
+      M >>= 4;
+      cur = valid ? c : 0;
+      if (valid && c > bestv) { bestv = c; bestrow = i; }
+      if (TB && i >= 0 && i < L + bw)
+        lds.tb[i * bw + jl] = static_cast<u8>(valid ? (arrow | (c > 0 ? 4 : 0)) : 3);
+    }
   }
-  // first maximum in row-major order: max value, then smallest row, then smallest column
-  const u64 key = (static_cast<u64>(static_cast<u32>(bestv)) << 32) |
-                  (static_cast<u64>(0xFFFFu - static_cast<u32>(bestrow)) << 8) |
-                  static_cast<u64>(0xFFu - static_cast<u32>(lane));
-  const u64 top = wave_max_u64(lane < bw ? key : 0ull);
-  best_r = static_cast<int>(0xFFFFu - static_cast<u32>((top >> 8) & 0xFFFFu));
-  best_c = static_cast<int>(0xFFu - static_cast<u32>(top & 0xFFu));
-  return static_cast<i16>(static_cast<int>(top >> 32));
 }
 
 // build_cigar_len_and_pos + get_traceback (src/AbismalAlign.hpp:166-193, :388-440).
 // Runs uniformly on the wave; ops are collected reversed in LDS then emitted.
 __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int diffs, int max_diffs,
                                            int score, int best_r, int best_c, u32 *cig_out,
-                                           u32 cig_stride, u32 &n_ops, u32 &n_body, u32 &aln_len,
+                                           u32 cig_stride, u32 &n_ops, int &ins, int &del, u32 &aln_len,
                                            u32 &t_pos, bool &overflow) {
   const int lane = lane_id();
-  n_body = 0;  // I/D/M runs left in ctmp[] (reversed), for the NM computation
+  ins = del = 0;  // count_total_ops<I>/<D> with oplen() narrowed to uint8_t (abismal_cigar_utils.hpp:50-53)
   if (score == 0 || diffs == 0) {
     if (lane == 0) cig_out[0] = static_cast<u32>(L) << 4;
     n_ops = 1;
@@ -414,6 +467,8 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   auto emit = [&](u32 run, int op) {
     if (n < cig_stride) { if (lane == 0) ctmp[n] = (run << 4) | static_cast<u32>(op); }
     else overflow = true;
+    if (op == 1) ins = static_cast<i16>(ins + static_cast<int>(static_cast<u8>(run)));
+    if (op == 2) del = static_cast<i16>(del + static_cast<int>(static_cast<u8>(run)));
     ++n;
   };
   auto step = [&](int a) {
@@ -449,23 +504,15 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
     cig_out[k] = v;
   }
   n_ops = total;
-  n_body = body;
   aln_len = static_cast<u32>(L - clip_tail - clip_head);
   t_pos = t_pos - static_cast<u32>((bw - 1) / 2) + static_cast<u32>(r);
 }
 
 // simple_aln::edit_distance with the reference's integer types
-// (src/AbismalAlign.hpp:73-89; oplen() narrows to uint8_t, abismal_cigar_utils.hpp:50-53)
-__device__ __forceinline__ int edit_distance(int scr, u32 len, const u32 *cig, u32 n_ops) {
+// (src/AbismalAlign.hpp:73-89); ins/del are the op totals gathered in wave_cigar
+__device__ __forceinline__ int edit_distance(int scr, u32 len, int ins, int del) {
   if (scr == 0)
     return static_cast<i16>(len);
-  int ins = 0, del = 0;
-  for (u32 k = 0; k < n_ops; ++k) {
-    const u32 x = cig[k];
-    const int oplen = static_cast<u8>(x >> 4);
-    if ((x & 15u) == 1u) ins = static_cast<i16>(ins + oplen);
-    if ((x & 15u) == 2u) del = static_cast<i16>(del + oplen);
-  }
   const int A = static_cast<i16>(scr + 4 * (ins + del));
   const u32 num = 2u * (len - static_cast<u32>(ins)) - static_cast<u32>(A);
   const int mism = static_cast<i16>(num / 5u);
@@ -483,6 +530,35 @@ __device__ __forceinline__ u32 enc_of(u32 flags) {
   return rc * 2u + (rc ^ ar);
 }
 
+// Stage the genome windows of jobs [first, first+n) of the LDS job list into
+// lds.gwin (one coalesced sweep, loads issued before the stores)
+__device__ __forceinline__ void stage_windows(const DevIndex &ix, const WaveLds &lds, int first, int n,
+                                              int md) {
+  const int lane = lane_id();
+  const int GW = static_cast<int>(lds.GW), total = n * GW;
+  for (int k0 = 0; k0 < total; k0 += 256) {
+    u64 v[4];
+    int at[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + lane + 64 * r;
+      at[r] = -1;
+      v[r] = 0;
+      if (k < total) {
+        const int g = k / GW, w = k - g * GW;
+        const u32 pos = lds.jpos[first + g];
+        const int bw = band_for(static_cast<int>(lds.jdf[first + g]) >> 16, md);
+        const u64 t_beg = static_cast<u64>(pos) - static_cast<u64>((bw - 1) / 2);
+        v[r] = ix.genome[(t_beg >> 4) + w];
+        at[r] = k;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (at[r] >= 0) lds.gwin[at[r]] = v[r];
+  }
+}
+
 // align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
 __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
                                           SeSet &S, Hit &best, u32 *cig_out, u32 cig_stride,
@@ -498,56 +574,118 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
     n_ops = 1;
     return;
   }
-  // prepare_for_alignments: order by (pos, flags), drop duplicates
+  // prepare_for_alignments: order by (pos, flags), drop duplicates.  Lane k looks
+  // at heap entry k; its payload sits in lane (key & 255).
   const bool mine = lane < S.sz;
-  const u64 key = (static_cast<u64>(S.hp) << 16) | S.hf;
+  const int slot_of = S.hk & 255;
+  const u32 e_pos = __shfl(S.pp, slot_of), e_flags = __shfl(S.pf, slot_of);
+  const int e_d = SeSet::key_d(S.hk);
+  const u64 key = (static_cast<u64>(e_pos) << 16) | e_flags;
   bool dup = false;
   for (int k = 0; k < S.sz; ++k) {
     const u64 kk = rdlane(key, k);
     dup |= (mine && k < lane && kk == key);
   }
-  const u64 uniq = __ballot(mine && !dup);
-  int slot = 0;
+  // jobs = unique entries that the reference would align: non-empty, diffs < 0.4L
+  const int invalid_at = static_cast<i16>(0.4 * Ls);  // valid_hit, :323-326
+  const bool is_job = mine && !dup && e_pos != 0 && e_d < invalid_at;
+  const u64 jobs = __ballot(is_job);
+  int rank = 0;
   for (int k = 0; k < S.sz; ++k) {
     const u64 kk = rdlane(key, k);
-    slot += ((uniq >> k) & 1) && kk < key;
+    rank += ((jobs >> k) & 1) && kk < key;
   }
-  const int n_uniq = __popcll(uniq);
-  const int invalid_at = static_cast<i16>(0.4 * Ls);  // valid_hit, :323-326
+  const int n_jobs = __popcll(jobs);
+  if (is_job) {
+    lds.jpos[rank] = e_pos;
+    lds.jdf[rank] = (static_cast<u32>(e_d) << 16) | e_flags;
+  }
+  __syncthreads();
 
   int top = 0;
   u32 top_pos = 0, b_pos = 0, b_flags = 0;
   int b_diffs = 0x7fff;
-  int dummy_r, dummy_c;
-  for (int s = 0; s < n_uniq; ++s) {
-    const u64 who = __ballot(mine && !dup && slot == s);
-    const int l = __builtin_ctzll(who);
-    const u32 pos = rdlane(S.hp, l), flags = rdlane(S.hf, l);
-    const int d = rdlane(S.hd, l);
-    if (pos == 0 || !(d < invalid_at))
-      continue;
-    const int sc = wave_align<false>(ix.genome, lds.qpk + enc_of(flags) * lds.W, lds.W, static_cast<int>(L),
-                                     d, md, pos, lds.tb, dummy_r, dummy_c);
-    ++n_aln;
-    if (sc > top) { b_diffs = d; b_flags = flags; b_pos = pos; top = sc; top_pos = pos; }
-    else if (sc == top) {
-      const u32 gap = pos > top_pos ? pos - top_pos : top_pos - pos;
-      if (sc == perfect ? pos != top_pos : gap > 3u) b_flags |= kFlagAmbig;
+  for (int s = 0; s < n_jobs;) {
+    // pack consecutive jobs side by side until the wave is full
+    AlnJob job = {0, 0, 0, 0, 0};
+    int used = 0, first = s, bw_min = 64, bw_max = 0;
+    while (s < n_jobs) {
+      const u32 df = lds.jdf[s];
+      const int bw = band_for(static_cast<int>(df) >> 16, md);
+      if (used + bw > 64) break;
+      if (lane >= used && lane < used + bw) {
+        const u64 t_beg = static_cast<u64>(lds.jpos[s]) - static_cast<u64>((bw - 1) / 2);
+        job.bw = bw;
+        job.jl = lane - used;
+        job.qoff = static_cast<int>(enc_of(df & 0xFFFFu) * lds.W);
+        job.g = s - first;
+        job.t0nib = static_cast<int>(t_beg & 15u);
+      }
+      used += bw;
+      bw_min = min(bw_min, bw);
+      bw_max = max(bw_max, bw);
+      ++s;
     }
+    stage_windows(ix, lds, first, s - first, md);
+    __syncthreads();
+    int bv, br;
+    wavefront<false>(lds, job, static_cast<int>(L), bw_min, bw_max, bv, br);
+    lds.lbest[lane] = bv;
+    __syncthreads();
+    // fold each band's columns; then apply the reference's selection in job order
+    int base = 0;
+    for (int k = first; k < s; ++k) {
+      const u32 df = lds.jdf[k];
+      const int d = static_cast<int>(df) >> 16;
+      const int bw = band_for(d, md);
+      int sc = lane < bw ? lds.lbest[base + lane] : 0;
+      sc = static_cast<i16>(static_cast<int>(wave_max_u64(static_cast<u64>(static_cast<u32>(sc)))));
+      base += bw;
+      const u32 pos = lds.jpos[k], flags = df & 0xFFFFu;
+      ++n_aln;
+      if (sc > top) { b_diffs = d; b_flags = flags; b_pos = pos; top = sc; top_pos = pos; }
+      else if (sc == top) {
+        const u32 gap = pos > top_pos ? pos - top_pos : top_pos - pos;
+        if (sc == perfect ? pos != top_pos : gap > 3u) b_flags |= kFlagAmbig;
+      }
+    }
+    __syncthreads();
   }
   best.diffs = 0x7fff; best.flags = static_cast<u16>(b_flags); best.pos = 0;
   if (b_pos == 0)
     return;
-  int br, bc;
-  const int sc = wave_align<true>(ix.genome, lds.qpk + enc_of(b_flags) * lds.W, lds.W, static_cast<int>(L),
-                                  b_diffs, md, b_pos, lds.tb, br, bc);
+  // traceback run of the winner: one job, band in lanes [0, bw)
+  const int bw = band_for(b_diffs, md);
+  AlnJob job = {0, 0, 0, 0, 0};
+  const u64 t_beg = static_cast<u64>(b_pos) - static_cast<u64>((bw - 1) / 2);
+  if (lane < bw) {
+    job.bw = bw;
+    job.jl = lane;
+    job.qoff = static_cast<int>(enc_of(b_flags) * lds.W);
+    job.t0nib = static_cast<int>(t_beg & 15u);
+  }
+  if (lane == 0) { lds.jpos[0] = b_pos; lds.jdf[0] = (static_cast<u32>(b_diffs) << 16) | (b_flags & 0xFFFFu); }
   __syncthreads();
-  u32 alen = 0, pos = b_pos, n_body = 0;
+  stage_windows(ix, lds, 0, 1, md);
+  __syncthreads();
+  int bv, brow;
+  wavefront<true>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
+  // first maximum in row-major order: max value, then smallest row, then smallest column
+  const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
+                  (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |
+                  static_cast<u64>(0xFFu - static_cast<u32>(lane));
+  const u64 topk = wave_max_u64(lane < bw ? k64 : 0ull);
+  const int br = static_cast<int>(0xFFFFu - static_cast<u32>((topk >> 8) & 0xFFFFu));
+  const int bc = static_cast<int>(0xFFu - static_cast<u32>(topk & 0xFFu));
+  const int sc = static_cast<i16>(static_cast<int>(topk >> 32));
+  __syncthreads();
+  u32 alen = 0, pos = b_pos;
+  int n_ins = 0, n_del = 0;
   wave_cigar(lds.tb, lds.ctmp, static_cast<int>(L), b_diffs, md, sc, br, bc, cig_out, cig_stride, n_ops,
-             n_body, alen, pos, overflow);
+             n_ins, n_del, alen, pos, overflow);
   __syncthreads();
   // NM from the score found by the scoring pass (best_scr), as the reference does
-  const int nm = edit_distance(top, alen, lds.ctmp, n_body);
+  const int nm = edit_distance(top, alen, n_ins, n_del);
   if (long_enough(alen, static_cast<u32>(Ls)) && nm <= md) {
     best.diffs = static_cast<i16>(nm);
     best.pos = pos;
@@ -559,6 +697,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
+template <bool TIMED>
 __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -566,9 +705,14 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
   lds.W = a.W;
   lds.WB = a.WB;
   lds.qpk = reinterpret_cast<u64 *>(smem);
+  lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
-  lds.ctmp = reinterpret_cast<u32 *>(lds.qbits + 4 * a.WB);
-  lds.mark = reinterpret_cast<u16 *>(lds.ctmp + a.cig_stride);
+  lds.gwin = lds.qbits + 4 * a.WB;
+  lds.ctmp = reinterpret_cast<u32 *>(lds.gwin + kMaxJobs * a.GW);
+  lds.jpos = lds.ctmp + a.cig_stride;
+  lds.jdf = lds.jpos + kSeCap;
+  lds.lbest = reinterpret_cast<int *>(lds.jdf + kSeCap);
+  lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
   lds.tb = reinterpret_cast<u8 *>(lds.mark + 64);
 
   // (rc, a_rich) calls per mode, in the reference's order
@@ -577,7 +721,9 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
   const u32 call_rc = a.mode == 2 ? 0xCu /*0,0,1,1*/ : 0x2u /*0,1*/;
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
-  WorkTally wt = {0, 0, 0, 0, 0};
+  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_begin = 0, t_a = 0, t_b = 0;
+  ABM_STAMP(t_begin);
   u32 n_aln = 0;
   bool overflow = false, too_long = false;
 
@@ -610,14 +756,17 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        seed_pass<true>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
+        seed_pass<true, TIMED>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
         // should_do_sensitive, :367-370
         if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
-          S.cutoff = rdlane(S.hd, 0);  // set_sensitive
-          seed_pass<false>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
+          S.cutoff = S.top_d();  // set_sensitive
+          seed_pass<false, TIMED>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
         }
       }
+      ABM_STAMP(t_a);
       choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, a.cig_stride, n_ops, overflow, n_aln);
+      ABM_STAMP(t_b);
+      if (TIMED) wt.t_align += t_b - t_a;
     }
     if (lane == 0) {
       a.res[r] = best;
@@ -634,6 +783,13 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
       atomicAdd(&a.work[3], static_cast<unsigned long long>(s3));
       atomicAdd(&a.work[4], static_cast<unsigned long long>(wt.updates));
       atomicAdd(&a.work[5], static_cast<unsigned long long>(n_aln));
+      if (TIMED) {
+        atomicAdd(&a.work[6], static_cast<unsigned long long>(wt.t_probe));
+        atomicAdd(&a.work[7], static_cast<unsigned long long>(wt.t_stream));
+        atomicAdd(&a.work[8], static_cast<unsigned long long>(wt.t_replay));
+        atomicAdd(&a.work[9], static_cast<unsigned long long>(wt.t_align));
+        atomicAdd(&a.work[10], static_cast<unsigned long long>(clock64() - t_begin));
+      }
     }
   }
   if (lane == 0 && (overflow || too_long))
@@ -641,12 +797,22 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
 }
 
 // ---- launchers ----------------------------------------------------------------
+u32 se_window_words(u32 max_len, double valid_frac) {
+  const int md = static_cast<i16>(valid_frac * max_len);
+  int bw = 2 * md + 1;
+  if (bw > static_cast<int>(kMaxBand) || bw < 1) bw = kMaxBand;
+  return ((max_len + bw + 15 + 15) >> 4) + 1;
+}
+
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac) {
   const int md = static_cast<i16>(valid_frac * max_len);
   int bw = 2 * md + 1;
   if (bw > static_cast<int>(kMaxBand) || bw < 0) bw = kMaxBand;
   if (bw < 1) bw = 1;
-  size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + static_cast<size_t>(cig_stride) * 4 + 64 * 2;
+  const u32 GW = se_window_words(max_len, valid_frac);
+  size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 +
+             static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
+             2 * kSeCap * 4 + 64 * 4 + 64 * 2;
   b += static_cast<size_t>(max_len + bw) * bw;
   return (b + 15) & ~static_cast<size_t>(15);
 }
@@ -655,7 +821,7 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel, 64,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false>, 64,
                                                    se_lds_bytes(W, WB, cig_stride, max_len, valid_frac)) != hipSuccess)
     return 0;
   return per_cu * prop.multiProcessorCount;
@@ -670,11 +836,12 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
   return hipGetLastError();
 }
 
-hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, hipStream_t st) {
+hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st) {
   if (a.n_reads == 0) return hipSuccess;
   const size_t lds = se_lds_bytes(a.W, a.WB, a.cig_stride, max_len, a.valid_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
-  hipLaunchKernelGGL(map_se_kernel, dim3(blocks), dim3(64), lds, st, a);
+  if (timed) hipLaunchKernelGGL(map_se_kernel<true>, dim3(blocks), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL(map_se_kernel<false>, dim3(blocks), dim3(64), lds, st, a);
   return hipGetLastError();
 }
 

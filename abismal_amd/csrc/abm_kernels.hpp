@@ -10,7 +10,7 @@ struct SeArgs {
   const u64 *packed;  // [n][4][W]
   const u32 *lens;    // [n]
   u64 n_reads;
-  u32 W, WB;          // words per packed encoding / per 2-letter bit string
+  u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
   int mode;           // ABM_SE_*
   double valid_frac;
   Hit *res;           // [n]
@@ -18,14 +18,15 @@ struct SeArgs {
   u32 cig_stride;
   u32 *cig_n;         // [n]
   u32 *status;        // ABM_STATUS_* bits
-  unsigned long long *work;  // optional [8]: seed_iters, search probes, candidates,
+  unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments
 };
 
+u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,
                              u32 *d_lens, hipStream_t st);
-hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, hipStream_t st);
+hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st);
 int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 
 }  // namespace abm

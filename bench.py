@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ABM_BENCH_CPU_SAMPLE", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-stamps", action="store_true",
+                    help="after the timed region, run one extra step of the diagnostic kernel and report phase shares")
     ap.add_argument("--workdir", default=os.environ.get("ABM_BENCH_DIR", "/tmp/abismal_bench"))
     args = ap.parse_args()
 
@@ -261,6 +263,15 @@ def main():
     launches, kernel_ms = ctx.take_kernel_time()
     work = ctx.take_work()
     ctx.set_timing(False)
+    phases = None
+    if args.phase_stamps:
+        ctx.set_phase_stamps(True)
+        step()
+        torch.cuda.synchronize()
+        pc = ctx.take_work().get("phase_cycles")
+        ctx.set_phase_stamps(False)
+        if pc:
+            phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
 
     # mapping statistics (six counters, src/abismal.cpp:865-895) reduced over ranks
     pos = res[:, 1]
@@ -338,6 +349,8 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                     "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])},
+        "work_per_read": {k: round(v / n, 2) for k, v in per_launch.items()},
+        "phase_shares_diagnostic": phases,
         "kernel_status": st_host, "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
     }
     print(json.dumps(line), flush=True)

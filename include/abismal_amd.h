@@ -117,7 +117,12 @@ uint32_t abm_max_read_length(void); /* longest read the kernels accept */
  * [0] seed offsets probed, [1] bucket-narrowing search probes, [2] candidates
  * compared, [3] read words compared, [4] candidate-set updates, [5] alignments.
  * Feeds the algorithmic-bytes model of SURVEY.md section 8(d). */
-int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[8]);
+int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[16]);
+/* Diagnostic build of the mapping kernel: adds s_memtime stamps per phase;
+ * take_work then also returns summed shader cycles in [6] probe+narrow,
+ * [7] candidate gather+Hamming, [8] ordered replay, [9] alignment, [10] total.
+ * Never enable it for a run whose time is quoted. */
+int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable);
 
 /* Measurement hook: when enabled, every mapping-kernel launch is bracketed by
  * HIP events recorded on the stream it is launched on; take_kernel_time waits

@@ -60,3 +60,32 @@ def test_se_trex_10k(oracle, trex_index, gpu_ctx, trex_se_reads, mode):
     compare_se(res, cig, cig_off, o_res, o_cig, o_cig_n, reads, f"tRex1 SE mode {mode}")
     mapped = int((res["pos"] != 0).sum())
     assert mapped > 0.8 * len(reads) * (0.9 if mode == 0 else 0.0) or mode != 0
+
+
+@pytest.fixture(scope="module")
+def repeat_setup(oracle, workdir):
+    """Repeat-rich genome indexed by the PRODUCT builder (must equal the oracle's)."""
+    import abismal_amd as A
+    from tests import synth
+    fa = os.path.join(workdir, "rep.fa")
+    synth.repeat_rich_genome(fa)
+    idx = os.path.join(workdir, "rep.idx")
+    A.index_build(fa, idx, 8)
+    ix = A.Index(idx)
+    ctx = A.Context(ix, 0)
+    oix = oracle.index_load(idx)
+    yield fa, idx, ctx, oix
+    oracle.index_free(oix)
+    ctx.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("mode,L,pbat", [(0, 100, 0.0), (1, 100, 1.0), (2, 150, 0.5), (0, 64, 0.0), (0, 250, 0.0)])
+def test_se_repeat_rich(oracle, repeat_setup, mode, L, pbat):
+    from tests import synth
+    fa, idx, ctx, oix = repeat_setup
+    reads = synth.trim_like_readloader(synth.mutated_reads(fa, 6000, L, seed=100 + L + mode, pbat_frac=pbat))
+    o_res, o_cig, o_cig_n, work = oracle.map_se(oix, reads, mode=mode, threads=8)
+    assert work["search_probes"] > 0, "fixture no longer exercises bucket narrowing"
+    res, cig, cig_off = ctx.map_se(reads, mode=mode)
+    compare_se(res, cig, cig_off, o_res, o_cig, o_cig_n, reads, f"repeat-rich mode {mode} L {L}")

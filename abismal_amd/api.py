@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_ctx_create", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
-    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_stats_allreduce",
+    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_stats_allreduce",
 ]
 
 
@@ -69,6 +69,7 @@ def load_library():
     lib.abm_ctx_take_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.abm_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.abm_ctx_set_phase_stamps.argtypes = [C.c_void_p, C.c_int]
+    lib.abm_ctx_set_read_cycles.argtypes = [C.c_void_p, C.c_void_p]
     lib.abm_ctx_take_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     vp = C.c_void_p
     lib.abm_map_se_batch.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp]
@@ -201,6 +202,9 @@ class Context:
             d["phase_cycles"] = dict(zip(["probe_narrow", "gather_hamming", "replay", "align", "total"],
                                          [int(x) for x in out[6:11]]))
         return d
+
+    def set_read_cycles(self, d_ptr):
+        _check(self._lib.abm_ctx_set_read_cycles(self.handle, d_ptr))
 
     def set_phase_stamps(self, on=True):
         _check(self._lib.abm_ctx_set_phase_stamps(self.handle, int(on)))

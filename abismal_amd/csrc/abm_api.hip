@@ -5,6 +5,7 @@
 #include "abm_kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -65,6 +66,7 @@ struct abm_ctx {
   DevBuf<abm::u32> cig, cig_n, status;
   // optional HIP-event timing of the mapping kernel (abm_ctx_set_timing)
   bool timing = false;
+  abm::u32 *read_cycles = nullptr;  // caller-owned device array for the diagnostic kernel
   bool phase_stamps = false;  // launch the diagnostic kernel variant with in-kernel phase stamps
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -113,6 +115,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.cig_n = d_cig_n;
   a.status = d_status;
   a.work = ctx->work.p;
+  a.read_cycles = ctx->phase_stamps ? ctx->read_cycles : nullptr;
   int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, params->valid_frac);
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -128,7 +131,9 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     ++ctx->events_used;
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(abm::launch_map_se(a, eff_len, static_cast<abm::u32>(waves) * 8u, ctx->phase_stamps, st));
+  abm::u32 grid = static_cast<abm::u32>(waves) * 8u;
+  if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
+  HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
 }
 
@@ -240,6 +245,14 @@ int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable) {
     if (!ctx) throw std::invalid_argument("ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->phase_stamps = enable != 0;
+  });
+}
+
+int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->read_cycles = d_read_cycles;
   });
 }
 

@@ -243,7 +243,16 @@ struct WorkTally {
   // diagnostic build only (TIMED): shader cycles per phase, from s_memtime
   long long t_probe, t_stream, t_replay, t_align, t_total;
 };
-#define ABM_STAMP(var) do { if (TIMED) var = clock64(); } while (0)
+// a stamp drains outstanding memory traffic first so that waits are charged to the
+// phase that issued them (the scheduler may otherwise hoist s_memtime above the wait)
+__device__ __forceinline__ long long phase_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return static_cast<long long>(t);
+}
+#define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
 template <bool SPECIFIC, bool TIMED>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
@@ -728,6 +737,8 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
   bool overflow = false, too_long = false;
 
   for (u64 r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    long long t_read = 0;
+    if (TIMED) t_read = clock64();
     const u32 L = a.lens[r];
     Hit best;
     best.diffs = 0x7fff; best.flags = 0; best.pos = 0;
@@ -771,6 +782,7 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
     if (lane == 0) {
       a.res[r] = best;
       a.cig_n[r] = best.pos != 0 ? n_ops : 0u;
+      if (TIMED && a.read_cycles) a.read_cycles[r] = static_cast<u32>((clock64() - t_read) >> 10);
     }
   }
   if (a.work) {  // exact per-launch work tallies for the roofline model
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
         atomicAdd(&a.work[7], static_cast<unsigned long long>(wt.t_stream));
         atomicAdd(&a.work[8], static_cast<unsigned long long>(wt.t_replay));
         atomicAdd(&a.work[9], static_cast<unsigned long long>(wt.t_align));
-        atomicAdd(&a.work[10], static_cast<unsigned long long>(clock64() - t_begin));
+        atomicAdd(&a.work[10], static_cast<unsigned long long>(phase_stamp() - t_begin));
       }
     }
   }

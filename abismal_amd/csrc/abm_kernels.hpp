@@ -18,6 +18,7 @@ struct SeArgs {
   u32 cig_stride;
   u32 *cig_n;         // [n]
   u32 *status;        // ABM_STATUS_* bits
+  u32 *read_cycles;   // optional [n], diagnostic kernel only: per-read shader cycles / 1024
   unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments
 };

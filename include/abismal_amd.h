@@ -123,6 +123,8 @@ int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[16]);
  * [7] candidate gather+Hamming, [8] ordered replay, [9] alignment, [10] total.
  * Never enable it for a run whose time is quoted. */
 int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable);
+/* Diagnostic kernel only: device array [n] receiving per-read shader cycles / 1024 (NULL = off). */
+int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles);
 
 /* Measurement hook: when enabled, every mapping-kernel launch is bracketed by
  * HIP events recorded on the stream it is launched on; take_kernel_time waits

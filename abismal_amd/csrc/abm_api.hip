@@ -57,8 +57,11 @@ struct abm_ctx {
   void *arena = nullptr;  // one allocation holding the seven index arrays
   // per-batch workspaces (grow-only; sized by the largest batch seen)
   DevBuf<abm::u64> packed;
-  DevBuf<abm::u32> lens;
+  DevBuf<abm::u32> lens, order, class33;
+  DevBuf<abm::u8> cls;
   DevBuf<unsigned long long> work;
+  DevBuf<unsigned long long> next_read;
+  unsigned launch_seq = 0;
   // staging for the host-buffer entry points
   DevBuf<char> blob;
   DevBuf<abm::u64> off;
@@ -101,6 +104,14 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   abm::SeArgs a{};
   a.ix = ctx->dix;
   if (params->max_candidates) a.ix.max_candidates = params->max_candidates;
+  if (n < (1ull << 32)) {
+    ctx->order.reserve(n);
+    ctx->cls.reserve(n);
+    ctx->class33.reserve(33);
+    HIPCHK(abm::launch_order_reads(a.ix, ctx->packed.p, ctx->lens.p, n, W, mode, ctx->cls.p, ctx->class33.p,
+                                   ctx->order.p, st));
+    a.order = ctx->order.p;
+  }
   a.packed = ctx->packed.p;
   a.lens = ctx->lens.p;
   a.n_reads = n;
@@ -115,6 +126,11 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.cig_n = d_cig_n;
   a.status = d_status;
   a.work = ctx->work.p;
+  // a small ring of work counters so launches queued on different streams never share one
+  ctx->next_read.reserve(64);
+  unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+  HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+  a.next_read = counter;
   a.read_cycles = ctx->phase_stamps ? ctx->read_cycles : nullptr;
   int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, params->valid_frac);
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
@@ -131,7 +147,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     ++ctx->events_used;
     HIPCHK(hipEventRecord(e0, st));
   }
-  abm::u32 grid = static_cast<abm::u32>(waves) * 8u;
+  abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
   HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
@@ -232,7 +248,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->arena) (void)hipFree(c->arena);
-  c->packed.release(); c->lens.release(); c->work.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;

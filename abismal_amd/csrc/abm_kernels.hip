@@ -115,6 +115,51 @@ struct SeSet {
     sift_up(hole, vk);
     return freed;
   }
+  // m = popcount(run) consecutive updates, each with diffs == cutoff == every
+  // slot's diffs, the set being full.  With all keys equal, pop_heap on 50
+  // elements (len 49) walks hole 0 -> 2 -> 6 -> 14 -> 30 (always the right child:
+  // "right < left" is false), the displaced last element lands in 30 without
+  // rising, and the new element stays at 49: a 6-deep shift register over slots
+  // {0,2,6,14,30,49}.  The evicted element's payload slot is recycled for the
+  // newcomer.  Lanes of `run` carry the candidates (cand_pos) in order.
+  __device__ __forceinline__ void fifo_run(u64 run, u32 cand_pos, u32 f) {
+    static_assert(kSeCap == 50, "chain derived for a 50-element heap");
+    const int chain[6] = {0, 2, 6, 14, 30, 49};
+    const int m = __popcll(run);
+    int oldk[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) oldk[i] = rdlane(hk, chain[i]);
+    // the (up to) six newest candidates of the run, newest first
+    int lanes_new[6];
+    u64 rest = run;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      lanes_new[j] = rest ? 63 - __builtin_clzll(rest) : 0;
+      if (rest) rest &= ~(1ull << lanes_new[j]);
+    }
+    const int c256 = cutoff * 256, mm = m % 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      // final content of chain[i] = element (m + i) of the sequence old[0..5], new[1..m];
+      // newcomer k recycles the payload slot of old[(k-1) % 6]
+      if (m + i < 6) {
+        int k_old = oldk[0];
+#pragma unroll
+        for (int t = 1; t < 6; ++t) if (m + i == t) k_old = oldk[t];
+        wrlane(hk, chain[i], k_old);
+      }
+      else {
+        int k_slot = oldk[i % 6];  // (m + i) % 6 with mm == 0
+#pragma unroll
+        for (int t = 1; t < 6; ++t) if (mm == t) k_slot = oldk[(t + i) % 6];
+        const int slot = k_slot & 255;
+        wrlane(hk, chain[i], c256 + slot);
+        wrlane(pp, slot, rdlane(cand_pos, lanes_new[5 - i]));
+        wrlane(pf, slot, f);
+      }
+    }
+  }
+
   // se_candidates::update, :394-404
   __device__ __forceinline__ void admit(bool specific, int d, u32 f, u32 p) {
     if (d == 0) {
@@ -341,6 +386,24 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       ABM_STAMP(td);
       if (TIMED) wt.t_stream += td - tc;
       while (todo && !S.sure_ambig) {
+        if (S.sz == static_cast<int>(kSeCap)) {
+          // Saturated, all-equal regime (tandem repeats / homopolymer reads): the
+          // set is full and every slot's distance equals the cutoff.  A survivor at
+          // exactly that distance evicts heap[0] and, all keys comparing equal,
+          // libstdc++'s pop_heap/push_heap reduce to a shift along one fixed chain
+          // of slots (see fifo_run).  A run of such survivors is applied at once.
+          const u64 uneq = __ballot(lane < static_cast<int>(kSeCap) && SeSet::key_d(S.hk) != S.cutoff);
+          if (uneq == 0) {
+            const u64 brk = todo & ~__ballot(valid && h == S.cutoff);
+            const u64 run = brk ? (todo & ((brk & (0 - brk)) - 1)) : todo;
+            if (run) {
+              S.fifo_run(run, pos, flags);
+              wt.updates += static_cast<u32>(__popcll(run));
+              todo &= ~run;
+              continue;
+            }
+          }
+        }
         const int l = __builtin_ctzll(todo);
         const int before = S.cutoff;
         S.admit(true, rdlane(h, l), flags, rdlane(pos, l));
@@ -736,7 +799,19 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
   u32 n_aln = 0;
   bool overflow = false, too_long = false;
 
-  for (u64 r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+  // reads are handed out by one device-wide counter (zeroed before every launch):
+  // work per read spans four orders of magnitude, so a static split would leave
+  // the launch waiting on whichever wave drew the heaviest reads
+  auto next_read = [&]() -> u64 {
+    unsigned long long v = 0;
+    if (lane == 0) v = atomicAdd(a.next_read, 1ull);
+    return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) |
+           static_cast<u32>(uni(static_cast<int>(v)));
+  };
+  u64 r_next = next_read();
+  while (r_next < a.n_reads) {
+    const u64 r = a.order ? static_cast<u64>(a.order[r_next]) : r_next;
+    r_next = next_read();  // fetched early; its latency hides under this read's work
     long long t_read = 0;
     if (TIMED) t_read = clock64();
     const u32 L = a.lens[r];
@@ -806,6 +881,73 @@ __global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
   }
   if (lane == 0 && (overflow || too_long))
     atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u));
+}
+
+// =============================================================================
+// Heaviest-first ordering.  Work per read spans four orders of magnitude and is
+// predicted well by how full the read's first seed buckets are, so reads are
+// binned by log2 of that occupancy and handed out from the heaviest bin down
+// (longest-processing-time-first): a wave that draws a monster draws it early.
+// Results are indexed by read, so the processing order never shows in the output.
+// =============================================================================
+__device__ __forceinline__ u32 weight_class(const DevIndex &ix, const u64 *pk, u32 L, bool g_to_a) {
+  // same keys as seed_pass at offset 0 (first 25 / 16 bases)
+  u32 k2 = 0, k3 = 0;
+  const u64 w0 = pk[0], w1 = L > 16 ? pk[1] : 0ull;
+  for (u32 j = 0; j < kKeyWeight; ++j) {
+    const u32 nb = static_cast<u32>((j < 16 ? w0 >> (j << 2) : w1 >> ((j - 16) << 2))) & 15u;
+    k2 = (k2 << 1) | bit2(nb);
+  }
+  for (u32 j = 0; j < kKeyWeight3; ++j)
+    k3 = k3 * 3u + trit(static_cast<u32>(w0 >> (j << 2)) & 15u, g_to_a);
+  const u32 *cnt3 = g_to_a ? ix.counter_a : ix.counter_t;
+  const u32 occ = (ix.counter[k2 + 1] - ix.counter[k2]) + (cnt3[k3 + 1] - cnt3[k3]);
+  return 32u - static_cast<u32>(__clz(static_cast<int>(occ | 1u)));  // 1..32
+}
+
+__global__ __launch_bounds__(256) void weigh_reads_kernel(DevIndex ix, const u64 *__restrict__ packed,
+                                                          const u32 *__restrict__ lens, u64 n, u32 W,
+                                                          int mode, u8 *__restrict__ cls,
+                                                          u32 *__restrict__ class_count) {
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const u32 L = lens[r];
+  u32 c = 0;
+  if (L >= kMinReadLen) {
+    const u64 *pk = packed + r * 4 * W;
+    // forward call of the mode and its reverse-strand partner
+    const bool ar = mode == 1;
+    c = max(weight_class(ix, pk + (ar ? 1 : 0) * W, L, ar), weight_class(ix, pk + (2 + (ar ? 0 : 1)) * W, L, !ar));
+  }
+  cls[r] = static_cast<u8>(c);
+  atomicAdd(&class_count[c], 1u);
+}
+
+__global__ void order_bases_kernel(u32 *class_count /*[33] in: counts, out: start of each class (heaviest first)*/) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    u32 at = 0;
+    for (int c = 32; c >= 0; --c) { const u32 k = class_count[c]; class_count[c] = at; at += k; }
+  }
+}
+
+__global__ __launch_bounds__(256) void order_scatter_kernel(const u8 *__restrict__ cls, u64 n,
+                                                            u32 *__restrict__ class_cursor,
+                                                            u32 *__restrict__ order) {
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  order[atomicAdd(&class_cursor[cls[r]], 1u)] = static_cast<u32>(r);
+}
+
+hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W,
+                              int mode, u8 *d_cls, u32 *d_class33, u32 *d_order, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_class33, 0, 33 * sizeof(u32), st);
+  if (e != hipSuccess) return e;
+  const u32 blocks = static_cast<u32>((n + 255) / 256);
+  hipLaunchKernelGGL(weigh_reads_kernel, dim3(blocks), dim3(256), 0, st, ix, d_packed, d_lens, n, W, mode, d_cls, d_class33);
+  hipLaunchKernelGGL(order_bases_kernel, dim3(1), dim3(64), 0, st, d_class33);
+  hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, st, d_cls, n, d_class33, d_order);
+  return hipGetLastError();
 }
 
 // ---- launchers ----------------------------------------------------------------

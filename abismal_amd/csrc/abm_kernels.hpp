@@ -9,6 +9,7 @@ struct SeArgs {
   DevIndex ix;
   const u64 *packed;  // [n][4][W]
   const u32 *lens;    // [n]
+  const u32 *order;   // [n] processing order (heaviest first), or null
   u64 n_reads;
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
   int mode;           // ABM_SE_*
@@ -18,6 +19,7 @@ struct SeArgs {
   u32 cig_stride;
   u32 *cig_n;         // [n]
   u32 *status;        // ABM_STATUS_* bits
+  unsigned long long *next_read;  // work counter, zero at launch
   u32 *read_cycles;   // optional [n], diagnostic kernel only: per-read shader cycles / 1024
   unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments
@@ -27,6 +29,8 @@ u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,
                              u32 *d_lens, hipStream_t st);
+hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W,
+                              int mode, u8 *d_cls, u32 *d_class33, u32 *d_order, hipStream_t st);
 hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st);
 int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 

@@ -53,13 +53,17 @@ def synth_genome_fasta(path, total_mbp, seed, device):
     def rand_seq(n):
         return lut[torch.randint(0, 256, (n,), generator=g, device=device)]
 
-    # repeat families: (consensus length, piece length, fraction of genome, divergence)
-    families = [(300, 300, 0.10, 0.12), (6000, 900, 0.15, 0.08), (2000, 400, 0.04, 0.15)]
+    # interspersed repeat families, hg38-like proportions:
+    # (consensus length, piece length, fraction of genome, per-copy divergence range)
+    families = [(300, 300, 0.10, (0.05, 0.20)),    # Alu-like SINEs
+                (6000, 900, 0.15, (0.05, 0.30)),   # L1-like LINE fragments
+                (2000, 400, 0.04, (0.15, 0.35))]   # older elements
     cons = [rand_seq(c) for c, _, _, _ in families]
+    sat_master = rand_seq(171)                     # alpha-satellite-like monomer
     with open(path, "wb") as f:
         for ci, n in enumerate(sizes):
             seq = rand_seq(n)
-            for (clen, plen, frac, div), con in zip(families, cons):
+            for (clen, plen, frac, (dlo, dhi)), con in zip(families, cons):
                 k = int(n * frac / plen)
                 if k == 0 or n <= plen + 1:
                     continue
@@ -67,19 +71,37 @@ def synth_genome_fasta(path, total_mbp, seed, device):
                 src0 = torch.randint(0, clen - plen + 1, (k,), generator=g, device=device)
                 ar = torch.arange(plen, device=device)
                 piece = con[(src0[:, None] + ar[None, :])]
+                div = dlo + (dhi - dlo) * torch.rand((k, 1), generator=g, device=device)
                 mut = torch.rand((k, plen), generator=g, device=device) < div
                 rnd = acgt[torch.randint(0, 4, (k, plen), generator=g, device=device)]
                 piece = torch.where(mut, rnd, piece)
                 seq[(at[:, None] + ar[None, :]).reshape(-1)] = piece.reshape(-1)
-            # low-complexity tracts (~1 %): motifs of 1-4 bases repeated over 256 bp
-            n_tr = max(1, int(n * 0.01 / 256))
+            # centromeric satellite arrays (~2 %): tandem 171-mers, array consensus 20 % off
+            # the master, copies 2 % off their array's consensus
+            sat_len = int(n * 0.02)
+            if sat_len > 20000:
+                n_arr = max(1, sat_len // 150000)
+                alen = (sat_len // n_arr) // 171 * 171
+                for a0 in torch.randint(0, n - alen, (n_arr,), generator=g, device=device).tolist():
+                    m0 = torch.rand((171,), generator=g, device=device) < 0.20
+                    acons = torch.where(m0, acgt[torch.randint(0, 4, (171,), generator=g, device=device)], sat_master)
+                    arr = acons.repeat(alen // 171)
+                    m1 = torch.rand((alen,), generator=g, device=device) < 0.02
+                    arr = torch.where(m1, acgt[torch.randint(0, 4, (alen,), generator=g, device=device)], arr)
+                    seq[a0:a0 + alen] = arr
+            # microsatellites / low complexity (~1 %): motifs of 1-4 bases, tract length
+            # geometric with mean ~30 bp (12..250)
+            n_tr = max(1, int(n * 0.01 / 30))
             if n > 1000:
                 at = torch.randint(0, n - 256, (n_tr,), generator=g, device=device)
                 ml = torch.randint(1, 5, (n_tr,), generator=g, device=device)
+                tl = (12 - 30.0 * torch.log(torch.rand((n_tr,), generator=g, device=device).clamp_min(1e-9))).clamp(12, 250).long()
                 motif = lut[torch.randint(0, 256, (n_tr, 4), generator=g, device=device)]
                 ar = torch.arange(256, device=device)
                 tract = torch.gather(motif, 1, ar[None, :] % ml[:, None])
-                seq[(at[:, None] + ar[None, :]).reshape(-1)] = tract.reshape(-1)
+                keep = ar[None, :] < tl[:, None]
+                dst = (at[:, None] + ar[None, :])[keep]
+                seq[dst] = tract[keep]
             # one long N gap (centromere-like) and a short N run per chromosome
             if n > 4_000_000:
                 seq[n // 3: n // 3 + min(1_000_000, n // 50)] = ord("N")
@@ -235,7 +257,7 @@ def main():
     log(f"{n} reads sampled on GPU in {time.time() - t0:.1f}s ({n_skipped} unseedable)")
     del genome_words
 
-    stride = 8
+    stride = 16
     res = torch.zeros((n, 2), dtype=torch.int32, device=dev)  # abm_hit = 8 bytes
     cig = torch.zeros((n, stride), dtype=torch.int32, device=dev)
     cig_n = torch.zeros((n,), dtype=torch.int32, device=dev)

@@ -56,7 +56,13 @@ struct abm_ctx {
   abm::DevIndex dix{};
   void *arena = nullptr;  // one allocation holding the seven index arrays
   // per-batch workspaces (grow-only; sized by the largest batch seen)
-  DevBuf<abm::u64> packed;
+  DevBuf<abm::u64> packed, packed2;
+  DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2;
+  DevBuf<abm::u8> need_big;
+  DevBuf<abm::Hit> pe_out;  // staging: pairs (20 B each) then se1, se2
+  DevBuf<abm::u32> cig2h, cig_n2h;
+  DevBuf<char> blob2;
+  DevBuf<abm::u64> off2;
   DevBuf<abm::u32> lens, order, class33;
   DevBuf<abm::u8> cls;
   DevBuf<unsigned long long> work;
@@ -151,6 +157,86 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
   HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
+}
+
+void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob1,
+               const uint64_t *d_off1, const char *d_blob2, const uint64_t *d_off2, uint32_t max_len,
+               abm_pair *d_pair, abm_hit *d_se1, abm_hit *d_se2, uint32_t *d_cig1, uint32_t *d_cig2,
+               uint32_t cig_stride, uint32_t *d_cig_n1, uint32_t *d_cig_n2, uint32_t *d_status, hipStream_t st) {
+  check_params(params);
+  if (mode < 0 || mode > 2) throw std::invalid_argument("bad paired-end mode");
+  if (cig_stride == 0) throw std::invalid_argument("cig_stride must be > 0");
+  if (n == 0) return;
+  if (n >= (1ull << 32)) throw std::invalid_argument("batch too large (>= 2^32 pairs)");
+  HIPCHK(hipSetDevice(ctx->device));
+  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kMaxReadLen);
+  const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
+  ctx->packed.reserve(n * 4 * W);
+  ctx->packed2.reserve(n * 4 * W);
+  ctx->lens.reserve(n);
+  ctx->lens2.reserve(n);
+  ctx->work.reserve(16);
+  ctx->order.reserve(n);
+  ctx->cls.reserve(n);
+  ctx->class33.reserve(33);
+  ctx->need_big.reserve(n);
+  ctx->subset.reserve(n);
+  ctx->subset_count.reserve(1);
+  ctx->next_read.reserve(64);
+  HIPCHK(abm::launch_pack_reads(d_blob1, reinterpret_cast<const abm::u64 *>(d_off1), n, W, ctx->packed.p, ctx->lens.p, st));
+  HIPCHK(abm::launch_pack_reads(d_blob2, reinterpret_cast<const abm::u64 *>(d_off2), n, W, ctx->packed2.p, ctx->lens2.p, st));
+  abm::PeArgs a{};
+  a.ix = ctx->dix;
+  if (params->max_candidates) a.ix.max_candidates = params->max_candidates;
+  HIPCHK(abm::launch_order_reads(a.ix, ctx->packed.p, ctx->lens.p, n, W, mode == 1 ? 1 : 0, ctx->cls.p, ctx->class33.p,
+                                 ctx->order.p, st));
+  a.packed1 = ctx->packed.p; a.packed2 = ctx->packed2.p;
+  a.lens1 = ctx->lens.p; a.lens2 = ctx->lens2.p;
+  a.order = ctx->order.p;
+  a.subset = ctx->subset.p; a.subset_count = ctx->subset_count.p;
+  a.n_pairs = n;
+  a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, params->valid_frac);
+  a.mode = mode;
+  a.valid_frac = params->valid_frac;
+  a.min_frag = params->min_frag; a.max_frag = params->max_frag;
+  a.allow_ambig = params->allow_ambig;
+  a.pairs = reinterpret_cast<abm::Hit *>(d_pair);
+  a.se1 = reinterpret_cast<abm::Hit *>(d_se1); a.se2 = reinterpret_cast<abm::Hit *>(d_se2);
+  a.cig1 = d_cig1; a.cig2 = d_cig2; a.cig_stride = cig_stride; a.cig_n1 = d_cig_n1; a.cig_n2 = d_cig_n2;
+  a.status = d_status;
+  a.work = ctx->work.p;
+  a.need_big = ctx->need_big.p;
+  // tier 1: every pair, small sets in LDS
+  {
+    a.cap = abm::kPeTier1Cap;
+    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, params->valid_frac, a.cap, false);
+    const int waves = abm::pe_resident_waves(lds, false);
+    if (waves <= 0) throw HipFail("map_pe_kernel (tier 1) does not fit on this device");
+    ctx->payload1.reserve(static_cast<size_t>(waves) * a.cap);
+    a.payload_ws = ctx->payload1.p;
+    a.list_ws = nullptr;
+    unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    a.next_read = counter;
+    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, st));
+  }
+  // tier 2: the pairs whose candidate sets outgrew tier 1, one wave per CU, 32768-entry sets
+  {
+    HIPCHK(abm::launch_collect_big(ctx->need_big.p, n, ctx->subset.p, ctx->subset_count.p, st));
+    a.cap = abm::kPeCapLarge;
+    a.order = nullptr;
+    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, params->valid_frac, a.cap, true);
+    const int waves = abm::pe_resident_waves(lds, true);
+    if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
+    ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);
+    ctx->list2.reserve(static_cast<size_t>(waves) * 4 * a.cap);
+    a.payload_ws = ctx->payload2.p;
+    a.list_ws = ctx->list2.p;
+    unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    a.next_read = counter;
+    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, st));
+  }
 }
 
 }  // namespace
@@ -248,7 +334,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->arena) (void)hipFree(c->arena);
-  c->packed.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -378,18 +464,93 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
   });
 }
 
-int abm_map_pe_device(abm_ctx *, int, const abm_params *, uint64_t, const char *, const uint64_t *,
-                      const char *, const uint64_t *, uint32_t, abm_pair *, abm_hit *, abm_hit *,
-                      uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, void *) {
-  g_error = "paired-end kernels are not built yet";
-  return -2;
+int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                      const char *d_seq_blob1, const uint64_t *d_seq_off1, const char *d_seq_blob2,
+                      const uint64_t *d_seq_off2, uint32_t max_len, abm_pair *d_pair,
+                      abm_hit *d_se1, abm_hit *d_se2, uint32_t *d_cig1, uint32_t *d_cig2,
+                      uint32_t cig_stride, uint32_t *d_cig_n1, uint32_t *d_cig_n2,
+                      uint32_t *d_status, void *stream) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    pe_device(ctx, mode, params, n, d_seq_blob1, d_seq_off1, d_seq_blob2, d_seq_off2, max_len, d_pair, d_se1,
+              d_se2, d_cig1, d_cig2, cig_stride, d_cig_n1, d_cig_n2, d_status, static_cast<hipStream_t>(stream));
+  });
 }
 
-int abm_map_pe_batch(abm_ctx *, int, const abm_params *, uint64_t, const char *, const uint64_t *,
-                     const char *, const uint64_t *, abm_pair *, abm_hit *, abm_hit *, uint32_t *,
-                     uint64_t *, uint32_t *, uint64_t *, uint64_t) {
-  g_error = "paired-end kernels are not built yet";
-  return -2;
+int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                     const char *seq_blob1, const uint64_t *seq_off1, const char *seq_blob2,
+                     const uint64_t *seq_off2, abm_pair *out_pair, abm_hit *out_se1,
+                     abm_hit *out_se2, uint32_t *out_cig_blob1, uint64_t *out_cig_off1,
+                     uint32_t *out_cig_blob2, uint64_t *out_cig_off2, uint64_t cig_capacity) {
+  return guarded([&] {
+    if (!ctx || !seq_off1 || !seq_off2 || !out_pair || !out_se1 || !out_se2 || !out_cig_off1 || !out_cig_off2)
+      throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    out_cig_off1[0] = out_cig_off2[0] = 0;
+    if (n == 0) return;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint32_t max_len = 0;
+    std::vector<uint64_t> rel1(n + 1), rel2(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) { rel1[i] = seq_off1[i] - seq_off1[0]; rel2[i] = seq_off2[i] - seq_off2[0]; }
+    for (uint64_t i = 0; i < n; ++i) {
+      if (seq_off1[i + 1] < seq_off1[i] || seq_off2[i + 1] < seq_off2[i]) throw std::invalid_argument("seq_off not monotone");
+      max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off1[i + 1] - seq_off1[i]));
+      max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off2[i + 1] - seq_off2[i]));
+    }
+    if (max_len > abm::kMaxReadLen)
+      throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
+                                  std::to_string(abm::kMaxReadLen));
+    const uint64_t bytes1 = rel1[n], bytes2 = rel2[n];
+    ctx->blob.reserve(std::max<uint64_t>(bytes1, 1));
+    ctx->blob2.reserve(std::max<uint64_t>(bytes2, 1));
+    ctx->off.reserve(n + 1);
+    ctx->off2.reserve(n + 1);
+    ctx->pe_out.reserve(n * 5);  // 20 B pairs + 8 B + 8 B, in units of 8 B Hit
+    ctx->cig_n.reserve(n);
+    ctx->cig_n2h.reserve(n);
+    ctx->status.reserve(1);
+    if (bytes1) HIPCHK(hipMemcpy(ctx->blob.p, seq_blob1 + seq_off1[0], bytes1, hipMemcpyHostToDevice));
+    if (bytes2) HIPCHK(hipMemcpy(ctx->blob2.p, seq_blob2 + seq_off2[0], bytes2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->off.p, rel1.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->off2.p, rel2.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    char *outb = reinterpret_cast<char *>(ctx->pe_out.p);
+    abm_pair *d_pair = reinterpret_cast<abm_pair *>(outb);
+    abm_hit *d_se1 = reinterpret_cast<abm_hit *>(outb + n * 20 + (8 - (n * 20) % 8) % 8);
+    abm_hit *d_se2 = d_se1 + n;
+    uint32_t stride = 8;
+    for (;;) {
+      ctx->cig.reserve(n * stride);
+      ctx->cig2h.reserve(n * stride);
+      HIPCHK(hipMemset(ctx->status.p, 0, 4));
+      HIPCHK(hipMemset(ctx->cig_n.p, 0, n * 4));
+      HIPCHK(hipMemset(ctx->cig_n2h.p, 0, n * 4));
+      pe_device(ctx, mode, params, n, ctx->blob.p, ctx->off.p, ctx->blob2.p, ctx->off2.p, max_len, d_pair, d_se1,
+                d_se2, ctx->cig.p, ctx->cig2h.p, stride, ctx->cig_n.p, ctx->cig_n2h.p, ctx->status.p, nullptr);
+      HIPCHK(hipDeviceSynchronize());
+      uint32_t status = 0;
+      HIPCHK(hipMemcpy(&status, ctx->status.p, 4, hipMemcpyDeviceToHost));
+      if ((status & ABM_STATUS_CIGAR_OVERFLOW) && stride < max_len + 2) { stride = max_len + 2; continue; }
+      if (status) throw std::runtime_error("kernel reported status " + std::to_string(status));
+      break;
+    }
+    HIPCHK(hipMemcpy(out_pair, d_pair, n * sizeof(abm_pair), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_se1, d_se1, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_se2, d_se2, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> c1(n * stride), c2(n * stride), n1(n), n2(n);
+    HIPCHK(hipMemcpy(c1.data(), ctx->cig.p, c1.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c2.data(), ctx->cig2h.p, c2.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n1.data(), ctx->cig_n.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n2.data(), ctx->cig_n2h.p, n * 4, hipMemcpyDeviceToHost));
+    uint64_t at1 = 0, at2 = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      if (at1 + n1[i] > cig_capacity || at2 + n2[i] > cig_capacity) throw std::length_error("cig_capacity too small");
+      if (n1[i]) std::memcpy(out_cig_blob1 + at1, c1.data() + i * stride, n1[i] * 4ull);
+      if (n2[i]) std::memcpy(out_cig_blob2 + at2, c2.data() + i * stride, n2[i] * 4ull);
+      at1 += n1[i]; at2 += n2[i];
+      out_cig_off1[i + 1] = at1; out_cig_off2[i + 1] = at2;
+    }
+  });
 }
 
 int abm_stats_allreduce(abm_ctx *const *, int, uint64_t *const *) {

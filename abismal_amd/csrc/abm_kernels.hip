@@ -2,7 +2,7 @@
 // kernel (seed probe -> bucket narrowing -> Hamming filter -> ordered replay
 // into the candidate set -> banded alignment -> CIGAR).  One wavefront maps one
 // read; see DESIGN.md for the data layout and the reasoning.
-#include "abm_kernels.hpp"
+#include "abm_kernels_core.hpp"
 
 namespace abm {
 
@@ -51,719 +51,6 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
   dst[W] = fa;
   dst[2 * W] = rt;
   dst[3 * W] = ra;
-}
-
-// =============================================================================
-// Wave-resident single-end candidate set (se_candidates, src/abismal.cpp:334-449).
-// The heap array lives across lanes: lane k holds heap slot k as one packed key
-// diffs*256 + payload_slot; (flags,pos) payloads never move -- lane p holds the
-// payload whose slot number is p.  A sift step therefore moves one register.
-// =============================================================================
-struct SeSet {
-  int hk;   // per lane k: heap[k] = diffs*256 + payload slot
-  u32 pf;   // per lane p: flags of payload p
-  u32 pp;   // per lane p: pos of payload p
-  int sz, cutoff, good_cutoff;
-  int best_d;
-  u32 best_f, best_p;
-  bool sure_ambig;
-
-  __device__ __forceinline__ static int key_d(int k) { return k >> 8; }
-  __device__ __forceinline__ void begin_read(u32 readlen) {
-    const int worst = static_cast<i16>(0.4 * readlen);  // se_element::reset(readlen), :292-296
-    hk = worst * 256; pf = 0; pp = 0;  // sentinel: heap[0] -> payload 0 = {pos 0}
-    sz = 1;
-    cutoff = worst;
-    good_cutoff = static_cast<i16>(readlen / 10u);
-    best_d = worst; best_f = 0; best_p = 0;
-    sure_ambig = false;
-  }
-  __device__ __forceinline__ int top_d() const { return key_d(rdlane(hk, 0)); }
-  // libstdc++ __push_heap with `key` entering at `hole`, comparator diffs<
-  __device__ __forceinline__ void sift_up(int hole, int key) {
-    int parent = (hole - 1) / 2;
-    while (hole > 0) {
-      const int pk = rdlane(hk, parent);
-      if (!(key_d(pk) < key_d(key))) break;
-      wrlane(hk, hole, pk);
-      hole = parent;
-      parent = (hole - 1) / 2;
-    }
-    wrlane(hk, hole, key);
-  }
-  // libstdc++ pop_heap on [0,n): returns the payload slot of the evicted maximum;
-  // the caller overwrites heap[n-1] and pushes, so only __adjust_heap of the
-  // displaced last element is performed here
-  __device__ __forceinline__ int pop_max(int n) {
-    const int len = n - 1;
-    const int freed = rdlane(hk, 0) & 255;
-    const int vk = rdlane(hk, len);
-    int hole = 0, second = 0;
-    while (second < (len - 1) / 2) {
-      second = 2 * (second + 1);
-      int sk = rdlane(hk, second);
-      const int lk = rdlane(hk, second - 1);
-      if (key_d(sk) < key_d(lk)) { --second; sk = lk; }
-      wrlane(hk, hole, sk);
-      hole = second;
-    }
-    if ((len & 1) == 0 && second == (len - 2) / 2) {
-      second = 2 * (second + 1);
-      wrlane(hk, hole, rdlane(hk, second - 1));
-      hole = second - 1;
-    }
-    sift_up(hole, vk);
-    return freed;
-  }
-  // m = popcount(run) consecutive updates, each with diffs == cutoff == every
-  // slot's diffs, the set being full.  With all keys equal, pop_heap on 50
-  // elements (len 49) walks hole 0 -> 2 -> 6 -> 14 -> 30 (always the right child:
-  // "right < left" is false), the displaced last element lands in 30 without
-  // rising, and the new element stays at 49: a 6-deep shift register over slots
-  // {0,2,6,14,30,49}.  The evicted element's payload slot is recycled for the
-  // newcomer.  Lanes of `run` carry the candidates (cand_pos) in order.
-  __device__ __forceinline__ void fifo_run(u64 run, u32 cand_pos, u32 f) {
-    static_assert(kSeCap == 50, "chain derived for a 50-element heap");
-    const int chain[6] = {0, 2, 6, 14, 30, 49};
-    const int m = __popcll(run);
-    int oldk[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) oldk[i] = rdlane(hk, chain[i]);
-    // the (up to) six newest candidates of the run, newest first
-    int lanes_new[6];
-    u64 rest = run;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      lanes_new[j] = rest ? 63 - __builtin_clzll(rest) : 0;
-      if (rest) rest &= ~(1ull << lanes_new[j]);
-    }
-    const int c256 = cutoff * 256, mm = m % 6;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      // final content of chain[i] = element (m + i) of the sequence old[0..5], new[1..m];
-      // newcomer k recycles the payload slot of old[(k-1) % 6]
-      if (m + i < 6) {
-        int k_old = oldk[0];
-#pragma unroll
-        for (int t = 1; t < 6; ++t) if (m + i == t) k_old = oldk[t];
-        wrlane(hk, chain[i], k_old);
-      }
-      else {
-        int k_slot = oldk[i % 6];  // (m + i) % 6 with mm == 0
-#pragma unroll
-        for (int t = 1; t < 6; ++t) if (mm == t) k_slot = oldk[(t + i) % 6];
-        const int slot = k_slot & 255;
-        wrlane(hk, chain[i], c256 + slot);
-        wrlane(pp, slot, rdlane(cand_pos, lanes_new[5 - i]));
-        wrlane(pf, slot, f);
-      }
-    }
-  }
-
-  // se_candidates::update, :394-404
-  __device__ __forceinline__ void admit(bool specific, int d, u32 f, u32 p) {
-    if (d == 0) {
-      if (best_p == 0) { best_d = 0; best_f = f; best_p = p; }
-      else if (p != best_p || f != best_f) best_f |= kFlagAmbig;
-    }
-    else {
-      int slot;
-      if (sz == static_cast<int>(kSeCap)) slot = pop_max(sz);
-      else slot = sz++;
-      wrlane(pf, slot, f);
-      wrlane(pp, slot, p);
-      sift_up(sz - 1, d * 256 + slot);
-    }
-    sure_ambig = (best_f & kFlagAmbig) && best_d == 0;
-    const int top = top_d();
-    cutoff = specific ? min(cutoff, top) : top;
-  }
-};
-
-// Per-wave LDS carve-up
-struct WaveLds {
-  u64 *qpk;    // [4][W] packed encodings
-  u64 *qbits;  // [4][WB] 2-letter bit strings, bit j = bit2(nibble j), 1 past the end
-  u16 *mark;   // [64]
-  u32 *ctmp;   // [cig_stride] reversed CIGAR scratch
-  u8 *tb;      // traceback bytes
-  u64 *gwin;   // [kMaxJobs][GW] genome windows of the alignments in flight
-  u32 *jpos;   // [kSeCap] alignment job list: position
-  u32 *jdf;    // [kSeCap] alignment job list: diffs<<16 | flags
-  int *lbest;  // [64]
-  u32 W, WB, GW;
-};
-constexpr u32 kMaxJobs = 21;  // 64 lanes / narrowest band (3)
-
-__device__ __forceinline__ u32 q_nibble(const u64 *qpk, u32 k) {
-  return static_cast<u32>(qpk[k >> 4] >> ((k & 15u) << 2)) & 15u;
-}
-
-// 16 consecutive read nibbles starting at base i (nibbles at or past L read as 0)
-__device__ __forceinline__ u64 q_window16(const u64 *qpk, u32 W, u32 i, u32 L) {
-  const u32 w = i >> 4, s = (i & 15u) << 2;
-  u64 x = qpk[w] >> s;
-  if (s && w + 1 < W) x |= qpk[w + 1] << (64 - s);
-  const u32 have = i < L ? min(16u, L - i) : 0u;
-  if (have < 16) x &= (have == 0 ? 0ull : ((1ull << (have << 2)) - 1));
-  return x;
-}
-
-// std::lower_bound's exact probe sequence (see oracle first_not)
-template <class Below>
-__device__ __forceinline__ u32 first_not(u32 lo, u32 hi, u32 &probes, Below below) {
-  int n = static_cast<int>(hi - lo);
-  while (n > 0) {
-    const int half = n >> 1;
-    ++probes;
-    if (below(lo + half)) { lo += half + 1; n -= half + 1; }
-    else n = half;
-  }
-  return lo;
-}
-
-// find_candidates, src/abismal.cpp:1163-1194 (range as indices into tbl[])
-__device__ __forceinline__ u32 narrow2(const u64 *__restrict__ genome, const u32 *__restrict__ tbl,
-                                       const u64 *qpk, u32 qbase, u32 limit, u32 maxc, u32 &lo,
-                                       u32 &hi, u32 &probes) {
-  u32 p = kKeyWeight, plo = lo, phi = hi;
-  for (; p != limit && (hi - lo) > maxc; ++p) {
-    plo = lo; phi = hi;
-    const u32 ones = first_not(lo, hi, probes, [&](u32 k) {
-      return bit2(gnib(genome, static_cast<u64>(tbl[k]) + p)) < 1u;
-    });
-    if (bit2(q_nibble(qpk, qbase + p))) lo = ones; else hi = ones;
-  }
-  if (lo == hi) { --p; lo = plo; hi = phi; }
-  return p;
-}
-
-// find_candidates_three, src/abismal.cpp:1214-1259
-__device__ __forceinline__ u32 narrow3(const u64 *__restrict__ genome, const u32 *__restrict__ tbl,
-                                       bool g_to_a, const u64 *qpk, u32 qbase, u32 limit, u32 maxc,
-                                       u32 &lo, u32 &hi, u32 &probes) {
-  const u32 mid_sym = g_to_a ? 2u : 1u, top_sym = g_to_a ? 8u : 4u;
-  u32 p = kKeyWeight3, plo = lo, phi = hi;
-  for (; p != limit && (hi - lo) > maxc; ++p) {
-    plo = lo; phi = hi;
-    const u32 b1 = first_not(lo, hi, probes, [&](u32 k) {
-      return sortsym3(gnib(genome, static_cast<u64>(tbl[k]) + p), g_to_a) < mid_sym;
-    });
-    const u32 b2 = first_not(lo, hi, probes, [&](u32 k) {
-      return sortsym3(gnib(genome, static_cast<u64>(tbl[k]) + p), g_to_a) < top_sym;
-    });
-    const u32 sym = sortsym3(q_nibble(qpk, qbase + p), g_to_a);
-    if (sym == 0) hi = b1;
-    else if (sym == mid_sym) { lo = b1; hi = b2; }
-    else lo = b2;
-  }
-  if (lo == hi) { --p; lo = plo; hi = phi; }
-  return p;
-}
-
-// full_compare without the early exit (src/abismal.cpp:1105-1122): the reference
-// stops once d exceeds the cutoff, which changes d only when the hit is rejected
-// anyway, so the complete distance gives identical admit/reject decisions.
-__device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64 *qpk, u32 nwords,
-                                       u32 pos) {
-  const u64 *g = genome + (pos >> 4);
-  const u32 sh = (pos & 15u) << 2;
-  int d = 0;
-  u64 g0 = g[0];
-  for (u32 w = 0; w < nwords; ++w) {
-    const u64 g1 = g[w + 1];
-    const u64 win = (g0 >> sh) | ((g1 << (63 - sh)) << 1);
-    d += 16 - __popcll(qpk[w] & win);
-    g0 = g1;
-  }
-  return static_cast<i16>(d);
-}
-
-// One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
-// the whole wave.  Lanes are seed offsets while probing/narrowing, then become
-// candidates (all checked buckets of 64 offsets flattened in reference order)
-// for the Hamming filter; survivors are replayed in order into the set.
-struct WorkTally {
-  u32 seed_iters, probes, cands, words, updates;
-  // diagnostic build only (TIMED): shader cycles per phase, from s_memtime
-  long long t_probe, t_stream, t_replay, t_align, t_total;
-};
-// a stamp drains outstanding memory traffic first so that waits are charged to the
-// phase that issued them (the scheduler may otherwise hoist s_memtime above the wait)
-__device__ __forceinline__ long long phase_stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return static_cast<long long>(t);
-}
-#define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
-
-template <bool SPECIFIC, bool TIMED>
-__device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
-                                          u32 flags, u32 L, SeSet &S, WorkTally &wt) {
-  const int lane = lane_id();
-  const u64 *qpk = lds.qpk + enc * lds.W;
-  const u64 *qb = lds.qbits + enc * lds.WB;
-  const u32 *cnt3 = g_to_a ? ix.counter_a : ix.counter_t;
-  const u32 *idx3 = g_to_a ? ix.index_a : ix.index_t;
-  const u32 maxc = ix.max_candidates;
-  const u32 nwords = (L + 15) >> 4;
-  const u32 spec_len = min(L - kWindow, L >> 1);
-  const u32 n_off = SPECIFIC ? max(kWindow, L >> 1) : L - kKeyWeight + 1;
-
-  long long ta = 0, tb_ = 0, tc = 0, td = 0;
-  for (u32 g0 = 0; g0 < n_off && !S.sure_ambig; g0 += 64) {
-    ABM_STAMP(ta);
-    const u32 i = g0 + lane;
-    const bool live = i < n_off;
-    u32 lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0;
-    bool chk2 = false, chk3 = false;
-    if (live) {
-      // 25-bit 2-letter key, MSB first (get_1bit_hash, src/AbismalIndex.hpp:285-294)
-      const u32 wq = i >> 6, sq = i & 63u;
-      u64 bits = qb[wq] >> sq;
-      if (sq) bits |= qb[wq + 1] << (64 - sq);
-      const u32 k2 = __brev(static_cast<u32>(bits) & 0x1FFFFFFu) >> 7;
-      // 16-digit base-3 key (get_base_3_hash, src/AbismalIndex.hpp:296-305)
-      const u64 win = q_window16(qpk, lds.W, i, L);
-      u32 k3 = 0;
-#pragma unroll
-      for (u32 j = 0; j < 16; ++j)
-        k3 = k3 * 3u + trit(static_cast<u32>(win >> (j << 2)) & 15u, g_to_a);
-      lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
-      lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
-      if (SPECIFIC) {
-        u32 probes = 0;
-        const u32 len2 = narrow2(ix.genome, ix.index, qpk, i, L - i, maxc, lo2, hi2, probes);
-        const u32 len3 = narrow3(ix.genome, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
-        chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
-        chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;
-        wt.probes += probes;
-      }
-      else {
-        const u32 d2 = hi2 - lo2, d3 = hi3 - lo3;
-        chk2 = d2 != 0 && d2 <= maxc && (d3 == 0 || d2 <= 10u * d3);
-        chk3 = d3 != 0 && d3 <= maxc;
-      }
-      ++wt.seed_iters;
-    }
-    const u32 na = chk2 ? hi2 - lo2 : 0u, nb = chk3 ? hi3 - lo3 : 0u;
-    u32 total;
-    const u32 start_a = wave_excl_sum(na + nb, total), start_b = start_a + na;
-    ABM_STAMP(tb_);
-    if (TIMED) wt.t_probe += tb_ - ta;
-
-    int carry = 0;
-    for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 64) {
-      // which (offset, table) segment does each of these 64 candidates belong to
-      ABM_STAMP(tc);
-      lds.mark[lane] = 0;
-      __syncthreads();
-      if (na && start_a - c0 < 64u) lds.mark[start_a - c0] = static_cast<u16>(2 * lane + 1);
-      if (nb && start_b - c0 < 64u) lds.mark[start_b - c0] = static_cast<u16>(2 * lane + 2);
-      __syncthreads();
-      const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
-      const int seg = m ? m - 1 : carry;
-      carry = rdlane(seg, 63);
-      const int owner = seg >> 1;
-      const bool three = seg & 1;
-      const u32 sa = __shfl(start_a, owner), sb = __shfl(start_b, owner);
-      const u32 ba = __shfl(lo2, owner), bb = __shfl(lo3, owner);
-      const u32 c = c0 + lane;
-      const bool valid = c < total;
-      u32 pos = 0;
-      int h = 0x7fff;
-      if (valid) {
-        const u32 entry = three ? idx3[bb + (c - sb)] : ix.index[ba + (c - sa)];
-        pos = entry - (g0 + static_cast<u32>(owner));
-        h = hamming(ix.genome, qpk, nwords, pos);
-        ++wt.cands;
-        wt.words += nwords;
-      }
-      // ordered replay (check_hits + se_candidates::update, :1133-1149, :394-404)
-      u64 todo = __ballot(valid && h <= S.cutoff);
-      ABM_STAMP(td);
-      if (TIMED) wt.t_stream += td - tc;
-      while (todo && !S.sure_ambig) {
-        if (S.sz == static_cast<int>(kSeCap)) {
-          // Saturated, all-equal regime (tandem repeats / homopolymer reads): the
-          // set is full and every slot's distance equals the cutoff.  A survivor at
-          // exactly that distance evicts heap[0] and, all keys comparing equal,
-          // libstdc++'s pop_heap/push_heap reduce to a shift along one fixed chain
-          // of slots (see fifo_run).  A run of such survivors is applied at once.
-          const u64 uneq = __ballot(lane < static_cast<int>(kSeCap) && SeSet::key_d(S.hk) != S.cutoff);
-          if (uneq == 0) {
-            const u64 brk = todo & ~__ballot(valid && h == S.cutoff);
-            const u64 run = brk ? (todo & ((brk & (0 - brk)) - 1)) : todo;
-            if (run) {
-              S.fifo_run(run, pos, flags);
-              wt.updates += static_cast<u32>(__popcll(run));
-              todo &= ~run;
-              continue;
-            }
-          }
-        }
-        const int l = __builtin_ctzll(todo);
-        const int before = S.cutoff;
-        S.admit(true, rdlane(h, l), flags, rdlane(pos, l));
-        ++wt.updates;
-        todo &= ~(((1ull << l) << 1) - 1);
-        if (S.cutoff < before) todo &= __ballot(valid && h <= S.cutoff);
-      }
-      ABM_STAMP(tc);
-      if (TIMED) wt.t_replay += tc - td;
-    }
-  }
-}
-
-// =============================================================================
-// Banded local alignment (AbismalAlign::align, src/AbismalAlign.hpp:320-386) as
-// an anti-diagonal wavefront.  Cell (i,j) of the reference's band table (row i =
-// target base t_beg+i-1, column j, read index q = i+j-bw) depends on (i-1,j)
-// [substitution], (i-1,j+1) [from_above] and (i,j-1) [from_left]; on the
-// anti-diagonal t = 2i+j all three are already known, from the same lane two
-// steps ago and from the two neighbouring lanes one step ago.  So lane = band
-// column, one DPP move per neighbour per step, and no in-row scan.  A band is
-// at most 61 lanes wide and usually ~21 (2*min(diffs,max_diffs)+1), so several
-// candidate alignments ("jobs") share one wave side by side.
-// Cell validity (left/right of the reference's row loop) reduces to 0 <= q < L;
-// invalid cells read as 0, exactly like the zero-filled table.
-// =============================================================================
-__device__ __forceinline__ int band_for(int diffs, int max_diffs) {
-  const int v = 2 * min(diffs, max_diffs) + 1;
-  return v < 0 ? static_cast<int>(kMaxBand) : min(static_cast<int>(kMaxBand), v);
-}
-__device__ __forceinline__ int from_prev_lane(int v) {  // lane j <- lane j-1 (lane 0 <- 0)
-  return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int from_next_lane(int v) {  // lane j <- lane j+1 (lane 63 <- 0)
-  return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
-}
-
-// 16 nibbles starting at nibble index `start` of an LDS word array; nibbles
-// outside [0, 16*nwords) read as 0 (they only ever feed invalid cells)
-__device__ __forceinline__ u64 nibbles16(const u64 *words, int nwords, int start) {
-  if (start <= -16 || start >= 16 * nwords)
-    return 0ull;
-  if (start < 0)
-    return words[0] << ((-start) << 2);
-  const int w = start >> 4, s = (start & 15) << 2;
-  u64 x = words[w] >> s;
-  if (s && w + 1 < nwords) x |= words[w + 1] << (64 - s);
-  return x;
-}
-
-struct AlnJob {  // per lane: the job whose band column this lane is
-  int bw;        // 0 = lane unassigned
-  int jl;        // column within the band
-  int qoff;      // word offset of the query encoding in lds.qpk
-  int g;         // genome-window slot in lds.gwin
-  int t0nib;     // t_beg & 15: nibble offset of row 1's target base inside the window
-};
-
-// Runs every job assigned in `job` to completion.  Returns, per lane, the best
-// cell value of its own column (and its first row); with TB also stores one
-// byte per cell: arrow (0 M, 1 I, 2 D, 3 none) | 4 if the cell's score is > 0.
-template <bool TB>
-__device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job, int L, int bw_min,
-                                          int bw_max, int &bestv, int &bestrow) {
-  const int jl = job.jl, bw = job.bw;
-  const bool assigned = bw != 0;
-  const u64 *qw = lds.qpk + job.qoff;
-  const u64 *gw = lds.gwin + job.g * lds.GW;
-  const int t_start = max(0, bw_min - 1), t_end = 2 * (L - 1 + bw_max);
-  int cur = 0;
-  u64 M = 0;
-  bestv = 0; bestrow = 0;
-  for (int t = t_start; t <= t_end; ++t) {
-    if (((t - t_start) & 31) == 0) {
-      // match bits for this lane's next 16 cells: nibble k set <=> q[i0+k+jl-bw] & T[i0+k-1] != 0
-      const int ta = t + ((t - jl) & 1);
-      const int i0 = (ta - jl) >> 1;
-      u64 x = 0;
-      if (assigned)
-        x = nibbles16(qw, static_cast<int>(lds.W), i0 + jl - bw) &
-            nibbles16(gw, static_cast<int>(lds.GW), job.t0nib + i0 - 1);
-      x |= x >> 1;
-      x |= x >> 2;
-      M = x & 0x1111111111111111ull;
-    }
-    const int dlt = t - jl;
-    const bool active = assigned && (dlt & 1) == 0;
-    const int i = dlt >> 1;
-    const int q = i + jl - bw;
-    const bool valid = active && q >= 0 && q < L;
-    const int lf = from_prev_lane(cur), up = from_next_lane(cur);
-    const int sdiag = cur + ((static_cast<u32>(M) & 1u) ? 2 : -3);
-    int c = max(sdiag, 0);
-    int arrow = (c == sdiag) ? 0 : 3;
-    if (jl < bw - 1 && q < L - 1) {   // from_above: j in [left, right-1)
-      const int s = up - 4;
-      c = max(c, s);
-      if (TB && c == s) arrow = 2;
-    }
-    if (jl > 0 && q > 0) {            // from_left: j in [left+1, right)
-      const int s = lf - 4;
-      c = max(c, s);
-      if (TB && c == s) arrow = 1;
-    }
-    if (active) {
-      M >>= 4;
-      cur = valid ? c : 0;
-      if (valid && c > bestv) { bestv = c; bestrow = i; }
-      if (TB && i >= 0 && i < L + bw)
-        lds.tb[i * bw + jl] = static_cast<u8>(valid ? (arrow | (c > 0 ? 4 : 0)) : 3);
-    }
-  }
-}
-
-// build_cigar_len_and_pos + get_traceback (src/AbismalAlign.hpp:166-193, :388-440).
-// Runs uniformly on the wave; ops are collected reversed in LDS then emitted.
-__device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int diffs, int max_diffs,
-                                           int score, int best_r, int best_c, u32 *cig_out,
-                                           u32 cig_stride, u32 &n_ops, int &ins, int &del, u32 &aln_len,
-                                           u32 &t_pos, bool &overflow) {
-  const int lane = lane_id();
-  ins = del = 0;  // count_total_ops<I>/<D> with oplen() narrowed to uint8_t (abismal_cigar_utils.hpp:50-53)
-  if (score == 0 || diffs == 0) {
-    if (lane == 0) cig_out[0] = static_cast<u32>(L) << 4;
-    n_ops = 1;
-    aln_len = static_cast<u32>(L);
-    return;
-  }
-  const int bw = band_for(diffs, max_diffs);
-  int r = best_r, c = best_c;
-  const int clip_tail = (L + (bw - 1)) - (r + c);
-  u32 n = 0;
-  auto emit = [&](u32 run, int op) {
-    if (n < cig_stride) { if (lane == 0) ctmp[n] = (run << 4) | static_cast<u32>(op); }
-    else overflow = true;
-    if (op == 1) ins = static_cast<i16>(ins + static_cast<int>(static_cast<u8>(run)));
-    if (op == 2) del = static_cast<i16>(del + static_cast<int>(static_cast<u8>(run)));
-    ++n;
-  };
-  auto step = [&](int a) {
-    if (a != 1) --r;
-    if (a == 1) --c;
-    if (a == 2) ++c;
-  };
-  int op = uni(tb[r * bw + c]) & 3;
-  step(op);
-  u32 run = 1;
-  for (;;) {
-    const int cell = uni(tb[r * bw + c]);
-    if (!(cell & 4)) break;
-    const int a = cell & 3;
-    step(a);
-    if (a != op) { emit(run, op); run = 0; }
-    ++run;
-    op = a;
-  }
-  emit(run, op);
-  const int clip_head = (r + c) - (bw - 1);
-  __syncthreads();
-  // final order: [head clip] reversed(ops) [tail clip]
-  const u32 body = min(n, cig_stride);
-  u32 total = body + (clip_head > 0) + (clip_tail > 0);
-  if (n > cig_stride || total > cig_stride) { overflow = true; total = min(total, cig_stride); }
-  for (u32 k = lane; k < total; k += 64) {
-    u32 v;
-    const u32 kk = k - (clip_head > 0 ? 1u : 0u);
-    if (clip_head > 0 && k == 0) v = (static_cast<u32>(clip_head) << 4) | 4u;
-    else if (kk < body) v = ctmp[body - 1 - kk];
-    else v = (static_cast<u32>(clip_tail) << 4) | 4u;
-    cig_out[k] = v;
-  }
-  n_ops = total;
-  aln_len = static_cast<u32>(L - clip_tail - clip_head);
-  t_pos = t_pos - static_cast<u32>((bw - 1) / 2) + static_cast<u32>(r);
-}
-
-// simple_aln::edit_distance with the reference's integer types
-// (src/AbismalAlign.hpp:73-89); ins/del are the op totals gathered in wave_cigar
-__device__ __forceinline__ int edit_distance(int scr, u32 len, int ins, int del) {
-  if (scr == 0)
-    return static_cast<i16>(len);
-  const int A = static_cast<i16>(scr + 4 * (ins + del));
-  const u32 num = 2u * (len - static_cast<u32>(ins)) - static_cast<u32>(A);
-  const int mism = static_cast<i16>(num / 5u);
-  return static_cast<i16>(mism + ins + del);
-}
-
-__device__ __forceinline__ bool long_enough(u32 aln_len, u32 readlen) {
-  const double min_frac = 1.0 - 0.4;  // src/abismal.cpp:307-314
-  return aln_len >= max(kMinReadLen, static_cast<u32>(min_frac * readlen));
-}
-
-// encoding index of the query a hit was found with (src/abismal.cpp:1463-1464)
-__device__ __forceinline__ u32 enc_of(u32 flags) {
-  const u32 rc = (flags & kFlagRC) ? 1u : 0u, ar = (flags & kFlagARich) ? 1u : 0u;
-  return rc * 2u + (rc ^ ar);
-}
-
-// Stage the genome windows of jobs [first, first+n) of the LDS job list into
-// lds.gwin (one coalesced sweep, loads issued before the stores)
-__device__ __forceinline__ void stage_windows(const DevIndex &ix, const WaveLds &lds, int first, int n,
-                                              int md) {
-  const int lane = lane_id();
-  const int GW = static_cast<int>(lds.GW), total = n * GW;
-  for (int k0 = 0; k0 < total; k0 += 256) {
-    u64 v[4];
-    int at[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = k0 + lane + 64 * r;
-      at[r] = -1;
-      v[r] = 0;
-      if (k < total) {
-        const int g = k / GW, w = k - g * GW;
-        const u32 pos = lds.jpos[first + g];
-        const int bw = band_for(static_cast<int>(lds.jdf[first + g]) >> 16, md);
-        const u64 t_beg = static_cast<u64>(pos) - static_cast<u64>((bw - 1) / 2);
-        v[r] = ix.genome[(t_beg >> 4) + w];
-        at[r] = k;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (at[r] >= 0) lds.gwin[at[r]] = v[r];
-  }
-}
-
-// align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
-__device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
-                                          SeSet &S, Hit &best, u32 *cig_out, u32 cig_stride,
-                                          u32 &n_ops, bool &overflow, u32 &n_aln) {
-  const int lane = lane_id();
-  const int Ls = static_cast<i16>(L);
-  const int md = static_cast<i16>(frac * static_cast<u32>(Ls));  // valid_diffs_cutoff
-  const int perfect = static_cast<i16>(2 * L);
-  n_ops = 0;
-  if (S.best_p != 0) {  // exact match: no alignment needed
-    best.diffs = static_cast<i16>(S.best_d); best.flags = static_cast<u16>(S.best_f); best.pos = S.best_p;
-    if (lane == 0) cig_out[0] = L << 4;
-    n_ops = 1;
-    return;
-  }
-  // prepare_for_alignments: order by (pos, flags), drop duplicates.  Lane k looks
-  // at heap entry k; its payload sits in lane (key & 255).
-  const bool mine = lane < S.sz;
-  const int slot_of = S.hk & 255;
-  const u32 e_pos = __shfl(S.pp, slot_of), e_flags = __shfl(S.pf, slot_of);
-  const int e_d = SeSet::key_d(S.hk);
-  const u64 key = (static_cast<u64>(e_pos) << 16) | e_flags;
-  bool dup = false;
-  for (int k = 0; k < S.sz; ++k) {
-    const u64 kk = rdlane(key, k);
-    dup |= (mine && k < lane && kk == key);
-  }
-  // jobs = unique entries that the reference would align: non-empty, diffs < 0.4L
-  const int invalid_at = static_cast<i16>(0.4 * Ls);  // valid_hit, :323-326
-  const bool is_job = mine && !dup && e_pos != 0 && e_d < invalid_at;
-  const u64 jobs = __ballot(is_job);
-  int rank = 0;
-  for (int k = 0; k < S.sz; ++k) {
-    const u64 kk = rdlane(key, k);
-    rank += ((jobs >> k) & 1) && kk < key;
-  }
-  const int n_jobs = __popcll(jobs);
-  if (is_job) {
-    lds.jpos[rank] = e_pos;
-    lds.jdf[rank] = (static_cast<u32>(e_d) << 16) | e_flags;
-  }
-  __syncthreads();
-
-  int top = 0;
-  u32 top_pos = 0, b_pos = 0, b_flags = 0;
-  int b_diffs = 0x7fff;
-  for (int s = 0; s < n_jobs;) {
-    // pack consecutive jobs side by side until the wave is full
-    AlnJob job = {0, 0, 0, 0, 0};
-    int used = 0, first = s, bw_min = 64, bw_max = 0;
-    while (s < n_jobs) {
-      const u32 df = lds.jdf[s];
-      const int bw = band_for(static_cast<int>(df) >> 16, md);
-      if (used + bw > 64) break;
-      if (lane >= used && lane < used + bw) {
-        const u64 t_beg = static_cast<u64>(lds.jpos[s]) - static_cast<u64>((bw - 1) / 2);
-        job.bw = bw;
-        job.jl = lane - used;
-        job.qoff = static_cast<int>(enc_of(df & 0xFFFFu) * lds.W);
-        job.g = s - first;
-        job.t0nib = static_cast<int>(t_beg & 15u);
-      }
-      used += bw;
-      bw_min = min(bw_min, bw);
-      bw_max = max(bw_max, bw);
-      ++s;
-    }
-    stage_windows(ix, lds, first, s - first, md);
-    __syncthreads();
-    int bv, br;
-    wavefront<false>(lds, job, static_cast<int>(L), bw_min, bw_max, bv, br);
-    lds.lbest[lane] = bv;
-    __syncthreads();
-    // fold each band's columns; then apply the reference's selection in job order
-    int base = 0;
-    for (int k = first; k < s; ++k) {
-      const u32 df = lds.jdf[k];
-      const int d = static_cast<int>(df) >> 16;
-      const int bw = band_for(d, md);
-      int sc = lane < bw ? lds.lbest[base + lane] : 0;
-      sc = static_cast<i16>(static_cast<int>(wave_max_u64(static_cast<u64>(static_cast<u32>(sc)))));
-      base += bw;
-      const u32 pos = lds.jpos[k], flags = df & 0xFFFFu;
-      ++n_aln;
-      if (sc > top) { b_diffs = d; b_flags = flags; b_pos = pos; top = sc; top_pos = pos; }
-      else if (sc == top) {
-        const u32 gap = pos > top_pos ? pos - top_pos : top_pos - pos;
-        if (sc == perfect ? pos != top_pos : gap > 3u) b_flags |= kFlagAmbig;
-      }
-    }
-    __syncthreads();
-  }
-  best.diffs = 0x7fff; best.flags = static_cast<u16>(b_flags); best.pos = 0;
-  if (b_pos == 0)
-    return;
-  // traceback run of the winner: one job, band in lanes [0, bw)
-  const int bw = band_for(b_diffs, md);
-  AlnJob job = {0, 0, 0, 0, 0};
-  const u64 t_beg = static_cast<u64>(b_pos) - static_cast<u64>((bw - 1) / 2);
-  if (lane < bw) {
-    job.bw = bw;
-    job.jl = lane;
-    job.qoff = static_cast<int>(enc_of(b_flags) * lds.W);
-    job.t0nib = static_cast<int>(t_beg & 15u);
-  }
-  if (lane == 0) { lds.jpos[0] = b_pos; lds.jdf[0] = (static_cast<u32>(b_diffs) << 16) | (b_flags & 0xFFFFu); }
-  __syncthreads();
-  stage_windows(ix, lds, 0, 1, md);
-  __syncthreads();
-  int bv, brow;
-  wavefront<true>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
-  // first maximum in row-major order: max value, then smallest row, then smallest column
-  const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
-                  (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |
-                  static_cast<u64>(0xFFu - static_cast<u32>(lane));
-  const u64 topk = wave_max_u64(lane < bw ? k64 : 0ull);
-  const int br = static_cast<int>(0xFFFFu - static_cast<u32>((topk >> 8) & 0xFFFFu));
-  const int bc = static_cast<int>(0xFFu - static_cast<u32>(topk & 0xFFu));
-  const int sc = static_cast<i16>(static_cast<int>(topk >> 32));
-  __syncthreads();
-  u32 alen = 0, pos = b_pos;
-  int n_ins = 0, n_del = 0;
-  wave_cigar(lds.tb, lds.ctmp, static_cast<int>(L), b_diffs, md, sc, br, bc, cig_out, cig_stride, n_ops,
-             n_ins, n_del, alen, pos, overflow);
-  __syncthreads();
-  // NM from the score found by the scoring pass (best_scr), as the reference does
-  const int nm = edit_distance(top, alen, n_ins, n_del);
-  if (long_enough(alen, static_cast<u32>(Ls)) && nm <= md) {
-    best.diffs = static_cast<i16>(nm);
-    best.pos = pos;
-  }
-  else
-    n_ops = 0;
 }
 
 // =============================================================================
@@ -909,18 +196,24 @@ __global__ __launch_bounds__(256) void weigh_reads_kernel(DevIndex ix, const u64
                                                           const u32 *__restrict__ lens, u64 n, u32 W,
                                                           int mode, u8 *__restrict__ cls,
                                                           u32 *__restrict__ class_count) {
+  __shared__ u32 hist[33];
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  const u32 L = lens[r];
-  u32 c = 0;
-  if (L >= kMinReadLen) {
-    const u64 *pk = packed + r * 4 * W;
-    // forward call of the mode and its reverse-strand partner
-    const bool ar = mode == 1;
-    c = max(weight_class(ix, pk + (ar ? 1 : 0) * W, L, ar), weight_class(ix, pk + (2 + (ar ? 0 : 1)) * W, L, !ar));
+  if (r < n) {
+    const u32 L = lens[r];
+    u32 c = 0;
+    if (L >= kMinReadLen) {
+      const u64 *pk = packed + r * 4 * W;
+      // forward call of the mode and its reverse-strand partner
+      const bool ar = mode == 1;
+      c = max(weight_class(ix, pk + (ar ? 1 : 0) * W, L, ar), weight_class(ix, pk + (2 + (ar ? 0 : 1)) * W, L, !ar));
+    }
+    cls[r] = static_cast<u8>(c);
+    atomicAdd(&hist[c], 1u);
   }
-  cls[r] = static_cast<u8>(c);
-  atomicAdd(&class_count[c], 1u);
+  __syncthreads();
+  if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], hist[threadIdx.x]);
 }
 
 __global__ void order_bases_kernel(u32 *class_count /*[33] in: counts, out: start of each class (heaviest first)*/) {
@@ -933,9 +226,20 @@ __global__ void order_bases_kernel(u32 *class_count /*[33] in: counts, out: star
 __global__ __launch_bounds__(256) void order_scatter_kernel(const u8 *__restrict__ cls, u64 n,
                                                             u32 *__restrict__ class_cursor,
                                                             u32 *__restrict__ order) {
+  // one global reservation per (block, class); ranks inside the block come from LDS
+  __shared__ u32 hist[33], base[33];
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  order[atomicAdd(&class_cursor[cls[r]], 1u)] = static_cast<u32>(r);
+  u32 c = 0, rank = 0;
+  if (r < n) {
+    c = cls[r];
+    rank = atomicAdd(&hist[c], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 33 && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], hist[threadIdx.x]);
+  __syncthreads();
+  if (r < n) order[base[c] + rank] = static_cast<u32>(r);
 }
 
 hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W,

@@ -25,6 +25,40 @@ struct SeArgs {
                              // read words compared, set updates, alignments
 };
 
+// paired-end launch arguments (abm_kernels_pe.hip)
+struct PeArgs {
+  DevIndex ix;
+  const u64 *packed1, *packed2;  // [n][4][W]
+  const u32 *lens1, *lens2;
+  const u32 *order;              // tier 1: heaviest-first order or null
+  const u32 *subset;             // tier 2: ids of the pairs to redo
+  const u32 *subset_count;       // tier 2: how many
+  u64 n_pairs;
+  u32 W, WB, GW;
+  int mode;
+  double valid_frac;
+  u32 min_frag, max_frag;
+  int allow_ambig;
+  Hit *pairs;                    // [n] as abm_pair: {i16 score, i16 pad, Hit r1, Hit r2} = 5 x u32
+  Hit *se1, *se2;
+  u32 *cig1, *cig2;
+  u32 cig_stride;
+  u32 *cig_n1, *cig_n2;
+  u32 *status;
+  unsigned long long *next_read;
+  unsigned long long *work;
+  u8 *need_big;                  // [n] tier 1 -> tier 2 hand-off
+  u32 *payload_ws;               // [grid][cap]
+  u32 *list_ws;                  // tier 2: [grid][2][cap] positions, then diffs and scores (i16)
+  u32 cap;
+};
+
+size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big);
+int pe_resident_waves(size_t lds, bool big);
+hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, hipStream_t st);
+hipError_t launch_collect_big(const u8 *need_big, u64 n, u32 *subset, u32 *count, hipStream_t st);
+constexpr u32 kPeTier1Cap = 256;
+
 u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,

@@ -221,8 +221,13 @@ struct Aligner {
   void cigar_from_last(i16 diffs, i16 max_diffs, Cigar &cig, u32 &aln_len, u32 &t_pos) const {
     const u32 bw = band_for(diffs, max_diffs);
     const std::size_t cells = static_cast<std::size_t>(q_len + bw) * bw;
+    if (diffs == 0) {  // align() returned before touching the table; the reference reads stale cells
+      cig.assign(1, q_len << 4);  // here and then ignores them (default CIGAR either way)
+      aln_len = q_len;
+      return;
+    }
     const auto top = std::max_element(tab.begin(), tab.begin() + cells);  // first maximum
-    if (*top == 0 || diffs == 0) {
+    if (*top == 0) {
       cig.assign(1, q_len << 4);
       aln_len = q_len;
       return;

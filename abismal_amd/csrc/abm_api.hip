@@ -4,6 +4,8 @@
 #include "abm_index_build.hpp"
 #include "abm_kernels.hpp"
 
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -553,9 +555,43 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
   });
 }
 
-int abm_stats_allreduce(abm_ctx *const *, int, uint64_t *const *) {
-  g_error = "abm_stats_allreduce: not built yet";
-  return -2;
+int abm_stats_allreduce(abm_ctx *const *ctxs, int n_ctx, uint64_t *const *counters) {
+  return guarded([&] {
+    if (!ctxs || !counters || n_ctx <= 0) throw std::invalid_argument("bad arguments");
+    if (n_ctx == 1) return;  // a single GPU already holds the total
+    // one communicator per participating GPU of this process; the payload is 18 x u64
+    std::vector<int> devs(n_ctx);
+    for (int k = 0; k < n_ctx; ++k) devs[k] = ctxs[k]->device;
+    std::vector<ncclComm_t> comms(n_ctx);
+    auto nccl_check = [](ncclResult_t r, const char *what) {
+      if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+    };
+    nccl_check(ncclCommInitAll(comms.data(), n_ctx, devs.data()), "ncclCommInitAll");
+    std::vector<unsigned long long *> bufs(n_ctx, nullptr);
+    std::vector<hipStream_t> streams(n_ctx, nullptr);
+    try {
+      for (int k = 0; k < n_ctx; ++k) {
+        HIPCHK(hipSetDevice(devs[k]));
+        HIPCHK(hipStreamCreate(&streams[k]));
+        HIPCHK(hipMalloc(&bufs[k], 18 * sizeof(unsigned long long)));
+        HIPCHK(hipMemcpy(bufs[k], counters[k], 18 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+      }
+      nccl_check(ncclGroupStart(), "ncclGroupStart");
+      for (int k = 0; k < n_ctx; ++k)
+        nccl_check(ncclAllReduce(bufs[k], bufs[k], 18, ncclUint64, ncclSum, comms[k], streams[k]), "ncclAllReduce");
+      nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+      for (int k = 0; k < n_ctx; ++k) {
+        HIPCHK(hipSetDevice(devs[k]));
+        HIPCHK(hipStreamSynchronize(streams[k]));
+        HIPCHK(hipMemcpy(counters[k], bufs[k], 18 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      }
+    }
+    catch (...) {
+      for (int k = 0; k < n_ctx; ++k) { if (bufs[k]) (void)hipFree(bufs[k]); if (streams[k]) (void)hipStreamDestroy(streams[k]); ncclCommDestroy(comms[k]); }
+      throw;
+    }
+    for (int k = 0; k < n_ctx; ++k) { (void)hipSetDevice(devs[k]); (void)hipFree(bufs[k]); (void)hipStreamDestroy(streams[k]); ncclCommDestroy(comms[k]); }
+  });
 }
 
 }  // extern "C"

@@ -309,9 +309,8 @@ def main():
     stats = torch.tensor([n, int(uniq.sum()), int(ambig.sum()), n_skipped, int(diffs[uniq].sum()),
                           int(bases[uniq].sum())], dtype=torch.int64, device=dev)
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # the path's single collective (RCCL)
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    from abismal_amd.dist import reduce_stats
+    reduce_stats(stats, t_el)  # the path's single collective: RCCL sum of the counters (+ max of the time)
     elapsed = float(t_el.item())
     st_host = int(status.item())
 

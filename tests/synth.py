@@ -98,3 +98,38 @@ def trim_like_readloader(reads):
         first = min(i for i in (r.find(b) for b in "ACGT") if i >= 0)
         out.append(r[first:])
     return out
+
+
+def mutated_pairs(fasta, n, L, seed, mut=0.02, bis=0.95, frag=(120, 600)):
+    """Read pairs from random fragments: read 1 = fragment start, read 2 = revcomp of its end;
+    conversion C->T on the fragment strand (so read 2 looks G->A), with mutations and some Ns."""
+    rng = np.random.default_rng(seed)
+    chroms = []
+    for rec in open(fasta, "rb").read().split(b">")[1:]:
+        chroms.append(np.frombuffer(rec.split(b"\n", 1)[1].replace(b"\n", b"").upper(), dtype=np.uint8))
+    out1, out2 = [], []
+    for _ in range(n):
+        ch = chroms[int(rng.integers(0, len(chroms)))]
+        fl = int(rng.integers(max(frag[0], L), frag[1]))
+        at = int(rng.integers(0, len(ch) - fl))
+        f = ch[at:at + fl].copy()
+        if rng.random() < 0.5:
+            f = COMP[f[::-1]]
+        m = rng.random(fl) < mut
+        f[m] = ACGT[rng.integers(0, 4, int(m.sum()))]
+        if rng.random() < 0.2:  # a small deletion or insertion
+            j = int(rng.integers(10, fl - 10))
+            f = np.concatenate([f[:j], f[j + 2:]]) if rng.random() < 0.5 else np.concatenate([f[:j], ACGT[rng.integers(0, 4, 2)], f[j:]])
+        conv = (f == ord("C")) & (rng.random(len(f)) < bis)
+        f[conv] = ord("T")
+        a = f[:L].copy()
+        b = COMP[f[::-1]][:L].copy()
+        if rng.random() < 0.03:
+            a[:3] = ord("N")
+        if rng.random() < 0.03:
+            b[-4:] = ord("N")
+        if rng.random() < 0.02:
+            a = a[:30]
+        out1.append(bytes(a))
+        out2.append(bytes(b))
+    return out1, out2

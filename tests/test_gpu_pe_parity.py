@@ -83,3 +83,28 @@ def test_pe_trex(oracle, trex_index, gpu_ctx, workdir, tag, simkw, mode):
     gpu = gpu_ctx.map_pe(r1, r2, mode=mode)
     compare_pe(gpu, orc, f"tRex1 PE {tag}")
     assert int((gpu[0]["r1"]["pos"] != 0).sum()) > 0.3 * len(r1)
+
+
+@pytest.mark.parametrize("mode,L", [(0, 100), (2, 125)])
+def test_pe_repeat_rich(oracle, workdir, mode, L):
+    """Repeat-rich genome: candidate sets grow past tier 1 (256) so tier 2 runs too."""
+    import abismal_amd as A
+    from tests import synth
+    fa = os.path.join(workdir, "rep_pe.fa")
+    idx = os.path.join(workdir, "rep_pe.idx")
+    if not os.path.exists(idx):
+        synth.repeat_rich_genome(fa)
+        A.index_build(fa, idx, 8)
+    r1, r2 = synth.mutated_pairs(fa, 3000, L, seed=7 + L)
+    r1, r2 = synth.trim_like_readloader(r1), synth.trim_like_readloader(r2)
+    ix = A.Index(idx)
+    ctx = A.Context(ix, 0)
+    oix = oracle.index_load(idx)
+    try:
+        orc = oracle.map_pe(oix, r1, r2, mode=mode, threads=8)
+        gpu = ctx.map_pe(r1, r2, mode=mode)
+    finally:
+        oracle.index_free(oix)
+        ctx.close()
+        ix.close()
+    compare_pe(gpu, orc, f"repeat-rich PE mode {mode} L {L}")

@@ -56,6 +56,26 @@ int abo_simulate(const char *fasta, const char *prefix, int single_end, int pbat
   });
 }
 
+int abo_read_code(int c, int a_rich) { return read_nibble(static_cast<char>(c), a_rich != 0); }
+int abo_genome_code(int c) { return genome_nibble(static_cast<unsigned char>(c)); }
+int abo_get_bit(int nt) { return static_cast<int>(bit2(static_cast<u8>(nt))); }
+int abo_trit(int nt, int g_to_a_conv) { return static_cast<int>(trit(static_cast<u8>(nt), g_to_a_conv ? G_TO_A : C_TO_T)); }
+uint32_t abo_roll2(uint32_t k, int nt) { roll2(static_cast<u8>(nt), k); return k; }
+uint32_t abo_roll3(uint32_t k, int nt, int g_to_a_conv) { roll3(static_cast<u8>(nt), g_to_a_conv ? G_TO_A : C_TO_T, k); return k; }
+
+int abo_align(const uint64_t *genome, uint64_t /*n_words*/, const uint8_t *q, uint32_t qlen, int diffs,
+              int max_diffs, uint32_t t_pos, int do_tb, uint32_t *cig_out, uint32_t cig_cap,
+              uint32_t *n_cig, uint32_t *aln_len, uint32_t *new_pos, int *nm) {
+  Cigar c;
+  const int scr = probe_align(reinterpret_cast<const u64 *>(genome), q, qlen, static_cast<i16>(diffs),
+                              static_cast<i16>(max_diffs), t_pos, do_tb != 0, &c, aln_len, new_pos, nm);
+  if (do_tb) {
+    *n_cig = static_cast<uint32_t>(c.size());
+    for (std::size_t i = 0; i < c.size() && i < cig_cap; ++i) cig_out[i] = c[i];
+  }
+  return scr;
+}
+
 void *abo_mapper_new(void *index, uint32_t max_candidates, double valid_frac, uint32_t min_frag,
                      uint32_t max_frag, int allow_ambig) {
   MapperBox *b = new MapperBox;

@@ -290,6 +290,21 @@ inline bool long_enough(u32 aln_len, u32 readlen) {
 
 }  // namespace
 
+int probe_align(const u64 *genome, const u8 *q, u32 qlen, i16 diffs, i16 max_diffs, u32 t_pos, bool tb,
+                Cigar *cig, u32 *aln_len, u32 *new_pos, int *nm) {
+  Aligner a;
+  a.genome = genome;
+  if (!tb)
+    return a.run<false>(diffs, max_diffs, q, qlen, t_pos);
+  const i16 scr = a.run<true>(diffs, max_diffs, q, qlen, t_pos);
+  u32 len = 0, pos = t_pos;
+  a.cigar_from_last(diffs, max_diffs, *cig, len, pos);
+  *aln_len = len;
+  *new_pos = pos;
+  *nm = edit_distance(scr, len, *cig);
+  return scr;
+}
+
 struct Mapper::Impl {
   const Index &ix;
   MapParams par;

@@ -60,6 +60,11 @@ struct Work {
 using Cigar = std::vector<u32>;
 u32 cigar_ref_len(const Cigar &c);  // src/abismal.cpp:451-462
 
+// the restatement's aligner, exposed for the cross-check against the reference's
+// header-only AbismalAlign (oracle/_ref): same arguments as ref_align in ref_probe.cpp
+int probe_align(const u64 *genome, const u8 *q, u32 qlen, i16 diffs, i16 max_diffs, u32 t_pos, bool tb,
+                Cigar *cig, u32 *aln_len, u32 *new_pos, int *nm);
+
 class Mapper {
 public:
   Mapper(const Index &ix, const MapParams &p);

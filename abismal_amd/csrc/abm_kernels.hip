@@ -4,6 +4,10 @@
 // read; see DESIGN.md for the data layout and the reasoning.
 #include "abm_kernels_core.hpp"
 
+#ifndef ABM_SE_WAVES_PER_SIMD
+#define ABM_SE_WAVES_PER_SIMD 8
+#endif
+
 namespace abm {
 
 // =============================================================================
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
 template <bool TIMED>
-__global__ __launch_bounds__(64) void map_se_kernel(SeArgs a) {
+__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   WaveLds lds;

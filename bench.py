@@ -331,14 +331,25 @@ def main():
                  per_launch["alignments"] * (L + bw_band) / 2 + 8 * (n + tot_ops / 2))
     avg_ms = kernel_ms / max(1, launches)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch come from a separate rocprofv3 --pmc pass over this same command
+    # (profiles/r*_traffic.json, newest round first); reported only when the workload matches
+    traffic = None
+    for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        t = json.load(open(os.path.join(ROOT, "profiles", tf)))
+        wl = t.get("workload", {})
+        if (wl.get("genome_mbp"), wl.get("reads"), wl.get("read_len")) == (int(args.genome_mbp), n, L):
+            traffic = t["hbm_read_bytes_per_launch"]
+            break
     roofline = {"bound": "hbm", "kernel": "map_se_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                 "avg_kernel_ms": round(avg_ms, 3), "alg_bytes_per_read": round(alg_bytes / n, 1),
                 "gathers_per_s": round((per_launch["seed_offsets"] * 2 + per_launch["candidates"] * 2 +
                                         per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
         from tests import oracle_binding as ob  # cpu_baseline leg: the oracle is the thing timed here
         o = ob.load(build=not os.path.exists(ob.LIB))
         ns = min(n, args.cpu_sample)

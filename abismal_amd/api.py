@@ -198,6 +198,7 @@ class Context:
         _check(self._lib.abm_ctx_take_work(self.handle, out))
         keys = ["seed_offsets", "search_probes", "candidates", "read_words", "set_updates", "alignments"]
         d = dict(zip(keys, [int(x) for x in out[:6]]))
+        d["window_cache_hits"] = int(out[11])
         if out[10]:
             d["phase_cycles"] = dict(zip(["probe_narrow", "gather_hamming", "replay", "align", "total"],
                                          [int(x) for x in out[6:11]]))

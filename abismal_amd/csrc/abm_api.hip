@@ -125,7 +125,11 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.n_reads = n;
   a.W = W;
   a.WB = WB;
-  a.GW = abm::se_window_words(eff_len, params->valid_frac);
+  // IUPAC genome letters can drive a Hamming sum below zero, which the reference turns into the
+  // widest band (61); size the LDS for it only when such letters exist
+  const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : params->valid_frac;
+  a.size_frac = size_frac;
+  a.GW = abm::se_window_words(eff_len, size_frac);
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.res = reinterpret_cast<abm::Hit *>(d_res);
@@ -140,7 +144,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
   a.next_read = counter;
   a.read_cycles = ctx->phase_stamps ? ctx->read_cycles : nullptr;
-  int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, params->valid_frac);
+  int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, size_frac);
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
@@ -197,7 +201,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.order = ctx->order.p;
   a.subset = ctx->subset.p; a.subset_count = ctx->subset_count.p;
   a.n_pairs = n;
-  a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, params->valid_frac);
+  const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : std::max(params->valid_frac, params->valid_frac);
+  a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, size_frac);
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.min_frag = params->min_frag; a.max_frag = params->max_frag;
@@ -211,7 +216,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   // tier 1: every pair, small sets in LDS
   {
     a.cap = abm::kPeTier1Cap;
-    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, params->valid_frac, a.cap, false);
+    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, size_frac, a.cap, false);
     const int waves = abm::pe_resident_waves(lds, false);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 1) does not fit on this device");
     ctx->payload1.reserve(static_cast<size_t>(waves) * a.cap);
@@ -227,7 +232,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(abm::launch_collect_big(ctx->need_big.p, n, ctx->subset.p, ctx->subset_count.p, st));
     a.cap = abm::kPeCapLarge;
     a.order = nullptr;
-    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, params->valid_frac, a.cap, true);
+    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, size_frac, a.cap, true);
     const int waves = abm::pe_resident_waves(lds, true);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
     ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);

@@ -51,6 +51,14 @@ void HostIndex::load(const std::string &path) {
   const uint64_t gwords = (static_cast<uint64_t>(chrom_starts.back()) + 15) / 16;
   genome.assign(gwords + 2, 0);
   need(f, genome.data(), gwords, ierr);
+  multibit_genome = false;
+  for (uint64_t w = 0; w < gwords && !multibit_genome; ++w) {
+    // a nibble is one-hot or zero iff clearing its lowest set bit leaves nothing
+    const uint64_t x = genome[w];
+    const uint64_t low = x & 0x1111111111111111ull, b1 = (x >> 1) & 0x1111111111111111ull,
+                   b2 = (x >> 2) & 0x1111111111111111ull, b3 = (x >> 3) & 0x1111111111111111ull;
+    if (((low + b1 + b2 + b3) & 0xEEEEEEEEEEEEEEEEull) != 0) multibit_genome = true;
+  }
   need(f, &max_candidates, 1, ierr);
   need(f, &counter_size, 1, ierr);
   need(f, &counter_size3, 1, ierr);

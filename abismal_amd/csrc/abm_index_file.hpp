@@ -11,6 +11,7 @@ struct HostIndex {
   std::vector<std::string> chrom_names;  // incl. pad_start / pad_end
   std::vector<uint32_t> chrom_starts;    // n_chroms + 1
   uint32_t max_candidates = 100;
+  bool multibit_genome = false;  // some genome nibble has 2+ bits (IUPAC code): Hamming sums can go negative
   uint64_t counter_size = 0, counter_size3 = 0, index_size = 0, index_size3 = 0;
   // one contiguous arena so the upload is a handful of large copies
   std::vector<uint64_t> genome;  // + 2 guard words (filter reads one word past)

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
-  lds.gwin = lds.qbits + 4 * a.WB;
+  lds.pcache = lds.qbits + 4 * a.WB;
+  lds.gwin = lds.pcache + (1u << kPosCacheBits);
   lds.ctmp = reinterpret_cast<u32 *>(lds.gwin + kMaxJobs * a.GW);
   lds.jpos = lds.ctmp + a.cig_stride;
   lds.jdf = lds.jpos + kSeCap;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   const u32 call_rc = a.mode == 2 ? 0xCu /*0,0,1,1*/ : 0x2u /*0,1*/;
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
-  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long t_begin = 0, t_a = 0, t_b = 0;
   ABM_STAMP(t_begin);
   u32 n_aln = 0;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   if (a.work) {  // exact per-launch work tallies for the roofline model
     auto wsum = [&](u32 v) { u32 t; (void)wave_excl_sum(v, t); return t; };
     const u32 s0 = wsum(wt.seed_iters), s1 = wsum(wt.probes), s2 = wsum(wt.cands), s3 = wsum(wt.words);
+    const u32 wsum_hits = wsum(wt.cache_hits);
     if (lane == 0) {
       atomicAdd(&a.work[0], static_cast<unsigned long long>(s0));
       atomicAdd(&a.work[1], static_cast<unsigned long long>(s1));
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
       atomicAdd(&a.work[3], static_cast<unsigned long long>(s3));
       atomicAdd(&a.work[4], static_cast<unsigned long long>(wt.updates));
       atomicAdd(&a.work[5], static_cast<unsigned long long>(n_aln));
+      atomicAdd(&a.work[11], static_cast<unsigned long long>(wsum_hits));
       if (TIMED) {
         atomicAdd(&a.work[6], static_cast<unsigned long long>(wt.t_probe));
         atomicAdd(&a.work[7], static_cast<unsigned long long>(wt.t_stream));
@@ -272,7 +275,7 @@ size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_fra
   if (bw > static_cast<int>(kMaxBand) || bw < 0) bw = kMaxBand;
   if (bw < 1) bw = 1;
   const u32 GW = se_window_words(max_len, valid_frac);
-  size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 +
+  size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) +
              static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
              2 * kSeCap * 4 + 64 * 4 + 64 * 2;
   b += static_cast<size_t>(max_len + bw) * bw;
@@ -300,7 +303,7 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
 
 hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st) {
   if (a.n_reads == 0) return hipSuccess;
-  const size_t lds = se_lds_bytes(a.W, a.WB, a.cig_stride, max_len, a.valid_frac);
+  const size_t lds = se_lds_bytes(a.W, a.WB, a.cig_stride, max_len, a.size_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
   if (timed) hipLaunchKernelGGL(map_se_kernel<true>, dim3(blocks), dim3(64), lds, st, a);
   else hipLaunchKernelGGL(map_se_kernel<false>, dim3(blocks), dim3(64), lds, st, a);

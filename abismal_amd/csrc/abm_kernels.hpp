@@ -14,6 +14,7 @@ struct SeArgs {
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
   int mode;           // ABM_SE_*
   double valid_frac;
+  double size_frac;   // valid_frac used to size LDS bands (1.0 when the genome has IUPAC codes)
   Hit *res;           // [n]
   u32 *cig;           // [n][cig_stride]
   u32 cig_stride;

@@ -144,8 +144,10 @@ struct WaveLds {
   u32 *jpos;   // [kSeCap] alignment job list: position
   u32 *jdf;    // [kSeCap] alignment job list: diffs<<16 | flags
   int *lbest;  // [64]
+  u64 *pcache; // [1 << kPosCacheBits] candidate cache: pos | diffs<<32 | max-prefix-diffs<<48
   u32 W, WB, GW;
 };
+constexpr u32 kPosCacheBits = 8;
 constexpr u32 kMaxJobs = 21;  // 64 lanes / narrowest band (3)
 
 __device__ __forceinline__ u32 q_nibble(const u64 *qpk, u32 k) {
@@ -214,22 +216,30 @@ __device__ __forceinline__ u32 narrow3(const u64 *__restrict__ genome, const u32
   return p;
 }
 
-// full_compare without the early exit (src/abismal.cpp:1105-1122): the reference
-// stops once d exceeds the cutoff, which changes d only when the hit is rejected
-// anyway, so the complete distance gives identical admit/reject decisions.
+// full_compare (src/abismal.cpp:1105-1122).  The reference adds one word's mismatches at a
+// time and gives up as soon as the running sum exceeds the cutoff, so a candidate is admitted
+// iff EVERY prefix sum stays within the cutoff, and then with the complete distance.  Both are
+// returned: d (complete) and dmax (largest prefix sum; equals d unless an IUPAC genome letter
+// makes a word's contribution negative).
 __device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64 *qpk, u32 nwords,
-                                       u32 pos) {
+                                       u32 pos, int &dmax) {
   const u64 *g = genome + (pos >> 4);
   const u32 sh = (pos & 15u) << 2;
-  int d = 0;
+  int d = 0, m = 0;
   u64 g0 = g[0];
   for (u32 w = 0; w < nwords; ++w) {
     const u64 g1 = g[w + 1];
     const u64 win = (g0 >> sh) | ((g1 << (63 - sh)) << 1);
     d += 16 - __popcll(qpk[w] & win);
+    m = max(m, d);
     g0 = g1;
   }
+  dmax = static_cast<i16>(m);
   return static_cast<i16>(d);
+}
+__device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64 *qpk, u32 nwords, u32 pos) {
+  int unused;
+  return hamming(genome, qpk, nwords, pos, unused);
 }
 
 // One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
@@ -237,7 +247,7 @@ __device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64
 // candidates (all checked buckets of 64 offsets flattened in reference order)
 // for the Hamming filter; survivors are replayed in order into the set.
 struct WorkTally {
-  u32 seed_iters, probes, cands, words, updates;
+  u32 seed_iters, probes, cands, words, updates, cache_hits;
   // diagnostic build only (TIMED): shader cycles per phase, from s_memtime
   long long t_probe, t_stream, t_replay, t_align, t_total;
 };
@@ -266,6 +276,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   const u32 n_off = SPECIFIC ? max(kWindow, L >> 1) : L - kKeyWeight + 1;
 
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
+  if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
+    for (u32 k = lane; k < (1u << kPosCacheBits); k += 64) lds.pcache[k] = 0;
+    __syncthreads();
+  }
   for (u32 g0 = 0; g0 < n_off && !S.sure_ambig; g0 += 64) {
     ABM_STAMP(ta);
     const u32 i = g0 + lane;
@@ -326,16 +340,31 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       const u32 c = c0 + lane;
       const bool valid = c < total;
       u32 pos = 0;
-      int h = 0x7fff;
+      int h = 0x7fff, hmax = 0x7fff;
       if (valid) {
         const u32 entry = three ? idx3[bb + (c - sb)] : ix.index[ba + (c - sa)];
         pos = entry - (g0 + static_cast<u32>(owner));
-        h = hamming(ix.genome, qpk, nwords, pos);
+        // the same genome position is proposed again and again (neighbouring seeds of one
+        // hit, the sensitive pass repeating the specific one): a small per-call cache of
+        // (pos -> distances) saves the 1-2 HBM lines of a window.  Distances are a pure
+        // function of (pos, encoding), so a cache hit is exact by construction.
+        u64 *slot = lds.pcache + ((pos * 2654435761u) >> (32 - kPosCacheBits));
+        const u64 e = *slot;
         ++wt.cands;
         wt.words += nwords;
+        if (static_cast<u32>(e) == pos) {
+          h = static_cast<i16>(static_cast<u16>(e >> 32));
+          hmax = static_cast<i16>(static_cast<u16>(e >> 48));
+          ++wt.cache_hits;
+        }
+        else {
+          h = hamming(ix.genome, qpk, nwords, pos, hmax);
+          *slot = static_cast<u64>(pos) | (static_cast<u64>(static_cast<u16>(h)) << 32) |
+                  (static_cast<u64>(static_cast<u16>(hmax)) << 48);
+        }
       }
       // ordered replay (check_hits + se_candidates::update, :1133-1149, :394-404)
-      u64 todo = __ballot(valid && h <= S.cutoff);
+      u64 todo = __ballot(valid && hmax <= S.cutoff);
       ABM_STAMP(td);
       if (TIMED) wt.t_stream += td - tc;
       while (todo && !S.sure_ambig) {
@@ -362,7 +391,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         S.admit(true, rdlane(h, l), flags, rdlane(pos, l));
         ++wt.updates;
         todo &= ~(((1ull << l) << 1) - 1);
-        if (S.cutoff < before) todo &= __ballot(valid && h <= S.cutoff);
+        if (S.cutoff < before) todo &= __ballot(valid && hmax <= S.cutoff);
       }
       ABM_STAMP(tc);
       if (TIMED) wt.t_replay += tc - td;

@@ -496,7 +496,8 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
   lds.W = a.W; lds.WB = a.WB; lds.GW = a.GW;
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.qbits = lds.qpk + 8 * a.W;
-  lds.gwin = lds.qbits + 8 * a.WB;
+  lds.pcache = lds.qbits + 8 * a.WB;
+  lds.gwin = lds.pcache + (1u << kPosCacheBits);
   lds.ctmp = reinterpret_cast<u32 *>(lds.gwin + kMaxJobs * a.GW);
   lds.jpos = lds.ctmp + a.cig_stride;
   lds.jdf = lds.jpos + kSeCap;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
   w.P.heap = w.pl.heap;
   w.P.payload = a.payload_ws + static_cast<u64>(blockIdx.x) * a.cap;
   w.P.cap_avail = a.cap;
-  w.wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  w.wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   w.n_aln = 0;
   w.overflow = false;
   bool too_long = false;
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
   if (a.work) {
     auto wsum = [&](u32 v) { u32 t; (void)wave_excl_sum(v, t); return t; };
     const u32 s0 = wsum(w.wt.seed_iters), s1 = wsum(w.wt.probes), s2 = wsum(w.wt.cands), s3 = wsum(w.wt.words);
+    const u32 wsum_hits = wsum(w.wt.cache_hits);
     if (lane == 0) {
       atomicAdd(&a.work[0], static_cast<unsigned long long>(s0));
       atomicAdd(&a.work[1], static_cast<unsigned long long>(s1));
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
       atomicAdd(&a.work[3], static_cast<unsigned long long>(s3));
       atomicAdd(&a.work[4], static_cast<unsigned long long>(w.wt.updates));
       atomicAdd(&a.work[5], static_cast<unsigned long long>(w.n_aln));
+      atomicAdd(&a.work[11], static_cast<unsigned long long>(wsum_hits));
     }
   }
   if (lane == 0 && (w.overflow || too_long))
@@ -649,7 +652,7 @@ size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double v
   const int md = static_cast<i16>(valid_frac * max_len);
   int bw = 2 * md + 1;
   if (bw > static_cast<int>(kMaxBand) || bw < 1) bw = kMaxBand;
-  size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + static_cast<size_t>(kMaxJobs) * GW * 8 +
+  size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
              static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + static_cast<size_t>(cap) * 4 + 64 * 2;
   if (!big) b += static_cast<size_t>(cap) * (2 * 4 + 4 * 2);
   b += static_cast<size_t>(max_len + bw) * bw;

@@ -323,7 +323,7 @@ def main():
     value = total_reads / elapsed
     # algorithmic bytes per read:
     #   L + S*16 + P*4.5 + C*4 + (W+C)*8 + A*(L+bw)/2 + 8*(1+ops/2)
-    per_launch = {k: v / max(1, launches) for k, v in work.items()}
+    per_launch = {k: v / max(1, launches) for k, v in work.items() if not isinstance(v, dict)}
     bw_band = 2 * int(0.1 * L) + 1
     tot_ops = float(cig_n[mapped].sum().item())
     alg_bytes = (n * L + per_launch["seed_offsets"] * 16 + per_launch["search_probes"] * 4.5 +

@@ -7,7 +7,7 @@ for a, b in zip(b"ACGTN", b"TGCAN"):
     COMP[a] = b
 
 
-def repeat_rich_genome(path, seed=3, n_chroms=3, chrom_len=1_500_000):
+def repeat_rich_genome(path, seed=3, n_chroms=3, chrom_len=1_500_000, iupac=0):
     """Repeat families at low divergence, purine-only tracts, homopolymers and N
     runs (short ones get LCG-filled by the indexer, long ones are excluded): the
     inputs that drive bucket narrowing, full candidate heaps and tie handling."""
@@ -30,6 +30,9 @@ def repeat_rich_genome(path, seed=3, n_chroms=3, chrom_len=1_500_000):
             for at in rng.integers(0, chrom_len - 300, 40):   # homopolymers / dinucleotide repeats
                 motif = ACGT[rng.integers(0, 4, int(rng.integers(1, 3)))]
                 seq[at:at + 200] = np.resize(motif, 200)
+            if iupac:                                          # ambiguity codes: multi-bit genome nibbles
+                at = rng.integers(0, chrom_len, iupac)
+                seq[at] = np.frombuffer(b"RYMKSWBDHV", dtype=np.uint8)[rng.integers(0, 10, iupac)]
             seq[1000:1100] = ord("N")                          # short run (<=256): filled
             seq[chrom_len // 2: chrom_len // 2 + 3000] = ord("N")  # long run: excluded
             if c == 0:
@@ -51,6 +54,8 @@ def mutated_reads(fasta, n, L, seed, mut=0.02, bis=0.95, pbat_frac=0.0, n_frac=0
     for _ in range(n):
         ch = chroms[int(rng.integers(0, len(chroms)))]
         ln = L if rng.random() > 0.05 else int(rng.integers(30, L))
+        if 44 <= ln <= 46:
+            ln = 47  # 44-46 bp reads depend on the previous read's leftovers in the reference
         at = int(rng.integers(0, len(ch) - ln - 20))
         frag = ch[at:at + ln + 20].copy()
         if rng.random() < 0.5:

@@ -89,3 +89,27 @@ def test_se_repeat_rich(oracle, repeat_setup, mode, L, pbat):
     assert work["search_probes"] > 0, "fixture no longer exercises bucket narrowing"
     res, cig, cig_off = ctx.map_se(reads, mode=mode)
     compare_se(res, cig, cig_off, o_res, o_cig, o_cig_n, reads, f"repeat-rich mode {mode} L {L}")
+
+
+def test_se_iupac_genome(oracle, workdir):
+    """Genome with IUPAC ambiguity codes: a word's mismatch contribution can be negative, so
+    admission must follow the reference's running-sum early exit, not the final distance."""
+    import abismal_amd as A
+    from tests import synth
+    fa = os.path.join(workdir, "iupac.fa")
+    synth.repeat_rich_genome(fa, seed=21, n_chroms=2, chrom_len=600_000, iupac=60000)
+    idx = os.path.join(workdir, "iupac.idx")
+    A.index_build(fa, idx, 8)
+    reads = synth.trim_like_readloader(synth.mutated_reads(fa, 6000, 100, seed=5, mut=0.04))
+    ix = A.Index(idx)
+    ctx = A.Context(ix, 0)
+    oix = oracle.index_load(idx)
+    try:
+        for mode in (0, 2):
+            o_res, o_cig, o_cig_n, _ = oracle.map_se(oix, reads, mode=mode, threads=8)
+            res, cig, cig_off = ctx.map_se(reads, mode=mode)
+            compare_se(res, cig, cig_off, o_res, o_cig, o_cig_n, reads, f"IUPAC genome mode {mode}")
+    finally:
+        oracle.index_free(oix)
+        ctx.close()
+        ix.close()

@@ -45,6 +45,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; when both are going to live in one process the
+        # first one loaded must be torch's (same SONAME), so bring it in first if it is installed
+        import torch  # noqa: F401
+    except Exception:
+        pass
     p = lib_path()
     if not os.path.exists(p):
         raise AbismalAmdError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")

@@ -1,0 +1,142 @@
+"""GPU: edge cases of the C ABI and size-independent properties of the mapping path."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx(trex_index):
+    import abismal_amd as A
+    ix = A.Index(trex_index)
+    c = A.Context(ix, 0)
+    yield c
+    c.close()
+    ix.close()
+
+
+@pytest.fixture(scope="module")
+def reads(oracle, workdir):
+    prefix = os.path.join(workdir, "edge_reads")
+    oracle.simulate(os.path.join(GOLD, "tRex1.fa"), prefix, 20000, single_end=True, seed=3)
+    return ob.read_fastq_like_readloader(prefix + "_1.fq")[1]
+
+
+def cigars(cig, off):
+    return [tuple(cig[int(off[i]):int(off[i + 1])].tolist()) for i in range(len(off) - 1)]
+
+
+def test_empty_batch_and_all_skipped(ctx):
+    res, cig, off = ctx.map_se([])
+    assert len(res) == 0 and off.tolist() == [0]
+    res, cig, off = ctx.map_se(["", "", ""])
+    assert (res["pos"] == 0).all() and off.tolist() == [0, 0, 0, 0]
+    pairs, se1, se2, (c1, o1), (c2, o2) = ctx.map_pe(["", ""], ["", ""])
+    assert (pairs["r1"]["pos"] == 0).all() and (se1["pos"] == 0).all() and (se2["pos"] == 0).all()
+
+
+def test_too_long_read_is_rejected_loudly(ctx):
+    import abismal_amd as A
+    with pytest.raises(A.AbismalAmdError, match="exceeds the kernel cap"):
+        ctx.map_se(["ACGT" * 200])
+    with pytest.raises(A.AbismalAmdError):
+        ctx.map_se(["ACGT" * 30], mode=7)
+
+
+def test_unseedable_and_ragged_inputs(ctx, oracle, trex_index, reads):
+    rng = np.random.default_rng(0)
+    weird = ["N" * 60, "A" * 44, "ACGT" * 11, "T" * 300, "", "NNNNACGTNNNN" * 8, "GATTACA" * 40]
+    ragged = [r[: int(rng.integers(44, len(r) + 1))] if r and len(r) >= 47 else r for r in reads[:3000]]
+    ragged = [r if not (44 <= len(r) <= 46) else r[:43] for r in ragged]   # 44-46 bp: see DESIGN.md
+    batch = weird + ragged
+    res, cig, off = ctx.map_se(batch)
+    oix = oracle.index_load(trex_index)
+    try:
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, [b if len(b) >= 44 else "" for b in batch], threads=8)
+    finally:
+        oracle.index_free(oix)
+    from tests.test_gpu_se_parity import compare_se
+    compare_se(res, cig, off, o_res, o_cig, o_n, batch, "ragged batch")
+
+
+def test_batch_order_and_size_do_not_matter(ctx, reads):
+    """Results are per read: permuting the batch, splitting it, or running it twice changes nothing
+    (the only cross-read state in the reference is buffer sizing, src/abismal.cpp:1549)."""
+    base = [r for r in reads if not (44 <= len(r) <= 46)]
+    res, cig, off = ctx.map_se(base)
+    res2, cig2, off2 = ctx.map_se(base)
+    assert res.tobytes() == res2.tobytes() and cig.tobytes() == cig2.tobytes()
+    perm = np.random.default_rng(1).permutation(len(base))
+    resp, cigp, offp = ctx.map_se([base[i] for i in perm])
+    c0, cp = cigars(cig, off), cigars(cigp, offp)
+    for k, i in enumerate(perm):
+        assert res[i]["pos"] == resp[k]["pos"]
+        if res[i]["pos"]:
+            assert res[i].tobytes() == resp[k].tobytes() and c0[i] == cp[k]
+    half = len(base) // 2
+    ra, ca, oa = ctx.map_se(base[:half])
+    rb, cb, ob_ = ctx.map_se(base[half:])
+    both = np.concatenate([ra, rb])
+    m = res["pos"] != 0
+    assert (both["pos"] == res["pos"]).all() and (both[m] == res[m]).all()
+    assert cigars(ca, oa) + cigars(cb, ob_) == c0
+
+
+def test_exact_reads_map_back_to_their_origin(ctx, trex_index):
+    """Reads cut from the genome without errors (fully converted) must come back unique at their
+    origin with NM 0 and an all-match CIGAR -- or be flagged ambiguous, never somewhere else."""
+    import bench
+    names, starts, gw = bench.read_index_genome(trex_index)
+    dec = np.frombuffer(b"NACNGNNNTNNNNNNN", dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    L = 100
+    pos = rng.integers(int(starts[1]) + 10100, int(starts[2]) - 200, 4000)
+    out, keep = [], []
+    for p in pos:
+        idx = np.arange(p, p + L)
+        nib = ((gw[idx >> 4] >> ((idx & 15).astype(np.uint64) * np.uint64(4))) & np.uint64(15)).astype(np.int64)
+        s = dec[nib]
+        if (s == ord("N")).any():
+            continue
+        out.append(bytes(s).replace(b"C", b"T"))
+        keep.append(int(p))
+    res, cig, off = ctx.map_se(out)
+    cg = cigars(cig, off)
+    n_unique = 0
+    for i, p in enumerate(keep):
+        assert res[i]["pos"] != 0, "an error-free read must seed (>= 44 bp guarantees a hit)"
+        if not (int(res[i]["flags"]) & 0x100):
+            assert int(res[i]["pos"]) == p and int(res[i]["diffs"]) == 0 and cg[i] == ((L << 4),)
+            n_unique += 1
+    assert n_unique > 0.9 * len(keep)
+
+
+def test_device_entry_point_matches_host_entry_point(ctx, reads):
+    import torch
+    import abismal_amd as A
+    base = [r for r in reads[:5000] if len(r) == 100]
+    res, cig, off = ctx.map_se(base)
+    dev = torch.device("cuda", 0)
+    n, L = len(base), 100
+    blob = torch.tensor(np.frombuffer("".join(base).encode(), dtype=np.uint8), device=dev)
+    offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    stride = 102
+    d_res = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    d_cig = torch.zeros((n, stride), dtype=torch.int32, device=dev)
+    d_n = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.map_se_device(A.SE_T_RICH, A.Params(), n, blob.data_ptr(), offs.data_ptr(), L, d_res.data_ptr(),
+                      d_cig.data_ptr(), stride, d_n.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(d_st.item()) == 0
+    got = d_res.cpu().numpy().view(A.HIT_DTYPE).reshape(-1)
+    m = res["pos"] != 0
+    assert (got["pos"] == res["pos"]).all() and (got[m] == res[m]).all()
+    cn = d_n.cpu().numpy()
+    dc = d_cig.cpu().numpy().view(np.uint32)
+    assert [tuple(dc[i, :cn[i]].tolist()) for i in range(n)] == cigars(cig, off)

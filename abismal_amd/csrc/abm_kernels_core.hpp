@@ -193,7 +193,11 @@ __device__ __forceinline__ u32 narrow2(const u64 *__restrict__ genome, const u32
   return p;
 }
 
-// find_candidates_three, src/abismal.cpp:1214-1259
+// find_candidates_three, src/abismal.cpp:1214-1259.  The reference runs two std::lower_bound
+// bisections (first symbol >= mid, first symbol >= top) over the same range; they start at the
+// same midpoint and share probes until their paths part, so both advance in lockstep here and a
+// probe whose index coincides is loaded once.  Each bisection still sees exactly its own probe
+// sequence, so the boundaries are the reference's even where the bucket tail is unsorted.
 __device__ __forceinline__ u32 narrow3(const u64 *__restrict__ genome, const u32 *__restrict__ tbl,
                                        bool g_to_a, const u64 *qpk, u32 qbase, u32 limit, u32 maxc,
                                        u32 &lo, u32 &hi, u32 &probes) {
@@ -201,12 +205,21 @@ __device__ __forceinline__ u32 narrow3(const u64 *__restrict__ genome, const u32
   u32 p = kKeyWeight3, plo = lo, phi = hi;
   for (; p != limit && (hi - lo) > maxc; ++p) {
     plo = lo; phi = hi;
-    const u32 b1 = first_not(lo, hi, probes, [&](u32 k) {
-      return sortsym3(gnib(genome, static_cast<u64>(tbl[k]) + p), g_to_a) < mid_sym;
-    });
-    const u32 b2 = first_not(lo, hi, probes, [&](u32 k) {
-      return sortsym3(gnib(genome, static_cast<u64>(tbl[k]) + p), g_to_a) < top_sym;
-    });
+    u32 l1 = lo, l2 = lo;
+    int n1 = static_cast<int>(hi - lo), n2 = n1;
+    while (n1 > 0 || n2 > 0) {
+      const int h1 = n1 >> 1, h2 = n2 >> 1;
+      const u32 m1 = l1 + static_cast<u32>(h1), m2 = l2 + static_cast<u32>(h2);
+      u32 s1 = 0, s2 = 0;
+      if (n1 > 0) { s1 = sortsym3(gnib(genome, static_cast<u64>(tbl[m1]) + p), g_to_a); ++probes; }
+      if (n2 > 0) {
+        if (n1 > 0 && m2 == m1) s2 = s1;
+        else { s2 = sortsym3(gnib(genome, static_cast<u64>(tbl[m2]) + p), g_to_a); ++probes; }
+      }
+      if (n1 > 0) { if (s1 < mid_sym) { l1 = m1 + 1; n1 -= h1 + 1; } else n1 = h1; }
+      if (n2 > 0) { if (s2 < top_sym) { l2 = m2 + 1; n2 -= h2 + 1; } else n2 = h2; }
+    }
+    const u32 b1 = l1, b2 = l2;
     const u32 sym = sortsym3(q_nibble(qpk, qbase + p), g_to_a);
     if (sym == 0) hi = b1;
     else if (sym == mid_sym) { lo = b1; hi = b2; }

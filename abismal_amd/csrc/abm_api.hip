@@ -59,7 +59,7 @@ struct abm_ctx {
   void *arena = nullptr;  // one allocation holding the seven index arrays
   // per-batch workspaces (grow-only; sized by the largest batch seen)
   DevBuf<abm::u64> packed, packed2;
-  DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2;
+  DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2, heap2;
   DevBuf<abm::u8> need_big;
   DevBuf<abm::Hit> pe_out;  // staging: pairs (20 B each) then se1, se2
   DevBuf<abm::u32> cig2h, cig_n2h;
@@ -237,6 +237,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
     ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);
     ctx->list2.reserve(static_cast<size_t>(waves) * 4 * a.cap);
+    ctx->heap2.reserve(static_cast<size_t>(waves) * a.cap);
+    a.heap_ws = ctx->heap2.p;
     a.payload_ws = ctx->payload2.p;
     a.list_ws = ctx->list2.p;
     unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
@@ -341,7 +343,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->arena) (void)hipFree(c->arena);
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;

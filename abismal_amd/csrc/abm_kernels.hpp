@@ -51,6 +51,7 @@ struct PeArgs {
   u8 *need_big;                  // [n] tier 1 -> tier 2 hand-off
   u32 *payload_ws;               // [grid][cap]
   u32 *list_ws;                  // tier 2: [grid][2][cap] positions, then diffs and scores (i16)
+  u32 *heap_ws;                  // tier 2: [grid][cap] candidate heap / sort buffer
   u32 cap;
 };
 

@@ -503,9 +503,12 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
   lds.jdf = lds.jpos + kSeCap;
   w.pl.jidx = lds.jdf + kSeCap;
   lds.lbest = reinterpret_cast<int *>(w.pl.jidx + kSeCap);
-  w.pl.heap = reinterpret_cast<u32 *>(lds.lbest + 64);
+  // tier 1: the set's heap is in LDS.  tier 2: a 32768-entry heap per wave would cap the CU at one
+  // wave, so it lives in global memory (L2-resident, touched by this wave only) and occupancy stays normal
+  u32 *after_heap = reinterpret_cast<u32 *>(lds.lbest + 64);
+  if (BIG) w.pl.heap = a.heap_ws + static_cast<u64>(blockIdx.x) * a.cap;
+  else { w.pl.heap = after_heap; after_heap += a.cap; }
   w.pl.cap = a.cap;
-  u32 *after_heap = w.pl.heap + a.cap;
   if (BIG) {
     u32 *ws = a.list_ws + static_cast<u64>(blockIdx.x) * 4 * a.cap;  // 2 pos arrays + (2 diffs + 2 scores) as i16
     w.pl.lpos[0] = ws; w.pl.lpos[1] = ws + a.cap;
@@ -653,8 +656,8 @@ size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double v
   int bw = 2 * md + 1;
   if (bw > static_cast<int>(kMaxBand) || bw < 1) bw = kMaxBand;
   size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
-             static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + static_cast<size_t>(cap) * 4 + 64 * 2;
-  if (!big) b += static_cast<size_t>(cap) * (2 * 4 + 4 * 2);
+             static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + 64 * 2;
+  if (!big) b += static_cast<size_t>(cap) * (4 + 2 * 4 + 4 * 2);
   b += static_cast<size_t>(max_len + bw) * bw;
   return (b + 15) & ~static_cast<size_t>(15);
 }
@@ -671,12 +674,8 @@ int pe_resident_waves(size_t lds, bool big) {
 
 hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, hipStream_t st) {
   if (grid == 0) return hipSuccess;
-  if (big) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(map_pe_kernel<true, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
+  if (big)
     hipLaunchKernelGGL((map_pe_kernel<true, false>), dim3(grid), dim3(64), lds, st, a);
-  }
   else
     hipLaunchKernelGGL((map_pe_kernel<false, false>), dim3(grid), dim3(64), lds, st, a);
   return hipGetLastError();

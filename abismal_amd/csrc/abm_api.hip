@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -64,12 +65,16 @@ struct abm_ctx {
   DevBuf<abm::Hit> pe_out;  // staging: pairs (20 B each) then se1, se2
   DevBuf<abm::u32> cig2h, cig_n2h;
   DevBuf<char> blob2;
+  DevBuf<unsigned long long> coff;
+  DevBuf<char> scan_tmp;
+  DevBuf<abm::u32> cblob;
   DevBuf<abm::u64> off2;
   DevBuf<abm::u32> lens, order, class33;
   DevBuf<abm::u8> cls;
   DevBuf<unsigned long long> work;
   DevBuf<unsigned long long> next_read;
   unsigned launch_seq = 0;
+  std::map<uint64_t, int> se_waves;
   // staging for the host-buffer entry points
   DevBuf<char> blob;
   DevBuf<abm::u64> off;
@@ -144,7 +149,13 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
   a.next_read = counter;
   a.read_cycles = ctx->phase_stamps ? ctx->read_cycles : nullptr;
-  int waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, size_frac);
+  // the occupancy query costs milliseconds: remember it per launch shape
+  const uint64_t shape = (static_cast<uint64_t>(W) << 48) ^ (static_cast<uint64_t>(cig_stride) << 24) ^ (static_cast<uint64_t>(eff_len) << 8) ^
+                         static_cast<uint64_t>(size_frac * 255.0);
+  int waves;
+  auto it = ctx->se_waves.find(shape);
+  if (it != ctx->se_waves.end()) waves = it->second;
+  else { waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, size_frac); ctx->se_waves[shape] = waves; }
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
@@ -163,6 +174,27 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
   HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
+}
+
+// fixed CIGAR slots on the device -> compact blob + offsets in the caller's host buffers
+void fetch_cigars(abm_ctx *ctx, const abm::Hit *d_res, const abm::u32 *d_cig, const abm::u32 *d_cig_n, uint64_t n,
+                  uint32_t stride, uint32_t *out_blob, uint64_t cap, uint64_t *out_off) {
+  ctx->coff.reserve(n + 1);
+  size_t tmp_bytes = 0;
+  HIPCHK(abm::launch_compact_cigars(nullptr, nullptr, nullptr, n, stride, ctx->coff.p, nullptr, nullptr, &tmp_bytes, nullptr));
+  ctx->scan_tmp.reserve(tmp_bytes + 16);
+  HIPCHK(abm::launch_compact_cigars(d_res, d_cig, d_cig_n, n, stride, ctx->coff.p, nullptr, ctx->scan_tmp.p, &tmp_bytes, nullptr));
+  unsigned long long total = 0;
+  HIPCHK(hipMemcpy(&total, ctx->coff.p + n, sizeof(total), hipMemcpyDeviceToHost));
+  if (total > cap) throw std::length_error("cig_capacity too small");
+  ctx->cblob.reserve(std::max<unsigned long long>(total, 1));
+  if (total) {
+    // offsets are already scanned: only the gather is left (counts kernel + scan are idempotent to skip)
+    HIPCHK(abm::launch_gather_cigars(d_cig, stride, ctx->coff.p, n, ctx->cblob.p, nullptr));
+    HIPCHK(hipMemcpy(out_blob, ctx->cblob.p, total * 4ull, hipMemcpyDeviceToHost));
+  }
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "offset width");
+  HIPCHK(hipMemcpy(out_off, ctx->coff.p, (n + 1) * 8ull, hipMemcpyDeviceToHost));
 }
 
 void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob1,
@@ -343,7 +375,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->arena) (void)hipFree(c->arena);
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -444,8 +476,7 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     if (bytes) HIPCHK(hipMemcpy(ctx->blob.p, seq_blob + base, bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
 
-    std::vector<uint32_t> cig, cig_n(n);
-    uint32_t stride = 8;
+    uint32_t stride = 16;
     for (;;) {  // a CIGAR longer than the slot triggers one rerun with full-size slots
       ctx->cig.reserve(n * stride);
       HIPCHK(hipMemset(ctx->status.p, 0, 4));
@@ -459,17 +490,7 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       break;
     }
     HIPCHK(hipMemcpy(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
-    cig.resize(n * stride);
-    HIPCHK(hipMemcpy(cig.data(), ctx->cig.p, cig.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cig_n.data(), ctx->cig_n.p, n * 4, hipMemcpyDeviceToHost));
-    uint64_t at = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-      const uint32_t k = out_res[i].pos ? cig_n[i] : 0;
-      if (at + k > cig_capacity) throw std::length_error("cig_capacity too small");
-      if (k) std::memcpy(out_cig_blob + at, cig.data() + i * stride, k * 4ull);
-      at += k;
-      out_cig_off[i + 1] = at;
-    }
+    fetch_cigars(ctx, ctx->res.p, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob, cig_capacity, out_cig_off);
   });
 }
 
@@ -527,7 +548,7 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     abm_pair *d_pair = reinterpret_cast<abm_pair *>(outb);
     abm_hit *d_se1 = reinterpret_cast<abm_hit *>(outb + n * 20 + (8 - (n * 20) % 8) % 8);
     abm_hit *d_se2 = d_se1 + n;
-    uint32_t stride = 8;
+    uint32_t stride = 16;
     for (;;) {
       ctx->cig.reserve(n * stride);
       ctx->cig2h.reserve(n * stride);
@@ -546,19 +567,8 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     HIPCHK(hipMemcpy(out_pair, d_pair, n * sizeof(abm_pair), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_se1, d_se1, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_se2, d_se2, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> c1(n * stride), c2(n * stride), n1(n), n2(n);
-    HIPCHK(hipMemcpy(c1.data(), ctx->cig.p, c1.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(c2.data(), ctx->cig2h.p, c2.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n1.data(), ctx->cig_n.p, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n2.data(), ctx->cig_n2h.p, n * 4, hipMemcpyDeviceToHost));
-    uint64_t at1 = 0, at2 = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-      if (at1 + n1[i] > cig_capacity || at2 + n2[i] > cig_capacity) throw std::length_error("cig_capacity too small");
-      if (n1[i]) std::memcpy(out_cig_blob1 + at1, c1.data() + i * stride, n1[i] * 4ull);
-      if (n2[i]) std::memcpy(out_cig_blob2 + at2, c2.data() + i * stride, n2[i] * 4ull);
-      at1 += n1[i]; at2 += n2[i];
-      out_cig_off1[i + 1] = at1; out_cig_off2[i + 1] = at2;
-    }
+    fetch_cigars(ctx, nullptr, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob1, cig_capacity, out_cig_off1);
+    fetch_cigars(ctx, nullptr, ctx->cig2h.p, ctx->cig_n2h.p, n, stride, out_cig_blob2, cig_capacity, out_cig_off2);
   });
 }
 

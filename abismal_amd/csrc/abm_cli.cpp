@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -34,55 +35,114 @@ constexpr uint32_t kMinReadLen = 44, kPadding = 32767;
 [[noreturn]] void die_abm(const char *what) { throw std::runtime_error(std::string(what) + ": " + abm_last_error()); }
 
 // ---- FASTQ, with ReadLoader's rules (src/abismal.cpp:164-201) -----------------
+// Stage 1 (one thread per input file) only cuts the file into batches of whole records;
+// stage 2 (a pool) applies the reference's per-record rules and lays the reads out for the C ABI.
+struct Stats { 
+  uint64_t v[6] = {0, 0, 0, 0, 0, 0};  // total, unique, ambiguous, skipped, edits, bases
+  void tally(bool empty_read, const abm_hit &h, bool count_ambig_error, uint32_t bases);
+  std::string yaml(const std::string &label) const;
+  std::string json() const;
+};
+struct Stats3 { Stats s[3]; };  // SE: s[0]; PE: pairs, read1, read2
+
 struct Batch {
-  uint64_t seq = 0;  // batch number, defines output order
+  uint64_t seq = 0;        // batch number, defines output order
+  uint64_t first_line[2] = {0, 0};
+  std::string raw[2];      // the FASTQ text of this batch
   std::vector<std::string> names[2];
   std::string blob[2];
   std::vector<uint64_t> off[2];
   // results
+  int gpu = 0;
   std::vector<abm_hit> se[2];
   std::vector<abm_pair> pairs;
   std::vector<uint32_t> cig[2];
   std::vector<uint64_t> cig_off[2];
   std::string sam;
+  Stats3 stats;
   size_t n() const { return names[0].size(); }
 };
 
-struct FastqReader {
-  std::ifstream in;
-  std::string path;
+struct RawSplitter {
+  FILE *f = nullptr;
+  std::string path, carry;
   uint64_t line_no = 0;
-  bool alive = true;
-  explicit FastqReader(const std::string &p) : in(p, std::ios::binary), path(p) {
-    if (!in) throw std::runtime_error("cannot open reads file: " + p);
+  bool eof = false;
+  explicit RawSplitter(const std::string &p) : f(std::fopen(p.c_str(), "rb")), path(p) {
+    if (!f) throw std::runtime_error("cannot open reads file: " + p);
   }
-  void load(size_t want, std::vector<std::string> &names, std::string &blob, std::vector<uint64_t> &off) {
-    names.clear(); blob.clear(); off.assign(1, 0);
-    std::string line, name;
-    for (size_t k = 0; k < 4 * want; ++k, ++line_no) {
-      if (!std::getline(in, line)) { alive = false; break; }
-      if (k % 4 == 0) {
-        if (line.empty())
-          throw std::runtime_error("file " + path + " contains an empty read name at line " + std::to_string(line_no));
-        name = line.substr(1, line.find_first_of(" \t") - 1);
+  ~RawSplitter() { if (f) std::fclose(f); }
+  // up to `want` records (4 lines each) of text; returns the number of complete lines delivered
+  uint64_t next(size_t want, std::string &out, uint64_t &first_line) {
+    first_line = line_no;
+    out.clear();
+    out.swap(carry);
+    const uint64_t need = 4 * static_cast<uint64_t>(want);
+    uint64_t lines = 0;
+    size_t scanned = 0;
+    auto scan = [&]() {
+      while (lines < need) {
+        const char *nl = static_cast<const char *>(std::memchr(out.data() + scanned, '\n', out.size() - scanned));
+        if (!nl) { scanned = out.size(); return; }
+        scanned = static_cast<size_t>(nl - out.data()) + 1;
+        ++lines;
       }
-      else if (k % 4 == 1) {
-        if (line.size() >= kPadding)
-          throw std::runtime_error("found a read of size " + std::to_string(line.size()) +
-                                   ", which is too long. Maximum allowed read size = " + std::to_string(kPadding));
-        const auto informative = std::count_if(line.begin(), line.end(), [](char c) { return c != 'N'; });
-        if (informative < static_cast<std::ptrdiff_t>(kMinReadLen)) line.clear();
-        else {
-          while (line.back() == 'N') line.pop_back();
-          line = line.substr(line.find_first_of("ACGT"));
-        }
-        names.push_back(name);
-        blob += line;
-        off.push_back(blob.size());
-      }
+    };
+    scan();
+    while (lines < need && !eof) {
+      const size_t old = out.size(), chunk = 32u << 20;
+      out.resize(old + chunk);
+      const size_t got = std::fread(&out[old], 1, chunk, f);
+      out.resize(old + got);
+      if (got < chunk) eof = true;
+      scan();
     }
+    if (lines == need) { carry.assign(out, scanned, std::string::npos); out.resize(scanned); }
+    else if (scanned < out.size()) ++lines;  // a last line without a newline still counts (getline semantics)
+    line_no += lines;
+    return lines;
   }
+  bool exhausted() const { return eof && carry.empty(); }
 };
+
+void parse_raw(const std::string &raw, uint64_t first_line, const std::string &path, std::vector<std::string> &names,
+               std::string &blob, std::vector<uint64_t> &off) {
+  names.clear(); blob.clear(); off.assign(1, 0);
+  blob.reserve(raw.size() / 2);
+  const char *p = raw.data(), *end = p + raw.size();
+  std::string line;
+  for (uint64_t k = 0; p < end; ++k) {
+    const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    const char *le = nl ? nl : end;
+    if (k % 4 == 0) {
+      if (le == p)
+        throw std::runtime_error("file " + path + " contains an empty read name at line " + std::to_string(first_line + k));
+      const char *q = p + 1;
+      while (q < le && *q != ' ' && *q != '\t') ++q;
+      names.emplace_back(p + 1, q);
+    }
+    else if (k % 4 == 1) {
+      const size_t len = static_cast<size_t>(le - p);
+      if (len >= kPadding)
+        throw std::runtime_error("found a read of size " + std::to_string(len) +
+                                 ", which is too long. Maximum allowed read size = " + std::to_string(kPadding));
+      size_t informative = 0;
+      for (const char *c = p; c < le; ++c) informative += (*c != 'N');
+      if (informative >= kMinReadLen) {
+        const char *e = le;
+        while (e > p && e[-1] == 'N') --e;                       // remove Ns from 3'
+        const char *b = p;
+        while (b < e && *b != 'A' && *b != 'C' && *b != 'G' && *b != 'T') ++b;  // ... and everything before the first base
+        if (b == e) throw std::runtime_error("read without A/C/G/T at line " + std::to_string(first_line + k));
+        blob.append(b, e);
+      }
+      off.push_back(blob.size());
+    }
+    if (!nl) break;
+    p = nl + 1;
+  }
+  names.resize(off.size() - 1);  // a trailing name line without its sequence is not a record
+}
 
 // ---- SAM text (format_se / format_pe, src/abismal.cpp:481-545, :648-773) -------
 struct Chroms {
@@ -107,18 +167,30 @@ uint32_t ref_len(const uint32_t *c, size_t n) {
   return r;
 }
 
-void append_revcomp(std::string &o, const char *s, size_t n) {
-  for (size_t i = 0; i < n; ++i) {
-    const char c = s[n - 1 - i];
-    o += c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+// SEQ as htslib prints it after its 4-bit round trip: IUPAC upper-cased, everything else N;
+// the reverse-strand variant complements first (src/common.hpp:28-44: non-ACGT -> N)
+struct SeqTables {
+  char fwd[256], rc[256];
+  SeqTables() {
+    static const char ok[] = "=ACMGRSVTWYHKDBN";
+    for (int c = 0; c < 256; ++c) {
+      const char u = static_cast<char>(std::toupper(c));
+      fwd[c] = (u && std::strchr(ok, u)) ? u : 'N';
+      rc[c] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+    }
   }
+};
+const SeqTables kSeq;
+
+inline void put_uint(std::string &o, uint64_t v) {
+  char buf[24];
+  int k = 24;
+  do { buf[--k] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+  o.append(buf + k, static_cast<size_t>(24 - k));
 }
-void append_seq(std::string &o, const char *s, size_t n) {  // htslib's 4-bit round trip
-  static const char ok[] = "=ACMGRSVTWYHKDBN";
-  for (size_t i = 0; i < n; ++i) {
-    const char u = static_cast<char>(std::toupper(static_cast<unsigned char>(s[i])));
-    o += (u && std::strchr(ok, u)) ? u : 'N';
-  }
+inline void put_int(std::string &o, int64_t v) {
+  if (v < 0) { o += '-'; put_uint(o, static_cast<uint64_t>(-v)); }
+  else put_uint(o, static_cast<uint64_t>(v));
 }
 
 struct Record {
@@ -137,16 +209,22 @@ struct Record {
 };
 
 void put_record(std::string &o, const Chroms &ch, const Record &r) {
-  o += *r.name; o += '\t'; o += std::to_string(r.flag); o += '\t';
-  o += ch.names[r.tid + 1]; o += '\t'; o += std::to_string(r.pos + 1); o += "\t255\t";
-  for (size_t i = 0; i < r.n_cig; ++i) { o += std::to_string(r.cig[i] >> 4); o += "MIDNSHP=XB"[std::min<uint32_t>(r.cig[i] & 15u, 9)]; }
+  o += *r.name; o += '\t'; put_uint(o, r.flag); o += '\t';
+  o += ch.names[r.tid + 1]; o += '\t'; put_uint(o, static_cast<uint64_t>(r.pos) + 1); o.append("\t255\t", 5);
+  for (size_t i = 0; i < r.n_cig; ++i) { put_uint(o, r.cig[i] >> 4); o += "MIDNSHP=XB"[std::min<uint32_t>(r.cig[i] & 15u, 9)]; }
   o += '\t';
-  if (r.mtid < 0) o += "*\t0\t";
-  else { o += (r.mtid == r.tid) ? std::string("=") : ch.names[r.mtid + 1]; o += '\t'; o += std::to_string(r.mpos + 1); o += '\t'; }
-  o += std::to_string(r.tlen); o += '\t';
-  if (r.rc) { std::string t; append_revcomp(t, r.seq, r.n_seq); append_seq(o, t.data(), t.size()); }
-  else append_seq(o, r.seq, r.n_seq);
-  o += "\t*\tNM:i:"; o += std::to_string(r.nm); o += "\tCV:A:"; o += r.cv; o += '\n';
+  if (r.mtid < 0) o.append("*\t0\t", 4);
+  else {
+    if (r.mtid == r.tid) o += '='; else o += ch.names[r.mtid + 1];
+    o += '\t'; put_uint(o, static_cast<uint64_t>(r.mpos) + 1); o += '\t';
+  }
+  put_int(o, r.tlen); o += '\t';
+  const size_t at = o.size();
+  o.resize(at + r.n_seq);
+  char *dst = &o[at];
+  if (r.rc) for (size_t i = 0; i < r.n_seq; ++i) dst[i] = kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])];
+  else for (size_t i = 0; i < r.n_seq; ++i) dst[i] = kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
+  o.append("\t*\tNM:i:", 8); put_int(o, r.nm); o.append("\tCV:A:", 6); o += r.cv; o += '\n';
 }
 
 enum Outcome { UNMAPPED, UNIQUE, AMBIG };
@@ -187,45 +265,42 @@ Outcome emit_pe(std::string &o, bool allow_ambig, const abm_pair &p, const Chrom
 }
 
 // ---- statistics (src/abismal.cpp:865-1071); 6 counters x {pairs|se, read1, read2} ----
-struct Stats {
-  uint64_t v[6] = {0, 0, 0, 0, 0, 0};  // total, unique, ambiguous, skipped, edits, bases
-  void tally(bool empty_read, const abm_hit &h, bool count_ambig_error, uint32_t bases) {
-    ++v[0];
-    const bool valid = h.pos != 0, amb = h.flags & 0x100;
-    v[1] += valid && !amb; v[2] += valid && amb; v[3] += empty_read;
-    if (valid && (!amb || count_ambig_error)) { v[4] += static_cast<uint64_t>(static_cast<int64_t>(h.diffs)); v[5] += bases; }
-  }
-  std::string yaml(const std::string &label) const {
-    // the reference keeps the first four in 32-bit counters (they wrap there)
-    const uint32_t total = static_cast<uint32_t>(v[0]), unique = static_cast<uint32_t>(v[1]),
-                   ambiguous = static_cast<uint32_t>(v[2]), skipped = static_cast<uint32_t>(v[3]);
-    auto frac = [&](double x) { return total > 0 ? x / total : 0.0; };
-    const uint32_t mapped = unique + ambiguous, unmapped = total - mapped;
-    std::ostringstream s; const char *t = "    ";
-    s << label << ":\n" << t << "total_reads: " << total << '\n' << t << "mapped:\n"
-      << t << "    num_mapped: " << mapped << '\n' << t << "    num_unique: " << unique << '\n'
-      << t << "    num_ambiguous: " << ambiguous << '\n' << t << "    percent_mapped: " << frac(mapped) * 100.0 << '\n'
-      << t << "    percent_unique: " << frac(unique) * 100.0 << '\n' << t << "    percent_ambiguous: " << frac(ambiguous) * 100.0 << '\n'
-      << t << "    unique_error:\n" << t << "        edits: " << v[4] << '\n' << t << "        total_bases: " << v[5] << '\n'
-      << t << "        error_rate: " << (v[5] > 0 ? static_cast<double>(v[4]) / v[5] : 0.0) << '\n'
-      << t << "num_unmapped: " << unmapped << '\n' << t << "num_skipped: " << skipped << '\n'
-      << t << "percent_unmapped: " << frac(unmapped) * 100.0 << '\n' << t << "percent_skipped: " << frac(skipped) * 100.0 << '\n';
-    return s.str();
-  }
-  std::string json() const {
-    std::ostringstream s;
-    s << "{\"edit_distance\":" << v[4] << ",\"reads_mapped_ambiguous\":" << static_cast<uint32_t>(v[2])
-      << ",\"reads_mapped_unique\":" << static_cast<uint32_t>(v[1]) << ",\"reads_skipped\":" << static_cast<uint32_t>(v[3])
-      << ",\"total_bases\":" << v[5] << ",\"total_reads\":" << static_cast<uint32_t>(v[0]) << "}";
-    return s.str();
-  }
-};
-struct Stats3 { Stats s[3]; };  // SE: s[0]; PE: pairs, read1, read2
+void Stats::tally(bool empty_read, const abm_hit &h, bool count_ambig_error, uint32_t bases) {
+  ++v[0];
+  const bool valid = h.pos != 0, amb = h.flags & 0x100;
+  v[1] += valid && !amb; v[2] += valid && amb; v[3] += empty_read;
+  if (valid && (!amb || count_ambig_error)) { v[4] += static_cast<uint64_t>(static_cast<int64_t>(h.diffs)); v[5] += bases; }
+}
+std::string Stats::yaml(const std::string &label) const {
+  // the reference keeps the first four in 32-bit counters (they wrap there)
+  const uint32_t total = static_cast<uint32_t>(v[0]), unique = static_cast<uint32_t>(v[1]),
+                 ambiguous = static_cast<uint32_t>(v[2]), skipped = static_cast<uint32_t>(v[3]);
+  auto frac = [&](double x) { return total > 0 ? x / total : 0.0; };
+  const uint32_t mapped = unique + ambiguous, unmapped = total - mapped;
+  std::ostringstream s; const char *t = "    ";
+  s << label << ":\n" << t << "total_reads: " << total << '\n' << t << "mapped:\n"
+    << t << "    num_mapped: " << mapped << '\n' << t << "    num_unique: " << unique << '\n'
+    << t << "    num_ambiguous: " << ambiguous << '\n' << t << "    percent_mapped: " << frac(mapped) * 100.0 << '\n'
+    << t << "    percent_unique: " << frac(unique) * 100.0 << '\n' << t << "    percent_ambiguous: " << frac(ambiguous) * 100.0 << '\n'
+    << t << "    unique_error:\n" << t << "        edits: " << v[4] << '\n' << t << "        total_bases: " << v[5] << '\n'
+    << t << "        error_rate: " << (v[5] > 0 ? static_cast<double>(v[4]) / v[5] : 0.0) << '\n'
+    << t << "num_unmapped: " << unmapped << '\n' << t << "num_skipped: " << skipped << '\n'
+    << t << "percent_unmapped: " << frac(unmapped) * 100.0 << '\n' << t << "percent_skipped: " << frac(skipped) * 100.0 << '\n';
+  return s.str();
+}
+std::string Stats::json() const {
+  std::ostringstream s;
+  s << "{\"edit_distance\":" << v[4] << ",\"reads_mapped_ambiguous\":" << static_cast<uint32_t>(v[2])
+    << ",\"reads_mapped_unique\":" << static_cast<uint32_t>(v[1]) << ",\"reads_skipped\":" << static_cast<uint32_t>(v[3])
+    << ",\"total_bases\":" << v[5] << ",\"total_reads\":" << static_cast<uint32_t>(v[0]) << "}";
+  return s.str();
+}
 
 struct Options {
   std::string index, genome, out, stats;
   bool bam = false, json = false, ambig = false, pbat = false, rpbat = false, arich = false, verbose = false;
-  uint32_t max_candidates = 0, min_frag = 32, max_frag = 3000, threads = 1;
+  uint32_t max_candidates = 0, min_frag = 32, max_frag = 3000;
+  uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));  // host parse/format threads
   int gpus = 0;
   size_t batch = 1u << 20;
   double max_distance = 0.1;
@@ -328,54 +403,116 @@ int cmd_map(int argc, char **argv) {
   const int se_mode = opt.rpbat ? ABM_SE_RANDOM : ((opt.arich || opt.pbat) ? ABM_SE_A_RICH : ABM_SE_T_RICH);
   const int pe_mode = opt.rpbat ? ABM_PE_RANDOM : (opt.pbat ? ABM_PE_PBAT : ABM_PE_NORMAL);
 
-  // reader -> per-GPU workers -> in-order writer
+  // Staged pipeline, every stage order-agnostic except the writer:
+  //   splitter (1 thread)   cuts the FASTQ file(s) into raw batches of whole records
+  //   parsers  (-t threads) apply ReadLoader's rules and lay reads out for the C ABI
+  //   mappers  (1 per GPU)  abm_map_{se,pe}_batch
+  //   formatters (-t)       SAM text + the batch's statistics
+  //   writer (this thread)  emits batches in input order
   std::mutex mu;
   std::condition_variable cv;
+  std::deque<std::unique_ptr<Batch>> q_parse, q_map, q_format;
   std::map<uint64_t, std::unique_ptr<Batch>> done;
-  uint64_t next_to_write = 0, next_to_read = 0;
-  bool reading_finished = false;
+  uint64_t n_batches = 0, next_to_write = 0;
+  size_t in_flight = 0;
+  bool split_done = false;
+  int parsers_live = 0, mappers_live = 0, formatters_live = 0;
   std::exception_ptr failure;
-  FastqReader rd1(opt.reads[0]);
-  std::unique_ptr<FastqReader> rd2;
-  if (paired) rd2.reset(new FastqReader(opt.reads[1]));
+  const size_t max_in_flight = static_cast<size_t>(4 * n_gpus + 8);
+  const unsigned n_host = std::max(1u, opt.threads);
   std::vector<Stats3> gpu_stats(n_gpus);
   const auto t_start = std::chrono::steady_clock::now();
 
-  auto worker = [&](int g) {
+  auto fail = [&]() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!failure) failure = std::current_exception();
+    cv.notify_all();
+  };
+
+  auto splitter = [&]() {
     try {
+      RawSplitter s1(opt.reads[0]);
+      std::unique_ptr<RawSplitter> s2;
+      if (paired) s2.reset(new RawSplitter(opt.reads[1]));
       for (;;) {
-        std::unique_ptr<Batch> b(new Batch);
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || reading_finished || done.size() < static_cast<size_t>(4 * n_gpus); });
-          if (failure || reading_finished) return;
-          b->seq = next_to_read++;
-          rd1.load(opt.batch, b->names[0], b->blob[0], b->off[0]);
-          if (paired) {
-            rd2->load(opt.batch, b->names[1], b->blob[1], b->off[1]);
-            if (b->names[0].size() != b->names[1].size())
-              throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(b->names[0].size()) +
-                                       ", batch 2: " + std::to_string(b->names[1].size()) +
-                                       ". Are you sure your paired-end inputs have the same number of reads?");
-          }
-          if (!rd1.alive || (paired && !rd2->alive)) reading_finished = true;
+          cv.wait(lk, [&] { return failure || in_flight < max_in_flight; });
+          if (failure) break;
         }
+        std::unique_ptr<Batch> b(new Batch);
+        const uint64_t l1 = s1.next(opt.batch, b->raw[0], b->first_line[0]);
+        uint64_t l2 = 0;
+        if (paired) l2 = s2->next(opt.batch, b->raw[1], b->first_line[1]);
+        const bool last = s1.exhausted() || (paired && s2->exhausted());
+        if (l1 == 0 && (!paired || l2 == 0)) break;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          b->seq = n_batches++;
+          ++in_flight;
+          q_parse.push_back(std::move(b));
+        }
+        cv.notify_all();
+        if (last) break;
+      }
+    }
+    catch (...) { fail(); }
+    std::lock_guard<std::mutex> lk(mu);
+    split_done = true;
+    cv.notify_all();
+  };
+
+  auto parser = [&]() {
+    try {
+      for (;;) {
+        std::unique_ptr<Batch> b;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return failure || !q_parse.empty() || split_done; });
+          if (failure || q_parse.empty()) break;
+          b = std::move(q_parse.front());
+          q_parse.pop_front();
+        }
+        for (int e = 0; e < (paired ? 2 : 1); ++e) {
+          parse_raw(b->raw[e], b->first_line[e], opt.reads[e], b->names[e], b->blob[e], b->off[e]);
+          std::string().swap(b->raw[e]);
+        }
+        if (paired && b->names[0].size() != b->names[1].size())
+          throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(b->names[0].size()) +
+                                   ", batch 2: " + std::to_string(b->names[1].size()) +
+                                   ". Are you sure your paired-end inputs have the same number of reads?");
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          q_map.push_back(std::move(b));
+        }
+        cv.notify_all();
+      }
+    }
+    catch (...) { fail(); }
+    std::lock_guard<std::mutex> lk(mu);
+    --parsers_live;
+    cv.notify_all();
+  };
+
+  auto mapper = [&](int g) {
+    try {
+      for (;;) {
+        std::unique_ptr<Batch> b;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return failure || !q_map.empty() || parsers_live == 0; });
+          if (failure || q_map.empty()) break;
+          b = std::move(q_map.front());
+          q_map.pop_front();
+        }
+        b->gpu = g;
         const size_t n = b->n();
-        Stats3 &st = gpu_stats[g];
         if (n) {
           const uint64_t cap = std::max<uint64_t>(1, std::max(b->blob[0].size(), b->blob[1].size()) + 2 * n);
           if (!paired) {
             b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
             if (abm_map_se_batch(ctxs[g], se_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->se[0].data(),
                                  b->cig[0].data(), cap, b->cig_off[0].data()) != 0) die_abm("mapping");
-            for (size_t i = 0; i < n; ++i) {
-              abm_hit h = b->se[0][i];
-              const size_t len = b->off[0][i + 1] - b->off[0][i];
-              const uint32_t *cg = b->cig[0].data() + b->cig_off[0][i];
-              const size_t ncg = b->cig_off[0][i + 1] - b->cig_off[0][i];
-              if (len && emit_se(b->sam, opt.ambig, h, ch, b->names[0][i], b->blob[0].data() + b->off[0][i], len, cg, ncg) == UNMAPPED) h.pos = 0;
-              st.s[0].tally(len == 0, h, opt.ambig, ref_len(cg, ncg));
-            }
           }
           else {
             b->pairs.resize(n); b->se[0].resize(n); b->se[1].resize(n);
@@ -383,35 +520,78 @@ int cmd_map(int argc, char **argv) {
             if (abm_map_pe_batch(ctxs[g], pe_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->blob[1].data(),
                                  b->off[1].data(), b->pairs.data(), b->se[0].data(), b->se[1].data(), b->cig[0].data(),
                                  b->cig_off[0].data(), b->cig[1].data(), b->cig_off[1].data(), cap) != 0) die_abm("mapping");
-            for (size_t i = 0; i < n; ++i) {
-              abm_pair p = b->pairs[i];
-              abm_hit h1 = b->se[0][i], h2 = b->se[1][i];
-              const char *s1 = b->blob[0].data() + b->off[0][i], *s2 = b->blob[1].data() + b->off[1][i];
-              const size_t l1 = b->off[0][i + 1] - b->off[0][i], l2 = b->off[1][i + 1] - b->off[1][i];
-              const uint32_t *c1 = b->cig[0].data() + b->cig_off[0][i], *c2 = b->cig[1].data() + b->cig_off[1][i];
-              const size_t nc1 = b->cig_off[0][i + 1] - b->cig_off[0][i], nc2 = b->cig_off[1][i + 1] - b->cig_off[1][i];
-              // select_output, src/abismal.cpp:1073-1088
-              const Outcome po = emit_pe(b->sam, opt.ambig, p, ch, b->names[0][i], b->names[1][i], s1, l1, s2, l2, c1, nc1, c2, nc2);
-              const bool report = p.r1.pos != 0 && (opt.ambig || !(p.r1.flags & 0x100));
-              bool pair_ok = report;
-              if (!report || po == UNMAPPED) {
-                if (po == UNMAPPED) { p.r1.pos = 0; p.r2.pos = 0; pair_ok = false; }
-                if (emit_se(b->sam, opt.ambig, h1, ch, b->names[0][i], s1, l1, c1, nc1) == UNMAPPED) h1.pos = 0;
-                if (emit_se(b->sam, opt.ambig, h2, ch, b->names[1][i], s2, l2, c2, nc2) == UNMAPPED) h2.pos = 0;
-              }
-              // paired_end_mapping_statistics::update, :1039-1057
-              Stats &ps = st.s[0];
-              ++ps.v[0];
-              const bool valid = p.r1.pos != 0, amb = p.r1.flags & 0x100;
-              ps.v[1] += valid && !amb; ps.v[2] += valid && amb; ps.v[3] += (l1 == 0 || l2 == 0);
-              if (pair_ok && valid) { ps.v[4] += static_cast<uint64_t>(static_cast<int64_t>(p.r1.diffs) + p.r2.diffs); ps.v[5] += ref_len(c1, nc1) + ref_len(c2, nc2); }
-              else {
-                st.s[1].tally(l1 == 0, h1, false, ref_len(c1, nc1));
-                st.s[2].tally(l2 == 0, h2, false, ref_len(c2, nc2));
-              }
-            }
           }
         }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          q_format.push_back(std::move(b));
+        }
+        cv.notify_all();
+      }
+    }
+    catch (...) { fail(); }
+    std::lock_guard<std::mutex> lk(mu);
+    --mappers_live;
+    cv.notify_all();
+  };
+
+  auto format_batch = [&](Batch &bt) {
+    Batch *b = &bt;
+    const size_t n = b->n();
+    Stats3 &st = b->stats;
+    b->sam.reserve(n * (paired ? 2 : 1) * 320);
+    if (!paired) {
+      for (size_t i = 0; i < n; ++i) {
+        abm_hit h = b->se[0][i];
+        const size_t len = b->off[0][i + 1] - b->off[0][i];
+        const uint32_t *cg = b->cig[0].data() + b->cig_off[0][i];
+        const size_t ncg = b->cig_off[0][i + 1] - b->cig_off[0][i];
+        if (len && emit_se(b->sam, opt.ambig, h, ch, b->names[0][i], b->blob[0].data() + b->off[0][i], len, cg, ncg) == UNMAPPED) h.pos = 0;
+        st.s[0].tally(len == 0, h, opt.ambig, ref_len(cg, ncg));
+      }
+      return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+      abm_pair p = b->pairs[i];
+      abm_hit h1 = b->se[0][i], h2 = b->se[1][i];
+      const char *s1 = b->blob[0].data() + b->off[0][i], *s2 = b->blob[1].data() + b->off[1][i];
+      const size_t l1 = b->off[0][i + 1] - b->off[0][i], l2 = b->off[1][i + 1] - b->off[1][i];
+      const uint32_t *c1 = b->cig[0].data() + b->cig_off[0][i], *c2 = b->cig[1].data() + b->cig_off[1][i];
+      const size_t nc1 = b->cig_off[0][i + 1] - b->cig_off[0][i], nc2 = b->cig_off[1][i + 1] - b->cig_off[1][i];
+      // select_output, src/abismal.cpp:1073-1088
+      const Outcome po = emit_pe(b->sam, opt.ambig, p, ch, b->names[0][i], b->names[1][i], s1, l1, s2, l2, c1, nc1, c2, nc2);
+      const bool report = p.r1.pos != 0 && (opt.ambig || !(p.r1.flags & 0x100));
+      bool pair_ok = report;
+      if (!report || po == UNMAPPED) {
+        if (po == UNMAPPED) { p.r1.pos = 0; p.r2.pos = 0; pair_ok = false; }
+        if (emit_se(b->sam, opt.ambig, h1, ch, b->names[0][i], s1, l1, c1, nc1) == UNMAPPED) h1.pos = 0;
+        if (emit_se(b->sam, opt.ambig, h2, ch, b->names[1][i], s2, l2, c2, nc2) == UNMAPPED) h2.pos = 0;
+      }
+      // paired_end_mapping_statistics::update, :1039-1057
+      Stats &ps = st.s[0];
+      ++ps.v[0];
+      const bool valid = p.r1.pos != 0, amb = p.r1.flags & 0x100;
+      ps.v[1] += valid && !amb; ps.v[2] += valid && amb; ps.v[3] += (l1 == 0 || l2 == 0);
+      if (pair_ok && valid) { ps.v[4] += static_cast<uint64_t>(static_cast<int64_t>(p.r1.diffs) + p.r2.diffs); ps.v[5] += ref_len(c1, nc1) + ref_len(c2, nc2); }
+      else {
+        st.s[1].tally(l1 == 0, h1, false, ref_len(c1, nc1));
+        st.s[2].tally(l2 == 0, h2, false, ref_len(c2, nc2));
+      }
+    }
+  };
+
+  auto formatter = [&]() {
+    try {
+      for (;;) {
+        std::unique_ptr<Batch> b;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return failure || !q_format.empty() || mappers_live == 0; });
+          if (failure || q_format.empty()) break;
+          b = std::move(q_format.front());
+          q_format.pop_front();
+        }
+        format_batch(*b);
         {
           std::lock_guard<std::mutex> lk(mu);
           done[b->seq] = std::move(b);
@@ -419,38 +599,47 @@ int cmd_map(int argc, char **argv) {
         cv.notify_all();
       }
     }
-    catch (...) {
-      std::lock_guard<std::mutex> lk(mu);
-      if (!failure) failure = std::current_exception();
-      cv.notify_all();
-    }
+    catch (...) { fail(); }
+    std::lock_guard<std::mutex> lk(mu);
+    --formatters_live;
+    cv.notify_all();
   };
 
-  std::vector<std::thread> workers;
-  for (int g = 0; g < n_gpus; ++g) workers.emplace_back(worker, g);
+  std::vector<std::thread> threads;
+  parsers_live = static_cast<int>(n_host);
+  mappers_live = n_gpus;
+  formatters_live = static_cast<int>(n_host);
+  threads.emplace_back(splitter);
+  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(parser);
+  for (int g = 0; g < n_gpus; ++g) threads.emplace_back(mapper, g);
+  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(formatter);
   uint64_t total_records = 0;
   {  // writer: batches leave in input order
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
-      cv.wait(lk, [&] { return failure || done.count(next_to_write) || (reading_finished && next_to_write == next_to_read); });
+      cv.wait(lk, [&] { return failure || done.count(next_to_write) || (formatters_live == 0 && done.empty()); });
       if (failure) break;
       auto it = done.find(next_to_write);
       if (it == done.end()) {
-        if (reading_finished && next_to_write == next_to_read) break;
+        if (formatters_live == 0 && done.empty()) break;
         continue;
       }
       std::unique_ptr<Batch> b = std::move(it->second);
       done.erase(it);
       ++next_to_write;
+      --in_flight;
       lk.unlock();
-      out << b->sam;
+      out.write(b->sam.data(), static_cast<std::streamsize>(b->sam.size()));
       total_records += b->n();
+      for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += b->stats.s[k].v[j];
+      b.reset();
       cv.notify_all();
       lk.lock();
     }
   }
   cv.notify_all();
-  for (auto &t : workers) t.join();
+  for (auto &t : threads) t.join();
   if (failure) std::rethrow_exception(failure);
   out.close();
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

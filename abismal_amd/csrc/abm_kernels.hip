@@ -4,6 +4,8 @@
 // read; see DESIGN.md for the data layout and the reasoning.
 #include "abm_kernels_core.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #ifndef ABM_SE_WAVES_PER_SIMD
 #define ABM_SE_WAVES_PER_SIMD 8
 #endif
@@ -258,6 +260,44 @@ hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32
   hipLaunchKernelGGL(weigh_reads_kernel, dim3(blocks), dim3(256), 0, st, ix, d_packed, d_lens, n, W, mode, d_cls, d_class33);
   hipLaunchKernelGGL(order_bases_kernel, dim3(1), dim3(64), 0, st, d_class33);
   hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, st, d_cls, n, d_class33, d_order);
+  return hipGetLastError();
+}
+
+// CIGAR compaction for the host entry points: fixed slots -> one blob + n+1 offsets
+__global__ __launch_bounds__(256) void cigar_counts_kernel(const Hit *__restrict__ res, const u32 *__restrict__ cig_n,
+                                                           u64 n, u32 stride, unsigned long long *__restrict__ cnt) {
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < n) cnt[r] = (res == nullptr || res[r].pos != 0) ? min(cig_n[r], stride) : 0u;
+  if (r == n) cnt[r] = 0;
+}
+__global__ __launch_bounds__(256) void cigar_gather_kernel(const u32 *__restrict__ cig, u32 stride,
+                                                           const unsigned long long *__restrict__ off, u64 n,
+                                                           u32 *__restrict__ blob) {
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const unsigned long long a = off[r], b = off[r + 1];
+  for (unsigned long long k = a; k < b; ++k) blob[k] = cig[r * stride + (k - a)];
+}
+
+// counts -> exclusive offsets (n+1 entries, in place) -> blob.  `tmp` is scan scratch of *tmp_bytes.
+hipError_t launch_compact_cigars(const Hit *d_res, const u32 *d_cig, const u32 *d_cig_n, u64 n, u32 stride,
+                                 unsigned long long *d_off /*[n+1]*/, u32 *d_blob, void *tmp, size_t *tmp_bytes,
+                                 hipStream_t st) {
+  if (tmp == nullptr) {
+    return hipcub::DeviceScan::ExclusiveSum(nullptr, *tmp_bytes, d_off, d_off, static_cast<int>(n + 1), st);
+  }
+  const u32 blocks = static_cast<u32>((n + 1 + 255) / 256);
+  hipLaunchKernelGGL(cigar_counts_kernel, dim3(blocks), dim3(256), 0, st, d_res, d_cig_n, n, stride, d_off);
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, *tmp_bytes, d_off, d_off, static_cast<int>(n + 1), st);
+  if (e != hipSuccess) return e;
+  if (d_blob) hipLaunchKernelGGL(cigar_gather_kernel, dim3(blocks), dim3(256), 0, st, d_cig, stride, d_off, n, d_blob);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned long long *d_off, u64 n, u32 *d_blob,
+                                hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(cigar_gather_kernel, dim3(static_cast<u32>((n + 255) / 256)), dim3(256), 0, st, d_cig, stride, d_off, n, d_blob);
   return hipGetLastError();
 }
 

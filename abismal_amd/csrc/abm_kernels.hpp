@@ -67,6 +67,10 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
                              u32 *d_lens, hipStream_t st);
 hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W,
                               int mode, u8 *d_cls, u32 *d_class33, u32 *d_order, hipStream_t st);
+hipError_t launch_compact_cigars(const Hit *d_res, const u32 *d_cig, const u32 *d_cig_n, u64 n, u32 stride,
+                                 unsigned long long *d_off, u32 *d_blob, void *tmp, size_t *tmp_bytes, hipStream_t st);
+hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned long long *d_off, u64 n, u32 *d_blob,
+                                hipStream_t st);
 hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st);
 int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 

@@ -8,6 +8,8 @@
 // statistics are summed with one RCCL all-reduce at the end.
 #include "../../include/abismal_amd.h"
 
+#include <zlib.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -26,6 +28,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+namespace abm { int sim_main(int argc, char **argv); }
 
 namespace {
 
@@ -64,14 +68,15 @@ struct Batch {
 };
 
 struct RawSplitter {
-  FILE *f = nullptr;
+  gzFile f = nullptr;  // zlib reads plain and gzip/bgzip-compressed FASTQ alike (bamxx::bgzf_file in the reference)
   std::string path, carry;
   uint64_t line_no = 0;
   bool eof = false;
-  explicit RawSplitter(const std::string &p) : f(std::fopen(p.c_str(), "rb")), path(p) {
+  explicit RawSplitter(const std::string &p) : f(gzopen(p.c_str(), "rb")), path(p) {
     if (!f) throw std::runtime_error("cannot open reads file: " + p);
+    gzbuffer(f, 1u << 20);
   }
-  ~RawSplitter() { if (f) std::fclose(f); }
+  ~RawSplitter() { if (f) gzclose(f); }
   // up to `want` records (4 lines each) of text; returns the number of complete lines delivered
   uint64_t next(size_t want, std::string &out, uint64_t &first_line) {
     first_line = line_no;
@@ -92,7 +97,9 @@ struct RawSplitter {
     while (lines < need && !eof) {
       const size_t old = out.size(), chunk = 32u << 20;
       out.resize(old + chunk);
-      const size_t got = std::fread(&out[old], 1, chunk, f);
+      const int got_i = gzread(f, &out[old], static_cast<unsigned>(chunk));
+      if (got_i < 0) throw std::runtime_error("error reading " + path);
+      const size_t got = static_cast<size_t>(got_i);
       out.resize(old + got);
       if (got < chunk) eof = true;
       scan();
@@ -208,7 +215,10 @@ struct Record {
   char cv;
 };
 
+void put_bam_record(std::string &o, const Record &r);
+thread_local bool t_bam = false;  // formatter threads switch put_record to BAM encoding
 void put_record(std::string &o, const Chroms &ch, const Record &r) {
+  if (t_bam) { put_bam_record(o, r); return; }
   o += *r.name; o += '\t'; put_uint(o, r.flag); o += '\t';
   o += ch.names[r.tid + 1]; o += '\t'; put_uint(o, static_cast<uint64_t>(r.pos) + 1); o.append("\t255\t", 5);
   for (size_t i = 0; i < r.n_cig; ++i) { put_uint(o, r.cig[i] >> 4); o += "MIDNSHP=XB"[std::min<uint32_t>(r.cig[i] & 15u, 9)]; }
@@ -226,6 +236,93 @@ void put_record(std::string &o, const Chroms &ch, const Record &r) {
   else for (size_t i = 0; i < r.n_seq; ++i) dst[i] = kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
   o.append("\t*\tNM:i:", 8); put_int(o, r.nm); o.append("\tCV:A:", 6); o += r.cv; o += '\n';
 }
+
+// ---- BAM (-B): the same records as binary BAM in BGZF blocks (SAM spec 4.2 / 4.1) ------------------
+// htslib's bam_set1 + bam_aux_update_int("NM") + bam_aux_append("CV",'A') in the reference
+// (src/abismal.cpp:513-543); quality is absent (0xFF), MAPQ 255.
+inline void put_le32(std::string &o, uint32_t v) { char b[4] = {static_cast<char>(v), static_cast<char>(v >> 8), static_cast<char>(v >> 16), static_cast<char>(v >> 24)}; o.append(b, 4); }
+inline void put_le16(std::string &o, uint16_t v) { char b[2] = {static_cast<char>(v), static_cast<char>(v >> 8)}; o.append(b, 2); }
+inline int reg2bin(int64_t beg, int64_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return static_cast<int>(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return static_cast<int>(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return static_cast<int>(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return static_cast<int>(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return static_cast<int>(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
+void put_bam_record(std::string &o, const Record &r) {
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  const size_t start = o.size();
+  put_le32(o, 0);  // block_size, patched below
+  put_le32(o, static_cast<uint32_t>(r.tid));
+  put_le32(o, r.pos);
+  const uint32_t rl = ref_len(r.cig, r.n_cig);
+  o += static_cast<char>(r.name->size() + 1);
+  o += static_cast<char>(255);
+  put_le16(o, static_cast<uint16_t>(reg2bin(r.pos, static_cast<int64_t>(r.pos) + (rl ? rl : 1))));
+  put_le16(o, static_cast<uint16_t>(r.n_cig));
+  put_le16(o, r.flag);
+  put_le32(o, static_cast<uint32_t>(r.n_seq));
+  put_le32(o, static_cast<uint32_t>(r.mtid));
+  put_le32(o, r.mtid < 0 ? 0xFFFFFFFFu : r.mpos);
+  put_le32(o, static_cast<uint32_t>(r.tlen));
+  o.append(*r.name); o += '\0';
+  for (size_t i = 0; i < r.n_cig; ++i) put_le32(o, r.cig[i]);
+  auto code = [&](size_t i) -> int {
+    const char c = r.rc ? kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])] : kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
+    const char *q = std::strchr(nt16, c);
+    return q ? static_cast<int>(q - nt16) : 15;
+  };
+  for (size_t i = 0; i < r.n_seq; i += 2)
+    o += static_cast<char>((code(i) << 4) | (i + 1 < r.n_seq ? code(i + 1) : 0));
+  o.append(r.n_seq, static_cast<char>(0xFF));
+  o.append("NM", 2);  // bam_aux_update_int: smallest type that holds the value
+  if (r.nm >= 0 && r.nm <= 255) { o += 'C'; o += static_cast<char>(r.nm); }
+  else if (r.nm >= 0) { o += 'S'; put_le16(o, static_cast<uint16_t>(r.nm)); }
+  else if (r.nm >= -128) { o += 'c'; o += static_cast<char>(r.nm); }
+  else { o += 's'; put_le16(o, static_cast<uint16_t>(static_cast<int16_t>(r.nm))); }
+  o.append("CVA", 3); o += r.cv;
+  const uint32_t bs = static_cast<uint32_t>(o.size() - start - 4);
+  o[start] = static_cast<char>(bs); o[start + 1] = static_cast<char>(bs >> 8); o[start + 2] = static_cast<char>(bs >> 16); o[start + 3] = static_cast<char>(bs >> 24);
+}
+// raw bytes -> BGZF blocks (each an independent gzip member with the BC extra field)
+void bgzf_compress(const std::string &raw, std::string &out) {
+  constexpr size_t kBlock = 0xff00;
+  std::vector<unsigned char> buf(compressBound(kBlock) + 64);
+  for (size_t at = 0; at < raw.size(); at += kBlock) {
+    const size_t len = std::min(kBlock, raw.size() - at);
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(raw.data() + at));
+    zs.avail_in = static_cast<uInt>(len);
+    zs.next_out = buf.data();
+    zs.avail_out = static_cast<uInt>(buf.size());
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("deflate failed"); }
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    const uint32_t crc = static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(raw.data() + at), static_cast<uInt>(len)));
+    static const unsigned char head[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+    out.append(reinterpret_cast<const char *>(head), 12);
+    out.append("BC", 2); put_le16(out, 2); put_le16(out, static_cast<uint16_t>(clen + 25));
+    out.append(reinterpret_cast<const char *>(buf.data()), clen);
+    put_le32(out, crc); put_le32(out, static_cast<uint32_t>(len));
+  }
+}
+std::string bam_header_bytes(const std::string &text, const Chroms &ch) {
+  std::string o("BAM\1", 4);
+  put_le32(o, static_cast<uint32_t>(text.size()));
+  o += text;
+  put_le32(o, static_cast<uint32_t>(ch.names.size() - 2));
+  for (size_t i = 1; i + 1 < ch.names.size(); ++i) {
+    put_le32(o, static_cast<uint32_t>(ch.names[i].size() + 1));
+    o += ch.names[i]; o += '\0';
+    put_le32(o, ch.starts[i + 1] - ch.starts[i]);
+  }
+  return o;
+}
+// (t_bam is defined above put_record's first use)
 
 enum Outcome { UNMAPPED, UNIQUE, AMBIG };
 
@@ -356,7 +453,6 @@ int cmd_map(int argc, char **argv) {
   if (opt.out.empty()) { std::cerr << "Missing required argument\n-o, -outfile\n"; return EXIT_SUCCESS; }
   if (opt.reads.size() != 1 && opt.reads.size() != 2) { std::cerr << "usage: abismal-amd map -i idx -o out.sam [flags] reads_1.fq [reads_2.fq]\n"; return EXIT_SUCCESS; }
   if (opt.index.empty() == opt.genome.empty()) { std::cerr << "Select one of index file (-i) or genome file (-g)\n"; return EXIT_SUCCESS; }
-  if (opt.bam) throw std::runtime_error("BAM output (-B) is not available in this build; write SAM and convert");
   const bool paired = opt.reads.size() == 2;
 
   std::string index_path = opt.index;
@@ -390,7 +486,8 @@ int cmd_map(int argc, char **argv) {
     h << "@PG\tID:ABISMAL\tVN:" << kVersion << "\tCL:\"";
     for (int i = 0; i < argc; ++i) h << argv[i] << ' ';
     h << "\"\n";
-    out << h.str();
+    if (!opt.bam) out << h.str();
+    else { std::string z; bgzf_compress(bam_header_bytes(h.str(), ch), z); out.write(z.data(), static_cast<std::streamsize>(z.size())); }
   }
 
   abm_params par;
@@ -537,6 +634,7 @@ int cmd_map(int argc, char **argv) {
 
   auto format_batch = [&](Batch &bt) {
     Batch *b = &bt;
+    t_bam = opt.bam;
     const size_t n = b->n();
     Stats3 &st = b->stats;
     b->sam.reserve(n * (paired ? 2 : 1) * 320);
@@ -592,6 +690,7 @@ int cmd_map(int argc, char **argv) {
           q_format.pop_front();
         }
         format_batch(*b);
+        if (opt.bam) { std::string z; bgzf_compress(b->sam, z); b->sam.swap(z); }
         {
           std::lock_guard<std::mutex> lk(mu);
           done[b->seq] = std::move(b);
@@ -641,6 +740,10 @@ int cmd_map(int argc, char **argv) {
   cv.notify_all();
   for (auto &t : threads) t.join();
   if (failure) std::rethrow_exception(failure);
+  if (opt.bam) {  // BGZF end-of-file marker
+    static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    out.write(reinterpret_cast<const char *>(eof_block), 28);
+  }
   out.close();
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
@@ -672,10 +775,11 @@ int cmd_map(int argc, char **argv) {
 
 int main(int argc, char **argv) {
   try {
-    if (argc < 2) { std::cout << "Program: abismal-amd\nVersion: " << kVersion << "\nUsage: abismal-amd <command> [options]\nCommands:\n    map:    map FASTQ reads to an index or a FASTA reference genome\n    idx:    make an index for a FASTA reference genome\n"; return EXIT_SUCCESS; }
+    if (argc < 2) { std::cout << "Program: abismal-amd\nVersion: " << kVersion << "\nUsage: abismal-amd <command> [options]\nCommands:\n    map:    map FASTQ reads to an index or a FASTA reference genome\n    idx:    make an index for a FASTA reference genome\n    sim:    simulate WGBS reads for a FASTA reference genome\n"; return EXIT_SUCCESS; }
     const std::string cmd = argv[1];
     if (cmd == "map") return cmd_map(argc - 1, argv + 1);
     if (cmd == "idx") return cmd_idx(argc - 1, argv + 1);
+    if (cmd == "sim") return abm::sim_main(argc - 1, argv + 1);
     std::cerr << "ERROR: invalid command " << cmd << '\n';
     return EXIT_SUCCESS;
   }

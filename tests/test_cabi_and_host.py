@@ -90,3 +90,24 @@ def test_readloader_rules():
     assert out[1] == ""            # 40 informative bases < 44
     assert out[2] == "A" * 50
     assert out[3] == "ACGT" * 11
+
+
+def test_product_sim_reproduces_the_fastq_goldens(tmp_path):
+    """`abismal-amd sim` (host-only) against data/md5sum.txt:1-7, command lines of test_scripts/test_simreads*.test."""
+    import subprocess
+    cli = os.path.join(ROOT, "abismal_amd", "abismal-amd")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    os.makedirs(tmp_path / "tests")
+    os.symlink(os.path.join(ROOT, "tests", "golden", "tRex1.fa"), tmp_path / "tests" / "tRex1.fa")
+    common = ["-seed", "1", "-n", "10000", "-m", "0.01", "-b", "0.98", "tests/tRex1.fa"]
+    for flags, prefix in ((["-single"], "tests/reads"), ([], "tests/reads_pe"), (["-a"], "tests/reads_pbat_pe"),
+                          (["-R"], "tests/reads_rpbat_pe")):
+        subprocess.run([cli, "sim"] + flags + ["-o", prefix] + common, cwd=tmp_path, check=True)
+    gold = dict(reversed(l.split()) for l in open(os.path.join(ROOT, "tests", "golden", "md5sum.txt")))
+    n = 0
+    for rel, want in gold.items():
+        if rel.endswith(".fq"):
+            assert hashlib.md5((tmp_path / rel).read_bytes()).hexdigest() == want, rel
+            n += 1
+    assert n == 7

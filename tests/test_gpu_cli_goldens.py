@@ -32,14 +32,31 @@ def chain(oracle, tmp_path_factory):
     fa = os.path.join(ROOT, "tests", "golden", "tRex1.fa")
     os.symlink(fa, wd / "tests" / "tRex1.fa")
     subprocess.run([CLI, "idx", "tests/tRex1.fa", "tests/tRex1.idx"], cwd=wd, check=True)
-    for prefix, kw in (("tests/reads", {"single_end": True}), ("tests/reads_pe", {}),
-                       ("tests/reads_pbat_pe", {"pbat": True}), ("tests/reads_rpbat_pe", {"random_pbat": True})):
-        oracle.simulate(fa, str(wd / prefix), 10000, **kw)
+    # the reads come from the product's own `sim` (md5-pinned on the CPU side by test_cabi_and_host.py)
+    common = ["-seed", "1", "-n", "10000", "-m", "0.01", "-b", "0.98", "tests/tRex1.fa"]
+    for flags, prefix in ((["-single"], "tests/reads"), ([], "tests/reads_pe"), (["-a"], "tests/reads_pbat_pe"),
+                          (["-R"], "tests/reads_rpbat_pe")):
+        subprocess.run([CLI, "sim"] + flags + ["-o", prefix] + common, cwd=wd, check=True)
     return wd
 
 
-def test_index_md5(chain):
-    assert md5(chain / "tests" / "tRex1.idx") == golden()["tests/tRex1.idx"]
+def test_index_and_fastq_md5(chain):
+    g = golden()
+    for rel in ("tests/tRex1.idx", "tests/reads_1.fq", "tests/reads_pe_1.fq", "tests/reads_pe_2.fq",
+                "tests/reads_pbat_pe_1.fq", "tests/reads_pbat_pe_2.fq", "tests/reads_rpbat_pe_1.fq",
+                "tests/reads_rpbat_pe_2.fq"):
+        assert md5(chain / rel) == g[rel], rel
+
+
+def test_gzip_input_gives_the_same_sam(chain):
+    import gzip
+    import shutil
+    with open(chain / "tests/reads_1.fq", "rb") as fi, gzip.open(chain / "tests/reads_1.fq.gz", "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    subprocess.run([CLI, "map", "-o", "tests/gz.sam", "-i", "tests/tRex1.idx", "tests/reads_1.fq.gz"], cwd=chain, check=True)
+    subprocess.run([CLI, "map", "-o", "tests/plain.sam", "-i", "tests/tRex1.idx", "tests/reads_1.fq"], cwd=chain, check=True)
+    body = lambda p: [l for l in open(chain / p) if not l.startswith("@PG")]
+    assert body("tests/gz.sam") == body("tests/plain.sam") and len(body("tests/gz.sam")) > 8000
 
 
 @pytest.mark.parametrize("args,outs", [
@@ -58,3 +75,46 @@ def test_map_goldens(chain, args, outs):
     g = golden()
     for o in outs:
         assert md5(chain / o) == g[o], f"{o} differs from the reference golden"
+
+
+def test_bam_output_carries_the_same_records(chain):
+    """-B: decode the BGZF/BAM stream with nothing but gzip + struct and compare every field with the SAM text."""
+    import gzip
+    import struct
+    for args, tag in ((["tests/reads_1.fq"], "se"), (["tests/reads_pe_1.fq", "tests/reads_pe_2.fq"], "pe")):
+        subprocess.run([CLI, "map", "-B", "-o", f"tests/{tag}.bam", "-i", "tests/tRex1.idx"] + args, cwd=chain, check=True)
+        subprocess.run([CLI, "map", "-o", f"tests/{tag}.sam", "-i", "tests/tRex1.idx"] + args, cwd=chain, check=True)
+        raw = open(chain / f"tests/{tag}.bam", "rb").read()
+        assert raw.endswith(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+        data = gzip.decompress(raw)
+        assert data[:4] == b"BAM\x01"
+        (l_text,) = struct.unpack_from("<I", data, 4)
+        text = data[8:8 + l_text].decode()
+        at = 8 + l_text
+        (n_ref,) = struct.unpack_from("<I", data, at); at += 4
+        refs = []
+        for _ in range(n_ref):
+            (ln,) = struct.unpack_from("<I", data, at); at += 4
+            refs.append(data[at:at + ln - 1].decode()); at += ln + 4
+        assert refs == ["chr1", "chr2"] and "@SQ\tSN:chr1\tLN:500000" in text
+        recs = []
+        while at < len(data):
+            (bs,) = struct.unpack_from("<I", data, at); at += 4
+            tid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHIiii", data, at)
+            p = at + 32
+            name = data[p:p + l_name - 1].decode(); p += l_name
+            cig = "".join(f"{c >> 4}{'MIDNSHP=XB'[c & 15]}" for c in struct.unpack_from(f"<{n_cig}I", data, p)); p += 4 * n_cig
+            sq = data[p:p + (l_seq + 1) // 2]; p += (l_seq + 1) // 2
+            seq = "".join("=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq))
+            assert data[p:p + l_seq] == b"\xff" * l_seq; p += l_seq
+            aux = data[p:at + bs]
+            assert aux[:3] == b"NMC" and aux[4:7] == b"CVA"
+            recs.append((name, flag, refs[tid], pos + 1, mapq, cig, "*" if mtid < 0 else "=", mpos + 1, tlen, seq, aux[3], chr(aux[7])))
+            at += bs
+        sam = []
+        for line in open(chain / f"tests/{tag}.sam"):
+            if line.startswith("@"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            sam.append((f[0], int(f[1]), f[2], int(f[3]), int(f[4]), f[5], f[6], int(f[7]), int(f[8]), f[9], int(f[11][5:]), f[12][5:]))
+        assert recs == sam and len(recs) > 8000

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_ctx_create", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
-    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_stats_allreduce",
+    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
 ]
 
 
@@ -77,6 +77,8 @@ def load_library():
     lib.abm_ctx_set_phase_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.abm_ctx_set_read_cycles.argtypes = [C.c_void_p, C.c_void_p]
     lib.abm_ctx_take_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.abm_ctx_take_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.abm_ctx_take_work_tiers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     vp = C.c_void_p
     lib.abm_map_se_batch.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp]
     lib.abm_map_se_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint64, vp, vp, C.c_uint32, vp, vp,
@@ -198,6 +200,21 @@ class Context:
         n, ms = C.c_uint64(), C.c_double()
         _check(self._lib.abm_ctx_take_kernel_time(self.handle, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
+
+    def take_kernel_times(self, capacity=256):
+        """per-launch mapping-kernel durations (ms) since the last call, in launch order"""
+        buf, n = (C.c_double * capacity)(), C.c_uint64()
+        _check(self._lib.abm_ctx_take_kernel_times(self.handle, buf, capacity, C.byref(n)))
+        return [float(buf[k]) for k in range(min(capacity, int(n.value)))]
+
+    def take_work_tiers(self):
+        """paired-end tallies per tier (see include/abismal_amd.h)"""
+        out = (C.c_uint64 * 32)()
+        _check(self._lib.abm_ctx_take_work_tiers(self.handle, out))
+        keys = ["seed_offsets", "search_probes", "candidates", "read_words", "set_updates", "alignments",
+                "cyc_probe_narrow", "cyc_gather_hamming", "cyc_replay", "cyc_se_fallback", "cyc_total",
+                "window_cache_hits", "cyc_sort_unique", "cyc_score_pairable", "cyc_mate", "cyc_best_single"]
+        return [dict(zip(keys, [int(x) for x in out[16 * t:16 * t + 16]])) for t in range(2)]
 
     def take_work(self):
         out = (C.c_uint64 * 16)()

@@ -99,6 +99,21 @@ void check_params(const abm_params *p) {
   if (!(p->valid_frac >= 0.0 && p->valid_frac <= 1.0)) throw std::invalid_argument("valid_frac out of range");
 }
 
+// HIP-event bracket around one mapping-kernel launch (abm_ctx_set_timing); returns the closing event
+hipEvent_t begin_timed(abm_ctx *ctx, hipStream_t st) {
+  if (!ctx->timing) return nullptr;
+  if (ctx->events_used == ctx->events.size()) {
+    hipEvent_t x, y;
+    HIPCHK(hipEventCreate(&x));
+    HIPCHK(hipEventCreate(&y));
+    ctx->events.emplace_back(x, y);
+  }
+  const hipEvent_t e0 = ctx->events[ctx->events_used].first, e1 = ctx->events[ctx->events_used].second;
+  ++ctx->events_used;
+  HIPCHK(hipEventRecord(e0, st));
+  return e1;
+}
+
 void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob,
                const uint64_t *d_off, uint32_t max_len, abm_hit *d_res, uint32_t *d_cig,
                uint32_t cig_stride, uint32_t *d_cig_n, uint32_t *d_status, hipStream_t st) {
@@ -111,7 +126,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
   ctx->packed.reserve(n * 4 * W);
   ctx->lens.reserve(n);
-  ctx->work.reserve(16);
+  ctx->work.reserve(32);
   HIPCHK(abm::launch_pack_reads(d_blob, reinterpret_cast<const abm::u64 *>(d_off), n, W, ctx->packed.p,
                                 ctx->lens.p, st));
   abm::SeArgs a{};
@@ -157,19 +172,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (it != ctx->se_waves.end()) waves = it->second;
   else { waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, size_frac); ctx->se_waves[shape] = waves; }
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->timing) {
-    if (ctx->events_used == ctx->events.size()) {
-      hipEvent_t x, y;
-      HIPCHK(hipEventCreate(&x));
-      HIPCHK(hipEventCreate(&y));
-      ctx->events.emplace_back(x, y);
-    }
-    e0 = ctx->events[ctx->events_used].first;
-    e1 = ctx->events[ctx->events_used].second;
-    ++ctx->events_used;
-    HIPCHK(hipEventRecord(e0, st));
-  }
+  hipEvent_t e1 = begin_timed(ctx, st);
   abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
   HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
@@ -213,7 +216,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   ctx->packed2.reserve(n * 4 * W);
   ctx->lens.reserve(n);
   ctx->lens2.reserve(n);
-  ctx->work.reserve(16);
+  ctx->work.reserve(32);
   ctx->order.reserve(n);
   ctx->cls.reserve(n);
   ctx->class33.reserve(33);
@@ -245,6 +248,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.status = d_status;
   a.work = ctx->work.p;
   a.need_big = ctx->need_big.p;
+  a.pair_diag = ctx->phase_stamps ? ctx->read_cycles : nullptr;
   // tier 1: every pair, small sets in LDS
   {
     a.cap = abm::kPeTier1Cap;
@@ -257,7 +261,9 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
-    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, st));
+    const hipEvent_t e1 = begin_timed(ctx, st);
+    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, ctx->phase_stamps, st));
+    if (e1) HIPCHK(hipEventRecord(e1, st));
   }
   // tier 2: the pairs whose candidate sets outgrew tier 1, one wave per CU, 32768-entry sets
   {
@@ -276,7 +282,10 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
-    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, st));
+    a.work = ctx->work.p + 16;  // tier 2 tallies separately (abm_ctx_take_work_tiers)
+    const hipEvent_t e1 = begin_timed(ctx, st);
+    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, ctx->phase_stamps, st));
+    if (e1) HIPCHK(hipEventRecord(e1, st));
   }
 }
 
@@ -363,8 +372,8 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
       c->dix.index_t = reinterpret_cast<const abm::u32 *>(base + offs[5]);
       c->dix.index_a = reinterpret_cast<const abm::u32 *>(base + offs[6]);
       c->dix.max_candidates = h.max_candidates;
-      c->work.reserve(16);
-      HIPCHK(hipMemset(c->work.p, 0, 16 * sizeof(unsigned long long)));
+      c->work.reserve(32);
+      HIPCHK(hipMemset(c->work.p, 0, 32 * sizeof(unsigned long long)));
     }
     catch (...) { abm_ctx_destroy(c); throw; }
     *out = c;
@@ -403,10 +412,21 @@ int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[16]) {
   return guarded([&] {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
-    unsigned long long tmp[16];
+    unsigned long long tmp[32];
     HIPCHK(hipMemcpy(tmp, ctx->work.p, sizeof(tmp), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(ctx->work.p, 0, sizeof(tmp)));
-    for (int k = 0; k < 16; ++k) out[k] = tmp[k];
+    for (int k = 0; k < 16; ++k) out[k] = tmp[k] + tmp[16 + k];
+  });
+}
+
+int abm_ctx_take_work_tiers(abm_ctx *ctx, uint64_t out[32]) {
+  return guarded([&] {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long tmp[32];
+    HIPCHK(hipMemcpy(tmp, ctx->work.p, sizeof(tmp), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(ctx->work.p, 0, sizeof(tmp)));
+    for (int k = 0; k < 32; ++k) out[k] = tmp[k];
   });
 }
 
@@ -432,6 +452,22 @@ int abm_ctx_take_kernel_time(abm_ctx *ctx, uint64_t *launches, double *total_ms)
     }
     *launches = ctx->events_used;
     *total_ms = sum;
+    ctx->events_used = 0;
+  });
+}
+
+int abm_ctx_take_kernel_times(abm_ctx *ctx, double *ms_out, uint64_t capacity, uint64_t *launches) {
+  return guarded([&] {
+    if (!ctx || !launches || (capacity && !ms_out)) throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    for (size_t k = 0; k < ctx->events_used; ++k) {
+      HIPCHK(hipEventSynchronize(ctx->events[k].second));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->events[k].first, ctx->events[k].second));
+      if (k < capacity) ms_out[k] = ms;
+    }
+    *launches = ctx->events_used;
     ctx->events_used = 0;
   });
 }

@@ -13,6 +13,7 @@ namespace abm {
 // =============================================================================
 struct SeSet {
   static constexpr bool kFifo = true;
+  static constexpr bool kAppend = false;
   int hk;   // per lane k: heap[k] = diffs*256 + payload slot
   u32 pf;   // per lane p: flags of payload p
   u32 pp;   // per lane p: pos of payload p
@@ -380,6 +381,12 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       u64 todo = __ballot(valid && hmax <= S.cutoff);
       ABM_STAMP(td);
       if (TIMED) wt.t_stream += td - tc;
+      if constexpr (Set::kAppend) if (SPECIFIC && !S.heaped && todo) {
+        // growing paired-end set: every survivor goes in, the whole chunk at once (see PeSet)
+        const int offered = __popcll(todo);
+        todo = S.append(todo, h, pos);
+        wt.updates += static_cast<u32>(offered - __popcll(todo));
+      }
       while (todo && !S.sure_ambig) {
         if constexpr (Set::kFifo) if (S.sz == static_cast<int>(kSeCap)) {
           // Saturated, all-equal regime (tandem repeats / homopolymer reads): the

@@ -7,6 +7,7 @@
 // fallback.  Two tiers run the same code: tier 1 keeps sets of up to 256
 // entries in LDS at normal occupancy; pairs whose sets outgrow that are redone
 // by tier 2 with one wave per CU and a 32768-entry set in LDS.
+#include <climits>
 #include "abm_kernels_core.hpp"
 
 namespace abm {
@@ -17,6 +18,7 @@ struct PeLds {
   i16 *ld[2];    //   ... diffs
   i16 *lsc[2];   //   ... alignment scores of the entries that can pair up
   u32 *jidx;     // [kSeCap] which list entry an alignment job belongs to
+  u32 *tmp;      // [cap] scratch table (tier 2: global memory)
   u32 cap;
 };
 
@@ -27,70 +29,172 @@ template <bool BIG> __device__ __forceinline__ int ld_list(const i16 *p) {
   return BIG ? static_cast<int>(__builtin_nontemporal_load(p)) : static_cast<int>(*p);
 }
 
-// pe_candidates, src/abismal.cpp:775-863.  Wave-uniform state + heap in LDS;
-// positions live in a per-wave global table indexed by a recycled handle.
+// pe_candidates, src/abismal.cpp:775-863, one set per wave.
+//
+// What the reference's heap does depends on the pass (:824-842):
+//  * specific pass (cutoff <= good_cutoff throughout, because set_specific starts it there):
+//    every admitted hit has diffs <= good_cutoff, so a full set GROWS by one instead of
+//    evicting, until 32768 entries.  The sentinel {0.4 L, pos 0} is never evicted, the cutoff
+//    never moves, and the set is simply "every hit within good_cutoff, in stream order".
+//    Nothing reads the heap's array order here, so hits are APPENDED, a whole chunk of 64
+//    candidates per step, straight into the list the mating code will sort.
+//  * sensitive pass: only runs if the set never grew (capacity still 32, :793-797); the cutoff
+//    restarts at the heap's top, hits beyond good_cutoff evict the top of a full set and the
+//    others still grow it (check_hits passes specific=true in both passes, :1364-1369).
+//  * a set that reaches 32768 entries starts evicting in the specific pass as well.
+// The last two need the real heap; it is rebuilt on demand by replaying std::push_heap over
+// the appended entries in their order of arrival (heapify), which reproduces libstdc++'s array
+// exactly.  Heap entries are (diffs << 16 | handle) keys, handle = slot in the position list.
+//
+// std::push_heap / std::pop_heap are restated so that the whole wave works on one operation:
+// a sift touches only one root-to-leaf path, so the lanes fetch the path (push: the hole's
+// ancestors, one per lane; pop: the 63 nodes of six heap levels at a time) in one memory round
+// trip, the walk itself runs on registers, and the moved keys are stored in parallel.
 struct PeSet {
   static constexpr bool kFifo = false;
-  u32 *heap;
-  u32 *payload;
+  static constexpr bool kAppend = true;
+  u32 *heap;   // [cap] keys, valid only while `heaped`
+  u32 *lpos;   // [cap] positions: arrival order while appending, handle-indexed once heaped
+  i16 *ld;     // [cap] diffs of the same entries (not maintained once heaped: the keys hold them)
   u32 cap_avail;
+  u32 top;     // heap[0]
   int sz, capacity, cutoff, good_cutoff;
-  bool sure_ambig, overflow;
+  bool sure_ambig, overflow, heaped;
 
   __device__ __forceinline__ static int key_d(u32 k) { return static_cast<int>(k) >> 16; }
-  __device__ __forceinline__ u32 rd(int i) const { return static_cast<u32>(uni(static_cast<int>(heap[i]))); }
   __device__ __forceinline__ void begin_read(u32 readlen) {
     const int worst = static_cast<i16>(0.4 * readlen);
-    heap[0] = static_cast<u32>(worst) << 16;  // sentinel, handle 0 -> pos 0
-    if (lane_id() == 0) payload[0] = 0;
+    top = static_cast<u32>(worst) << 16;  // sentinel, handle 0 -> pos 0
+    if (lane_id() == 0) { lpos[0] = 0; ld[0] = static_cast<i16>(worst); }
+    __syncthreads();
     sz = 1;
     capacity = static_cast<int>(kPeCapSmall);
     cutoff = worst;
     good_cutoff = static_cast<i16>(readlen / 10);
     sure_ambig = false;
     overflow = false;
+    heaped = false;
   }
   __device__ __forceinline__ bool wants_sensitive() const {
     return capacity == static_cast<int>(kPeCapSmall) || cutoff > good_cutoff;
   }
-  __device__ __forceinline__ void sift_up(int hole, u32 key) {
-    while (hole > 0) {
-      const int parent = (hole - 1) / 2;
-      const u32 pk = rd(parent);
-      if (!(key_d(pk) < key_d(key))) break;
-      heap[hole] = pk;
-      hole = parent;
+  // specific pass, not heaped: the chunk's survivors (lanes in `todo`, distance h, position pos) all
+  // go in, in lane order.  Returns the lanes still to be offered one by one (none, unless the set
+  // just reached 32768 entries and turned into a heap).
+  __device__ __forceinline__ u64 append(u64 todo, int h, u32 pos) {
+    const int lane = lane_id();
+    const int limit = static_cast<int>(min(cap_avail, kPeCapLarge));
+    const int cnt = __popcll(todo), take = min(cnt, limit - sz);
+    const int rank = __popcll(todo & ((1ull << lane) - 1));
+    const bool mine = (todo >> lane) & 1ull;
+    if (mine && rank < take) { lpos[sz + rank] = pos; ld[sz + rank] = static_cast<i16>(h); }
+    sz += take;
+    capacity = max(capacity, sz);
+    sure_ambig = (sz == capacity) && cutoff == 0;
+    if (take == cnt) return 0;
+    if (cap_avail < kPeCapLarge) {  // this tier ran out of room: redo in the next
+      overflow = true;
+      sure_ambig = true;
+      return 0;
     }
-    heap[hole] = key;
+    __syncthreads();
+    heapify();
+    return todo & __ballot(mine && rank >= take);
   }
-  __device__ __forceinline__ int pop_max(int n) {  // libstdc++ pop_heap on [0,n); see SeSet::pop_max
+  // the heap std::push_heap leaves after the entries arrived one by one
+  __device__ __forceinline__ void heapify() {
+    const int lane = lane_id();
+    for (int i0 = 0; i0 < sz; i0 += 64) {
+      const int dl = i0 + lane < sz ? static_cast<int>(ld[i0 + lane]) : 0;
+      const int m = min(64, sz - i0);
+      for (int k = 0; k < m; ++k)
+        push(i0 + k, (static_cast<u32>(rdlane(dl, k)) << 16) | static_cast<u32>(i0 + k));
+    }
+    heaped = true;
+  }
+  __device__ __forceinline__ void set_sensitive() {
+    if (!heaped) heapify();
+    cutoff = key_d(top);
+  }
+  // std::push_heap of `key` into slot `hole` (libstdc++ __push_heap): lane t holds the hole's
+  // t-th ancestor; parents with fewer diffs than the key move down one level
+  __device__ __forceinline__ void push(int hole, u32 key) {
+    const int lane = lane_id();
+    const int node = lane < 17 ? ((hole + 1) >> lane) - 1 : -1;
+    const int par = lane < 17 ? ((hole + 1) >> (lane + 1)) - 1 : -1;
+    u32 pk = 0;
+    if (par >= 0) pk = heap[par];
+    const bool moves = par >= 0 && key_d(pk) < key_d(key);
+    const int stop = __builtin_ctzll(~__ballot(moves));
+    if (lane < stop) heap[node] = pk;
+    else if (lane == stop) heap[node] = key;
+    if (((hole + 1) >> stop) == 1) top = key;
+    __syncthreads();
+  }
+  // std::pop_heap on [0,n) (libstdc++ __adjust_heap: the hole follows the larger child -- the
+  // right one on ties -- down to a leaf, then the last element sifts up from there); returns the
+  // handle of the evicted top.  Slot n-1 is left for the caller to refill.
+  __device__ __forceinline__ int pop_max(int n) {
+    const int lane = lane_id();
     const int len = n - 1;
-    const int freed = static_cast<int>(rd(0) & 0x7FFFu);
-    const u32 vk = rd(len);
-    int hole = 0, second = 0;
+    const int freed = static_cast<int>(top & 0x7FFFu);
+    // this lane's place in a six-level subtree: level lt, j-th node of that level (lane 63: the last element)
+    const int lt = 31 - __clz(lane + 1);
+    const int lj = lane + 1 - (1 << lt);
+    int g = 0, gdepth = 0;
+    u32 K;
+    auto load_subtree = [&](int root, int depth) {
+      g = root; gdepth = depth;
+      const int idx = lane == 63 ? len : ((root + 1) << lt) - 1 + lj;
+      K = idx <= len ? heap[idx] : 0u;
+    };
+    auto key_at = [&](int x, int t) { return rdlane(K, (1 << t) - 1 + (x - (((g + 1) << t) - 1))); };
+    load_subtree(0, 0);
+    const u32 vk = rdlane(K, 63);
+    int hole = 0, second = 0, depth = 0;
+    int pidx = 0;   // lane t: the path's node at depth t ...
+    u32 pnew = 0;   // ... and the child key that moves into it
     while (second < (len - 1) / 2) {
       second = 2 * (second + 1);
-      u32 sk = rd(second);
-      const u32 lk = rd(second - 1);
+      int t = depth + 1 - gdepth;
+      if (t > 5) { load_subtree(hole, depth); t = 1; }
+      u32 sk = key_at(second, t);
+      const u32 lk = key_at(second - 1, t);
       if (key_d(sk) < key_d(lk)) { --second; sk = lk; }
-      heap[hole] = sk;
+      if (lane == depth) { pidx = hole; pnew = sk; }
       hole = second;
+      ++depth;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
       second = 2 * (second + 1);
-      heap[hole] = rd(second - 1);
+      int t = depth + 1 - gdepth;
+      if (t > 5) { load_subtree(hole, depth); t = 1; }
+      const u32 lk = key_at(second - 1, t);
+      if (lane == depth) { pidx = hole; pnew = lk; }
       hole = second - 1;
+      ++depth;
     }
-    sift_up(hole, vk);
+    if (lane == depth) pidx = hole;
+    // __push_heap of the last element from the leaf: the path's nodes now hold their children's
+    // keys; while the one above has fewer diffs than vk it moves back down (restoring the old key)
+    const u32 above = __shfl_up(pnew, 1);
+    const bool back = lane >= 1 && lane <= depth && key_d(above) < key_d(vk);
+    const u64 stay = ~__ballot(back) & ((2ull << depth) - 1);
+    const int ts = 63 - __builtin_clzll(stay);
+    if (lane < ts) heap[pidx] = pnew;
+    else if (lane == ts) heap[pidx] = vk;
+    top = ts == 0 ? vk : rdlane(pnew, 0);
+    __syncthreads();
     return freed;
   }
-  // pe_candidates::update, :824-842
+  // pe_candidates::update, :824-842, on the heap
   __device__ __forceinline__ void admit(bool specific, int d, u32 /*flags*/, u32 p) {
     if (overflow) return;
+    if (!heaped) heapify();
     int handle;
     if (sz == capacity) {
       if (specific && capacity != static_cast<int>(kPeCapLarge) && d <= good_cutoff) {
-        if (capacity == static_cast<int>(cap_avail)) {  // tier 1 ran out of room: redo in tier 2
+        if (capacity == static_cast<int>(cap_avail)) {  // this tier ran out of room: redo in the next
           overflow = true;
           sure_ambig = true;
           return;
@@ -105,11 +209,11 @@ struct PeSet {
     }
     else
       handle = sz;
-    if (lane_id() == 0) payload[handle] = p;
+    if (lane_id() == 0) lpos[handle] = p;
     ++sz;
-    sift_up(sz - 1, (static_cast<u32>(d) << 16) | static_cast<u32>(handle));
-    const int top = key_d(rd(0));
-    cutoff = specific ? min(cutoff, top) : top;
+    push(sz - 1, (static_cast<u32>(d) << 16) | static_cast<u32>(handle));
+    const int topd = key_d(top);
+    cutoff = specific ? min(cutoff, topd) : topd;
     sure_ambig = (sz == capacity) && cutoff == 0;
   }
 };
@@ -155,10 +259,13 @@ template <bool BIG> struct PeWave {
   PeSet P;
   // finished-set bookkeeping for the orientation call in flight (index 0 = endA)
   int lsz[2];
-  bool worth[2];
+  bool worth[2], heap_order[2];
   u32 lflags[2];
   // CIGAR bookkeeping per read end
   u32 n_ops[2], ref_len[2];
+  // diagnostic build only (TIMED): shader cycles per phase
+  long long t_sort, t_score, t_mate, t_single;
+  int max_set;
 
   __device__ __forceinline__ WaveLds lds_of(int end) const {
     WaveLds w = lds;
@@ -175,27 +282,61 @@ template <bool BIG> struct PeWave {
     const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
     const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
     lflags[which] = flags;
+    P.lpos = pl.lpos[which];
+    P.ld = pl.ld[which];
     P.begin_read(L[end]);
     if (L[end] >= kMinReadLen) {
       P.cutoff = P.good_cutoff;  // set_specific
       seed_pass<true, TIMED>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       if (!P.overflow && P.wants_sensitive()) {
-        P.cutoff = PeSet::key_d(P.rd(0));  // set_sensitive
+        P.set_sensitive();
         seed_pass<false, TIMED>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       }
     }
     need_big |= P.overflow;
-    // freeze: the list keeps heap-array order (what best_single replays if no mating happens)
     const int n = P.sz;
     __syncthreads();
-    for (int i = lane_id(); i < n; i += 64) {
-      const u32 e = P.heap[i];
-      pl.lpos[which][i] = __builtin_nontemporal_load(P.payload + (e & 0x7FFFu));
-      pl.ld[which][i] = static_cast<i16>(static_cast<int>(e) >> 16);
-    }
+    if (P.heaped) freeze_heap_order(which, n);
     lsz[which] = n;
+    max_set = max(max_set, n);
+    heap_order[which] = P.heaped || n <= 1;
     worth[which] = n != static_cast<int>(kPeCapLarge) || P.cutoff != 0;  // should_align, :799-802
     __syncthreads();
+  }
+
+  // the list in the heap's array order (what best_single replays if no mating happens, :1715-1720)
+  __device__ __forceinline__ void freeze_heap_order(int which, int n) {
+    const int lane = lane_id();
+    u32 *lp = pl.lpos[which];
+    i16 *ldv = pl.ld[which];
+    if (n <= 64) {
+      u32 e = 0, p = 0;
+      if (lane < n) { e = P.heap[lane]; p = lp[e & 0x7FFFu]; }
+      __syncthreads();
+      if (lane < n) { lp[lane] = p; ldv[lane] = static_cast<i16>(static_cast<int>(e) >> 16); }
+    }
+    else {  // through the per-wave scratch table
+      for (int i = lane; i < n; i += 64) pl.tmp[i] = lp[P.heap[i] & 0x7FFFu];
+      __syncthreads();
+      for (int i = lane; i < n; i += 64) {
+        lp[i] = pl.tmp[i];
+        ldv[i] = static_cast<i16>(static_cast<int>(P.heap[i]) >> 16);
+      }
+    }
+    __syncthreads();
+  }
+
+  // a list still in arrival order, put into the heap's array order after the fact (only needed
+  // when the other end's set makes the reference skip the mating)
+  __device__ __forceinline__ void heap_order_now(int which) {
+    if (heap_order[which]) return;
+    P.lpos = pl.lpos[which];
+    P.ld = pl.ld[which];
+    P.sz = lsz[which];
+    P.heaped = false;
+    P.heapify();
+    freeze_heap_order(which, lsz[which]);
+    heap_order[which] = true;
   }
 
   // prepare_for_mating (:844-852): sort by position, drop duplicates; diffs are
@@ -386,41 +527,120 @@ template <bool BIG> struct PeWave {
     ref_len[end] = alen - static_cast<u32>(n_ins) + static_cast<u32>(n_del);
   }
 
-  // best_pair, src/abismal.cpp:1722-1831.  List 0 is endA's (the reference's
-  // res1), list 1 endB's; `swapped` = endA is read 2.
+  // best_pair, src/abismal.cpp:1722-1831.  List 0 is endA's (the reference's res1), list 1
+  // endB's; `swapped` = endA is read 2.
+  //
+  // The reference walks list 1 (j2) and, for each entry, the window of list-0 entries (j1) whose
+  // fragment would be min_dist..max_dist long; both lists are sorted, so the window of entry ib
+  // is [lo, hi) with lo = first pos1 + max_dist >= lim and hi = first pos1 + min_dist > lim,
+  // lim = pos2 + len2 -- what its rewind/advance loops arrive at.  Here 64 list-1 entries find
+  // their windows at once, and all (j2, j1) steps of those windows are laid out in the
+  // reference's order and taken 64 at a time; within a chunk only the steps that change
+  // pe_element's state (:570-587) are visited one by one.  "*a1 == 0" (first visit of a list-0 entry, or
+  // one whose score is 0) is "j1 >= the previous entry's hi", because hi never decreases; the
+  // score of the most recent such alignment is what the reference's scr1 holds when a better
+  // pair is recorded (:1787-1795), which the traceback's edit distance then uses.
   __device__ __forceinline__ void mate(int endA, u64 r, PairBest &best) {
+    const int lane = lane_id();
     const int endB = 1 - endA;
     const bool swapped = endA == 1;
-    const long long na = lsz[0], nb = lsz[1];
+    const int na = lsz[0], nb = lsz[1];
     const u32 lenB = L[endB];
-    auto posA = [&](long long i) { return static_cast<u32>(uni(static_cast<int>(ld_list<BIG>(pl.lpos[0] + i)))); };
-    auto posB = [&](long long i) { return static_cast<u32>(uni(static_cast<int>(ld_list<BIG>(pl.lpos[1] + i)))); };
-    long long ia = 0, ib = 0;
-    while (ia != na && posA(ia) == 0) ++ia;
-    while (ib != nb && posB(ib) == 0) ++ib;
+    const u32 *posA = pl.lpos[0], *posB = pl.lpos[1];
     int last_sa = 0, keep_sa = 0, keep_sb = 0;
     u32 keep_pa = 0, keep_pb = 0;
-    // The reference aligns an A entry at its first visit and memoises the score (an entry that
-    // scored 0 is realigned at every visit, with the same result); `last_sa` is the score of the
-    // most recent such alignment, which is what best_scr1 ends up holding (:1787-1795).
-    for (; ib != nb && !best.sure_ambig(); ++ib) {
-      const u32 pb = posB(ib);
-      const int db = uni(ld_list<BIG>(pl.ld[1] + ib));
-      int sb = 0;
-      const u32 frag_end = pb + lenB;
-      while (ia == na || (ia != 0 && posA(ia) + a.max_frag >= frag_end)) --ia;
-      while (ia != na && posA(ia) + a.max_frag < frag_end) ++ia;
-      for (; ia != na && posA(ia) + a.min_frag <= frag_end && !best.sure_ambig(); ++ia) {
-        const u32 pa = posA(ia);
-        const int da = uni(ld_list<BIG>(pl.ld[0] + ia));
-        if (sb == 0) sb = uni(ld_list<BIG>(pl.lsc[1] + ib));
-        // "if (*a1 == 0) { scr1 = align(...); *a1 = scr1; }": visited[] marks first visits
-        const int sa = uni(ld_list<BIG>(pl.lsc[0] + ia));
-        if (!visited_test_and_set(ia) || sa == 0) last_sa = sa;
-        const int pair = static_cast<i16>(sb + sa);
-        const bool better = swapped ? best.offer(pair, db, lflags[1], pb, da, lflags[0], pa)
-                                    : best.offer(pair, da, lflags[0], pa, db, lflags[1], pb);
-        if (better) { keep_sa = last_sa; keep_sb = sb; keep_pa = pa; keep_pb = pb; }
+    int prev_hi = 0;
+    int ib0 = (nb > 0 && static_cast<u32>(uni(static_cast<int>(ld_list<BIG>(posB)))) == 0u) ? 1 : 0;
+    for (; ib0 < nb && !best.sure_ambig(); ib0 += 64) {
+      const int ib = ib0 + lane;
+      u32 pb = 0;
+      int db = 0, sb = 0, lo = 0, hi = 0;
+      if (ib < nb) {
+        pb = ld_list<BIG>(posB + ib);
+        const u32 lim = pb + lenB;
+        int n = na;
+        while (n > 0) {  // first pos1 + max_dist >= lim
+          const int half = n >> 1;
+          if (ld_list<BIG>(posA + lo + half) + a.max_frag < lim) { lo += half + 1; n -= half + 1; }
+          else n = half;
+        }
+        hi = lo;
+        n = na - lo;
+        while (n > 0) {  // first pos1 + min_dist > lim, from lo on
+          const int half = n >> 1;
+          if (ld_list<BIG>(posA + hi + half) + a.min_frag <= lim) { hi += half + 1; n -= half + 1; }
+          else n = half;
+        }
+        if (hi > lo) { db = ld_list<BIG>(pl.ld[1] + ib); sb = ld_list<BIG>(pl.lsc[1] + ib); }
+      }
+      else { lo = hi = na; }
+      const u32 cnt = static_cast<u32>(hi - lo);
+      u32 total;
+      const u32 start = wave_excl_sum(cnt, total);
+      // entries before this one have been visited up to the previous entry's hi
+      int seen = __shfl_up(hi, 1);
+      if (lane == 0) seen = prev_hi;
+      prev_hi = rdlane(hi, min(63, nb - 1 - ib0));
+      int carry = 0;
+      for (u32 c0 = 0; c0 < total && !best.sure_ambig(); c0 += 64) {
+        lds.mark[lane] = 0;
+        __syncthreads();
+        if (cnt && start - c0 < 64u) lds.mark[start - c0] = static_cast<u16>(lane + 1);
+        __syncthreads();
+        const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
+        const int owner = m ? m - 1 : carry;
+        carry = rdlane(owner, 63);
+        const u32 c = c0 + lane;
+        const bool valid = c < total;
+        const int ia = __shfl(lo, owner) + static_cast<int>(c - __shfl(start, owner));
+        const u32 o_pb = __shfl(pb, owner);
+        const int o_db = __shfl(db, owner), o_sb = __shfl(sb, owner), o_seen = __shfl(seen, owner);
+        u32 pa = 0;
+        int da = 0, sa = 0;
+        if (valid) {
+          pa = ld_list<BIG>(posA + ia);
+          da = ld_list<BIG>(pl.ld[0] + ia);
+          sa = ld_list<BIG>(pl.lsc[0] + ia);
+        }
+        // scr1 as of each step: the score of the latest step that (re)aligned its list-0 entry
+        const u64 fresh = __ballot(valid && (ia >= o_seen || sa == 0));
+        const u64 upto = fresh & ((2ull << lane) - 1);
+        const int src = upto ? 63 - __builtin_clzll(upto) : lane;
+        const int sa_src = __shfl(sa, src);
+        const int scr1 = upto ? sa_src : last_sa;
+        // the run of updates
+        const int pair = static_cast<i16>(o_sb + sa);
+        const long long key = valid ? (static_cast<long long>(pair) << 20) - (da + o_db) : LLONG_MIN;
+        // Only a step that beats the standing best, or the first one that ties with it, changes
+        // anything; a tie at the best possible score makes the reference stop on the spot
+        // (sure_ambig, :1763,:1779) even though a later step might still have had fewer diffs.
+        u64 rem = __ballot(valid);
+        while (rem) {
+          const long long cur = (static_cast<long long>(best.aln_score) << 20) - (best.d1 + best.d2);
+          const u64 ge = __ballot(valid && key >= cur) & rem;
+          if (!ge) break;
+          const u64 gt = __ballot(valid && key > cur) & rem;
+          const int wl = __builtin_ctzll(ge);
+          if ((gt >> wl) & 1ull) {
+            const int w_da = rdlane(da, wl), w_db = rdlane(o_db, wl);
+            const u32 w_pa = rdlane(pa, wl), w_pb = rdlane(o_pb, wl);
+            if (swapped) { best.d1 = w_db; best.f1 = lflags[1]; best.p1 = w_pb; best.d2 = w_da; best.f2 = lflags[0]; best.p2 = w_pa; }
+            else { best.d1 = w_da; best.f1 = lflags[0]; best.p1 = w_pa; best.d2 = w_db; best.f2 = lflags[1]; best.p2 = w_pb; }
+            best.aln_score = rdlane(pair, wl);
+            keep_sa = rdlane(scr1, wl);
+            keep_sb = rdlane(o_sb, wl);
+            keep_pa = w_pa;
+            keep_pb = w_pb;
+            rem &= ~((2ull << wl) - 1);
+          }
+          else {
+            best.f1 |= kFlagAmbig;
+            if (best.aln_score == best.max_aln_score) break;
+            rem = gt ? (rem & ~((1ull << __builtin_ctzll(gt)) - 1)) : 0ull;  // more ties change nothing
+          }
+        }
+        last_sa = rdlane(scr1, static_cast<int>(min(63u, total - 1 - c0)));
+        __syncthreads();
       }
     }
     if (keep_pa == 0)
@@ -439,17 +659,6 @@ template <bool BIG> struct PeWave {
       best.clear();
   }
 
-  // visited bitmap for list 0, kept in the (now idle) score array's sign bit would alter
-  // scores, so a separate bitmap lives at the tail of the sort buffer (heap area)
-  __device__ __forceinline__ bool visited_test_and_set(long long i) {
-    u32 *bm = pl.heap;  // cap/32 words are enough; the heap is dead during mating
-    const u32 w = static_cast<u32>(uni(static_cast<int>(bm[i >> 5])));
-    const u32 bit = 1u << (i & 31);
-    if (w & bit) return true;
-    bm[i >> 5] = w | bit;
-    return false;
-  }
-
   // map_fragments + select_maps + best_single (:1715-1720, :1833-1885)
   template <bool TIMED> __device__ __forceinline__ bool orientation(int endA, bool ar, u64 r, PairBest &best) {
     const int endB = 1 - endA;
@@ -463,26 +672,43 @@ template <bool BIG> struct PeWave {
     seed_end<TIMED>(1, endB, true, !ar);
     if (need_big && !BIG)
       return true;
+    long long t0 = 0, t1 = 0;
     if (worth[0] && worth[1]) {
+      ABM_STAMP(t0);
       sort_unique(0, endA);
       sort_unique(1, endB);
+      ABM_STAMP(t1);
+      if (TIMED) t_sort += t1 - t0;
       score_pairable(endA);
-      // clear the visited bitmap
-      for (int i = lane_id(); i < (lsz[0] + 31) / 32; i += 64) pl.heap[i] = 0;
-      __syncthreads();
+      ABM_STAMP(t0);
+      if (TIMED) t_score += t0 - t1;
       mate(endA, r, best);
+      ABM_STAMP(t1);
+      if (TIMED) t_mate += t1 - t0;
     }
+    else {
+      heap_order_now(0);
+      heap_order_now(1);
+    }
+    ABM_STAMP(t0);
     // best_single: every entry of each set, in array order, into that end's single-end set
     const int ends[2] = {endA, endB};
     for (int which = 0; which < 2; ++which) {
       SeSet &S = se[ends[which]];
-      for (int k = 0; k < lsz[which] && !S.sure_ambig; ++k) {
-        const int d = uni(ld_list<BIG>(pl.ld[which] + k));
-        const u32 p = static_cast<u32>(uni(static_cast<int>(ld_list<BIG>(pl.lpos[which] + k))));
-        S.admit(false, d, lflags[which], p);
-        ++wt.updates;
+      const int n = lsz[which];
+      for (int k0 = 0; k0 < n && !S.sure_ambig; k0 += 64) {
+        const int i = k0 + lane_id();
+        const int dl = i < n ? ld_list<BIG>(pl.ld[which] + i) : 0;
+        const u32 pv = i < n ? ld_list<BIG>(pl.lpos[which] + i) : 0u;
+        const int m = min(64, n - k0);
+        for (int k = 0; k < m && !S.sure_ambig; ++k) {
+          S.admit(false, rdlane(dl, k), lflags[which], rdlane(pv, k));
+          ++wt.updates;
+        }
       }
     }
+    ABM_STAMP(t1);
+    if (TIMED) t_single += t1 - t0;
     return true;
   }
 };
@@ -525,12 +751,17 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
   lds.tb = reinterpret_cast<u8 *>(lds.mark + 64);
 
   w.P.heap = w.pl.heap;
-  w.P.payload = a.payload_ws + static_cast<u64>(blockIdx.x) * a.cap;
+  // scratch table for permuting a list: global for tier 2; tier 1 borrows the window cache (idle outside seed passes)
+  static_assert(kPeTier1Cap * 4 <= (8u << kPosCacheBits), "tier-1 scratch table must fit the window cache");
+  w.pl.tmp = BIG ? a.payload_ws + static_cast<u64>(blockIdx.x) * a.cap : reinterpret_cast<u32 *>(lds.pcache);
   w.P.cap_avail = a.cap;
   w.wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   w.n_aln = 0;
   w.overflow = false;
+  w.t_sort = w.t_score = w.t_mate = w.t_single = 0;
   bool too_long = false;
+  long long t_begin = 0, t_fb = 0;
+  ABM_STAMP(t_begin);
 
   auto next_item = [&]() -> u64 {
     unsigned long long v = 0;
@@ -568,6 +799,15 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
     w.se[0].begin_read(w.L[0] >= kMinReadLen ? w.L[0] : 0u);
     w.se[1].begin_read(w.L[1] >= kMinReadLen ? w.L[1] : 0u);
     w.need_big = false;
+    w.max_set = 0;
+    long long t_pair = 0;
+    ABM_STAMP(t_pair);
+#ifdef ABM_DIAG_MONSTER
+    const long long t_pair0 = t_pair;
+    const WorkTally wt0 = w.wt;
+    const long long m0 = w.t_sort, m1 = w.t_score, m2 = w.t_mate, m3 = w.t_single, m4 = t_fb;
+    const u32 na0 = w.n_aln;
+#endif
     w.n_ops[0] = w.n_ops[1] = 0;
     w.ref_len[0] = w.ref_len[1] = 0;
 
@@ -603,6 +843,8 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
     h1.diffs = static_cast<i16>(0.4 * w.L[0]); h1.flags = 0; h1.pos = 0;
     h2.diffs = static_cast<i16>(0.4 * w.L[1]); h2.flags = 0; h2.pos = 0;
     if (!best.should_report(a.allow_ambig != 0)) {  // single-end fallback at half the error budget
+      long long tf0 = 0, tf1 = 0;
+      ABM_STAMP(tf0);
       for (int e = 0; e < 2; ++e) {
         const WaveLds we = w.lds_of(e);
         u32 nops = 0;
@@ -611,7 +853,16 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
                   w.overflow, w.n_aln);
         if (h.pos != 0 || w.se[e].best_p != 0) w.n_ops[e] = nops;
       }
+      ABM_STAMP(tf1);
+      if (TIMED) t_fb += tf1 - tf0;
     }
+#ifdef ABM_DIAG_MONSTER
+    if (BIG && w.max_set <= ABM_DIAG_MONSTER) {  // tally only the pairs with very large sets
+      w.wt = wt0; w.t_sort = m0; w.t_score = m1; w.t_mate = m2; w.t_single = m3; t_fb = m4; w.n_aln = na0;
+      ABM_STAMP(t_pair);
+      t_begin += phase_stamp() - t_pair0;
+    }
+#endif
     if (lane == 0) {
       u32 *po = reinterpret_cast<u32 *>(a.pairs) + r * 5;
       po[0] = static_cast<u32>(static_cast<u16>(static_cast<i16>(best.aln_score)));
@@ -624,6 +875,9 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
       a.cig_n1[r] = w.n_ops[0];
       a.cig_n2[r] = w.n_ops[1];
       if (!BIG) a.need_big[r] = 0;
+      if (TIMED && a.pair_diag)
+        a.pair_diag[r] = (min(static_cast<u32>(w.max_set), 0xFFFFu) << 16) |
+                         static_cast<u32>(min((phase_stamp() - t_pair) >> 16, 0xFFFFll));
     }
   }
   if (a.work) {
@@ -638,6 +892,17 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
       atomicAdd(&a.work[4], static_cast<unsigned long long>(w.wt.updates));
       atomicAdd(&a.work[5], static_cast<unsigned long long>(w.n_aln));
       atomicAdd(&a.work[11], static_cast<unsigned long long>(wsum_hits));
+      if (TIMED) {
+        atomicAdd(&a.work[6], static_cast<unsigned long long>(w.wt.t_probe));
+        atomicAdd(&a.work[7], static_cast<unsigned long long>(w.wt.t_stream));
+        atomicAdd(&a.work[8], static_cast<unsigned long long>(w.wt.t_replay));
+        atomicAdd(&a.work[9], static_cast<unsigned long long>(t_fb));
+        atomicAdd(&a.work[10], static_cast<unsigned long long>(phase_stamp() - t_begin));
+        atomicAdd(&a.work[12], static_cast<unsigned long long>(w.t_sort));
+        atomicAdd(&a.work[13], static_cast<unsigned long long>(w.t_score));
+        atomicAdd(&a.work[14], static_cast<unsigned long long>(w.t_mate));
+        atomicAdd(&a.work[15], static_cast<unsigned long long>(w.t_single));
+      }
     }
   }
   if (lane == 0 && (w.overflow || too_long))
@@ -672,10 +937,14 @@ int pe_resident_waves(size_t lds, bool big) {
   return per_cu * prop.multiProcessorCount;
 }
 
-hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, hipStream_t st) {
+hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st) {
   if (grid == 0) return hipSuccess;
-  if (big)
+  if (big && timed)
+    hipLaunchKernelGGL((map_pe_kernel<true, true>), dim3(grid), dim3(64), lds, st, a);
+  else if (big)
     hipLaunchKernelGGL((map_pe_kernel<true, false>), dim3(grid), dim3(64), lds, st, a);
+  else if (timed)
+    hipLaunchKernelGGL((map_pe_kernel<false, true>), dim3(grid), dim3(64), lds, st, a);
   else
     hipLaunchKernelGGL((map_pe_kernel<false, false>), dim3(grid), dim3(64), lds, st, a);
   return hipGetLastError();

@@ -273,6 +273,35 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    diag = None
+    if args.phase_stamps and rank == 0:
+        # one more step through the diagnostic kernels: per-tier durations and phase shares
+        ctx.take_work_tiers()
+        ctx.set_timing(True)
+        ctx.set_phase_stamps(True)
+        pd = torch.zeros((n,), dtype=torch.int32, device=dev)
+        ctx.set_read_cycles(pd.data_ptr())
+        step()
+        torch.cuda.synchronize()
+        ctx.set_phase_stamps(False)
+        ctx.set_read_cycles(None)
+        pdh = pd.cpu().numpy().view(np.uint32)
+        size, cyc = (pdh >> 16).astype(np.int64), (pdh & 0xFFFF).astype(np.int64) << 16
+        hist = []
+        for lo_, hi_ in ((0, 257), (257, 1025), (1025, 4097), (4097, 16385), (16385, 65536)):
+            sel = (size >= lo_) & (size < hi_)
+            hist.append({"largest_set": f"{lo_}-{hi_ - 1}", "pairs": int(sel.sum()),
+                         "gcycles": round(float(cyc[sel].sum()) / 1e9, 2),
+                         "max_mcycles": round(float(cyc[sel].max()) / 1e6, 1) if sel.any() else 0})
+        times = ctx.take_kernel_times()
+        ctx.set_timing(False)
+        tiers = ctx.take_work_tiers()
+        diag = {"kernel_ms": [round(t, 2) for t in times], "by_set_size": hist, "tiers": []}
+        for t in tiers:
+            tot = max(1, t["cyc_total"])
+            diag["tiers"].append({
+                "counts": {k: t[k] for k in ("seed_offsets", "search_probes", "candidates", "set_updates", "alignments")},
+                "share": {k[4:]: round(t[k] / tot, 3) for k in t if k.startswith("cyc_") and k != "cyc_total"}})
     concordant = pairs[:, 2] != 0
     fallback = (~concordant).unsqueeze(1) & torch.stack([se1[:, 1] != 0, se2[:, 1] != 0], 1)
     stats = torch.tensor([n, int(concordant.sum()), int(fallback.sum()), 0, 0, 0], dtype=torch.int64, device=dev)
@@ -305,7 +334,7 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step"},
-        "cpu_baseline": cpu, "kernel_status": int(status.item()),
+        "cpu_baseline": cpu, "kernel_status": int(status.item()), "phase_stamps": diag,
         "mapping": {"pairs": int(stats[0]), "concordant": int(stats[1]), "ends_mapped_single": int(stats[2])}}), flush=True)
 
 

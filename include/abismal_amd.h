@@ -123,6 +123,13 @@ int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[16]);
  * [7] candidate gather+Hamming, [8] ordered replay, [9] alignment, [10] total.
  * Never enable it for a run whose time is quoted. */
 int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable);
+/* Paired-end runs keep separate tallies per tier: out[0..15] tier 1 (sets of up
+ * up to 256 entries), out[16..31] tier 2 (the pairs redone with 32768-entry
+ * sets); take_work returns their sum.  With phase stamps the paired-end kernel
+ * fills [6] probe+narrow, [7] gather+Hamming, [8] replay, [9] single-end
+ * fallback, [10] total, [12] sort+unique, [13] pairable-entry alignments,
+ * [14] mating + tracebacks, [15] best_single replay. */
+int abm_ctx_take_work_tiers(abm_ctx *ctx, uint64_t out[32]);
 /* Diagnostic kernel only: device array [n] receiving per-read shader cycles / 1024 (NULL = off). */
 int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles);
 
@@ -131,6 +138,8 @@ int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles);
  * for them and returns the number of launches and their summed duration. */
 int abm_ctx_set_timing(abm_ctx *ctx, int enable);
 int abm_ctx_take_kernel_time(abm_ctx *ctx, uint64_t *launches, double *total_ms);
+/* Same, one duration per launch in launch order (paired-end: tier 1, tier 2, ...). */
+int abm_ctx_take_kernel_times(abm_ctx *ctx, double *ms_out, uint64_t capacity, uint64_t *launches);
 
 /* Mapping statistics are six counters per struct (src/abismal.cpp:865-895) in
  * up to three structs (pairs, read1, read2: :1034-1037) = 18 x u64.  Sums them

@@ -267,7 +267,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   }
   // tier 2: the pairs whose candidate sets outgrew tier 1, one wave per CU, 32768-entry sets
   {
-    HIPCHK(abm::launch_collect_big(ctx->need_big.p, n, ctx->subset.p, ctx->subset_count.p, st));
+    HIPCHK(abm::launch_collect_big(ctx->need_big.p, ctx->cls.p, n, ctx->class33.p, ctx->subset.p, ctx->subset_count.p, st));
     a.cap = abm::kPeCapLarge;
     a.order = nullptr;
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, size_frac, a.cap, true);

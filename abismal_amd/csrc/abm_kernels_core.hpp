@@ -633,6 +633,122 @@ __device__ __forceinline__ void stage_windows(const DevIndex &ix, const WaveLds 
   }
 }
 
+// ---- scoring runs (align<false>): two job sets per wave ---------------------------
+// On the anti-diagonal schedule a lane computes a cell only every other step.  A second
+// set of jobs, laid out over the same lanes and started one step later, fills the idle
+// steps: whatever a lane's neighbours published in the previous step then always belongs
+// to the set the lane is working on now, so both sets share the two DPP moves and no
+// select is needed -- each lane just alternates between its two jobs (`jp` on even steps
+// counted from t_start, `jq` on odd ones; dp/dq = 1 if that job belongs to the delayed set).
+__device__ __forceinline__ void wavefront_pair(const WaveLds &lds, const AlnJob &jp, const AlnJob &jq, int dp,
+                                               int dq, int L, int bw_min, int bw_max, int &bestp, int &bestq) {
+  const int t_start = max(0, bw_min - 1), t_end = 2 * (L - 1 + bw_max) + 1;
+  const u64 *qp = lds.qpk + jp.qoff, *gp = lds.gwin + jp.g * lds.GW;
+  const u64 *qq = lds.qpk + jq.qoff, *gq = lds.gwin + jq.g * lds.GW;
+  int curp = 0, curq = 0, pub = 0;
+  u64 Mp = 0, Mq = 0;
+  bestp = bestq = 0;
+  auto refill = [&](const AlnJob &j, const u64 *qw, const u64 *gw, int time) -> u64 {
+    const int i0 = (time - j.jl) >> 1;
+    u64 x = 0;
+    if (j.bw)
+      x = nibbles16(qw, static_cast<int>(lds.W), i0 + j.jl - j.bw) &
+          nibbles16(gw, static_cast<int>(lds.GW), j.t0nib + i0 - 1);
+    x |= x >> 1;
+    x |= x >> 2;
+    return x & 0x1111111111111111ull;
+  };
+  auto cell = [&](const AlnJob &j, int time, int &cur, u64 &M, int &best) {
+    const int i = (time - j.jl) >> 1;
+    const int q = i + j.jl - j.bw;
+    const bool valid = j.bw != 0 && q >= 0 && q < L;
+    const int lf = from_prev_lane(pub), up = from_next_lane(pub);
+    int c = max(cur + ((static_cast<u32>(M) & 1u) ? 2 : -3), 0);
+    if (j.jl < j.bw - 1 && q < L - 1) c = max(c, up - 4);  // from_above
+    if (j.jl > 0 && q > 0) c = max(c, lf - 4);             // from_left
+    M >>= 4;
+    cur = valid ? c : 0;
+    best = max(best, cur);
+    pub = cur;
+  };
+  for (int t = t_start; t <= t_end; t += 2) {
+    if (((t - t_start) & 31) == 0) {
+      Mp = refill(jp, qp, gp, t - dp);
+      Mq = refill(jq, qq, gq, t + 1 - dq);
+    }
+    cell(jp, t - dp, curp, Mp, bestp);
+    cell(jq, t + 1 - dq, curq, Mq, bestq);
+  }
+}
+
+__device__ __forceinline__ int wave_max_i32(int x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x = max(x, __shfl_xor(x, d));
+  return x;
+}
+
+// Scores jobs [first, ...) of the LDS job list (jpos / jdf = diffs<<16 | flags), as many as fit
+// one wave: consecutive jobs share a slot of lanes (one in each set), slots sit side by side.
+// Returns one past the last job taken; the score of job first+k is left in lds.lbest[k].
+__device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &lds, int first, int n_jobs,
+                                           int L, int md, int qbase) {
+  const int lane = lane_id();
+  AlnJob ja = {0, 0, 0, 0, 0}, jb = {0, 0, 0, 0, 0};
+  int used = 0, s = first, bw_min = 64, bw_max = 0, my_o = 0;
+  while (s < n_jobs && s - first + 2 <= static_cast<int>(kMaxJobs)) {
+    const bool two = s + 1 < n_jobs;
+    const u32 dfa = lds.jdf[s], dfb = two ? lds.jdf[s + 1] : 0u;
+    const int bwa = band_for(static_cast<int>(dfa) >> 16, md);
+    const int bwb = two ? band_for(static_cast<int>(dfb) >> 16, md) : 0;
+    const int width = max(bwa, bwb);
+    if (used + width > 64) break;
+    const int o = lane - used;
+    if (o >= 0 && o < width) my_o = o;
+    if (o >= 0 && o < bwa) {
+      const u64 t_beg = static_cast<u64>(lds.jpos[s]) - static_cast<u64>((bwa - 1) / 2);
+      ja.bw = bwa; ja.qoff = qbase + static_cast<int>(enc_of(dfa & 0xFFFFu) * lds.W);
+      ja.g = s - first; ja.t0nib = static_cast<int>(t_beg & 15u);
+    }
+    if (o >= 0 && o < bwb) {
+      const u64 t_beg = static_cast<u64>(lds.jpos[s + 1]) - static_cast<u64>((bwb - 1) / 2);
+      jb.bw = bwb; jb.qoff = qbase + static_cast<int>(enc_of(dfb & 0xFFFFu) * lds.W);
+      jb.g = s + 1 - first; jb.t0nib = static_cast<int>(t_beg & 15u);
+    }
+    used += width;
+    bw_min = min(bw_min, two ? min(bwa, bwb) : bwa);
+    bw_max = max(bw_max, width);
+    s += two ? 2 : 1;
+  }
+  stage_windows(ix, lds, first, s - first, md);
+  __syncthreads();
+  const int t_start = max(0, bw_min - 1);
+  const bool even = ((t_start - my_o) & 1) == 0;  // which of the lane's jobs is due on even steps
+  ja.jl = jb.jl = my_o;
+  int bp, bq;
+  wavefront_pair(lds, even ? ja : jb, even ? jb : ja, even ? 0 : 1, even ? 1 : 0, L, bw_min, bw_max, bp, bq);
+  lds.lbest[lane] = (even ? bp : bq) | ((even ? bq : bp) << 16);
+  __syncthreads();
+  int base = 0, mine = 0;
+  for (int k = first; k < s;) {
+    const bool two = k + 1 < s;
+    const int bwa = band_for(static_cast<int>(lds.jdf[k]) >> 16, md);
+    const int bwb = two ? band_for(static_cast<int>(lds.jdf[k + 1]) >> 16, md) : 0;
+    const int v = lane < max(bwa, bwb) ? lds.lbest[base + lane] : 0;
+    const int sa = wave_max_i32(lane < bwa ? (v & 0xFFFF) : 0);
+    if (lane == k - first) mine = sa;
+    if (two) {
+      const int sb = wave_max_i32(lane < bwb ? (v >> 16) : 0);
+      if (lane == k + 1 - first) mine = sb;
+    }
+    base += max(bwa, bwb);
+    k += two ? 2 : 1;
+  }
+  __syncthreads();
+  lds.lbest[lane] = mine;
+  __syncthreads();
+  return s;
+}
+
 // align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
 __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
                                           SeSet &S, Hit &best, u32 *cig_out, u32 cig_stride,
@@ -680,41 +796,13 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   u32 top_pos = 0, b_pos = 0, b_flags = 0;
   int b_diffs = 0x7fff;
   for (int s = 0; s < n_jobs;) {
-    // pack consecutive jobs side by side until the wave is full
-    AlnJob job = {0, 0, 0, 0, 0};
-    int used = 0, first = s, bw_min = 64, bw_max = 0;
-    while (s < n_jobs) {
-      const u32 df = lds.jdf[s];
-      const int bw = band_for(static_cast<int>(df) >> 16, md);
-      if (used + bw > 64) break;
-      if (lane >= used && lane < used + bw) {
-        const u64 t_beg = static_cast<u64>(lds.jpos[s]) - static_cast<u64>((bw - 1) / 2);
-        job.bw = bw;
-        job.jl = lane - used;
-        job.qoff = static_cast<int>(enc_of(df & 0xFFFFu) * lds.W);
-        job.g = s - first;
-        job.t0nib = static_cast<int>(t_beg & 15u);
-      }
-      used += bw;
-      bw_min = min(bw_min, bw);
-      bw_max = max(bw_max, bw);
-      ++s;
-    }
-    stage_windows(ix, lds, first, s - first, md);
-    __syncthreads();
-    int bv, br;
-    wavefront<false>(lds, job, static_cast<int>(L), bw_min, bw_max, bv, br);
-    lds.lbest[lane] = bv;
-    __syncthreads();
-    // fold each band's columns; then apply the reference's selection in job order
-    int base = 0;
+    const int first = s;
+    s = score_round(ix, lds, first, n_jobs, static_cast<int>(L), md, 0);
+    // apply the reference's selection in job order
     for (int k = first; k < s; ++k) {
       const u32 df = lds.jdf[k];
       const int d = static_cast<int>(df) >> 16;
-      const int bw = band_for(d, md);
-      int sc = lane < bw ? lds.lbest[base + lane] : 0;
-      sc = static_cast<i16>(static_cast<int>(wave_max_u64(static_cast<u64>(static_cast<u32>(sc)))));
-      base += bw;
+      const int sc = static_cast<i16>(lds.lbest[k - first]);
       const u32 pos = lds.jpos[k], flags = df & 0xFFFFu;
       ++n_aln;
       if (sc > top) { b_diffs = d; b_flags = flags; b_pos = pos; top = sc; top_pos = pos; }

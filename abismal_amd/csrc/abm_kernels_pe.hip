@@ -423,7 +423,6 @@ template <bool BIG> struct PeWave {
     for (int which = 0; which < 2; ++which) {
       const int end = ends[which], n = lsz[which];
       const int md = static_cast<i16>(a.valid_frac * L[end]);
-      const int qoff = static_cast<int>((end * 4 + enc_of(lflags[which])) * lds.W);
       int cursor = 0;
       for (;;) {
         int n_jobs = 0;
@@ -446,35 +445,10 @@ template <bool BIG> struct PeWave {
         }
         if (n_jobs == 0) break;
         for (int s = 0; s < n_jobs;) {  // rounds of side-by-side bands
-          AlnJob job = {0, 0, 0, 0, 0};
-          int used = 0, first = s, bw_min = 64, bw_max = 0;
-          while (s < n_jobs) {
-            const u32 df = lds.jdf[s];
-            const int bw = band_for(static_cast<int>(df) >> 16, md);
-            if (used + bw > 64) break;
-            if (lane >= used && lane < used + bw) {
-              const u64 t_beg = static_cast<u64>(lds.jpos[s]) - static_cast<u64>((bw - 1) / 2);
-              job.bw = bw; job.jl = lane - used; job.qoff = qoff; job.g = s - first;
-              job.t0nib = static_cast<int>(t_beg & 15u);
-            }
-            used += bw; bw_min = min(bw_min, bw); bw_max = max(bw_max, bw);
-            ++s;
-          }
-          stage_windows(a.ix, lds, first, s - first, md);
-          __syncthreads();
-          int bv, br;
-          wavefront<false>(lds, job, static_cast<int>(L[end]), bw_min, bw_max, bv, br);
-          lds.lbest[lane] = bv;
-          __syncthreads();
-          int base = 0;
-          for (int k = first; k < s; ++k) {
-            const int bw = band_for(static_cast<int>(lds.jdf[k]) >> 16, md);
-            int sc = lane < bw ? lds.lbest[base + lane] : 0;
-            sc = static_cast<i16>(static_cast<int>(wave_max_u64(static_cast<u64>(static_cast<u32>(sc)))));
-            base += bw;
-            if (lane == 0) pl.lsc[which][pl.jidx[k]] = static_cast<i16>(sc);
-            ++n_aln;
-          }
+          const int first = s;
+          s = score_round(a.ix, lds, first, n_jobs, static_cast<int>(L[end]), md, static_cast<int>(end * 4 * lds.W));
+          if (lane < s - first) pl.lsc[which][pl.jidx[first + lane]] = static_cast<i16>(lds.lbest[lane]);
+          n_aln += static_cast<u32>(s - first);
           __syncthreads();
         }
       }
@@ -857,6 +831,15 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
       if (TIMED) t_fb += tf1 - tf0;
     }
 #ifdef ABM_DIAG_MONSTER
+    if (TIMED && BIG) {
+      const long long tot = phase_stamp() - t_pair0;
+      if (tot > 1000000000ll && lane == 0)
+        printf("pair %llu set %d Mcyc %lld probe %lld stream %lld replay %lld sort %lld score %lld mate %lld single %lld fb %lld | offs %u probes %u cands(l0) %u upd %u aln %u L %u %u\n",
+               (unsigned long long)r, w.max_set, tot >> 20, (w.wt.t_probe - wt0.t_probe) >> 20, (w.wt.t_stream - wt0.t_stream) >> 20,
+               (w.wt.t_replay - wt0.t_replay) >> 20, (w.t_sort - m0) >> 20, (w.t_score - m1) >> 20, (w.t_mate - m2) >> 20,
+               (w.t_single - m3) >> 20, (t_fb - m4) >> 20, w.wt.seed_iters - wt0.seed_iters, w.wt.probes - wt0.probes,
+               w.wt.cands - wt0.cands, w.wt.updates - wt0.updates, w.n_aln - na0, w.L[0], w.L[1]);
+    }
     if (BIG && w.max_set <= ABM_DIAG_MONSTER) {  // tally only the pairs with very large sets
       w.wt = wt0; w.t_sort = m0; w.t_score = m1; w.t_mate = m2; w.t_single = m3; t_fb = m4; w.n_aln = na0;
       ABM_STAMP(t_pair);
@@ -909,11 +892,40 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
     atomicOr(a.status, (w.overflow ? 1u : 0u) | (too_long ? 2u : 0u));
 }
 
-// compact the pairs flagged by tier 1 into a list for tier 2
-__global__ __launch_bounds__(256) void collect_big_kernel(const u8 *__restrict__ need_big, u64 n,
-                                                          u32 *__restrict__ subset, u32 *__restrict__ count) {
+// compact the pairs flagged by tier 1 into a list for tier 2, heaviest weight class first (a
+// counting sort on the class the tier-1 ordering already computed): the few pairs with huge
+// candidate sets run for a long time on their single wave and must not start last
+__global__ __launch_bounds__(256) void big_hist_kernel(const u8 *__restrict__ need_big, const u8 *__restrict__ cls,
+                                                       u64 n, u32 *__restrict__ class_count) {
+  __shared__ u32 hist[33];
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r < n && need_big[r]) subset[atomicAdd(count, 1u)] = static_cast<u32>(r);
+  if (r < n && need_big[r]) atomicAdd(&hist[cls[r]], 1u);
+  __syncthreads();
+  if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void big_bases_kernel(u32 *class_count /*[33] in: counts, out: start of each class*/, u32 *total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    u32 at = 0;
+    for (int c = 32; c >= 0; --c) { const u32 k = class_count[c]; class_count[c] = at; at += k; }
+    *total = at;
+  }
+}
+__global__ __launch_bounds__(256) void big_scatter_kernel(const u8 *__restrict__ need_big, const u8 *__restrict__ cls,
+                                                          u64 n, u32 *__restrict__ class_cursor,
+                                                          u32 *__restrict__ subset) {
+  __shared__ u32 hist[33], base[33];
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool take = r < n && need_big[r];
+  u32 c = 0, rank = 0;
+  if (take) { c = cls[r]; rank = atomicAdd(&hist[c], 1u); }
+  __syncthreads();
+  if (threadIdx.x < 33 && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], hist[threadIdx.x]);
+  __syncthreads();
+  if (take) subset[base[c] + rank] = static_cast<u32>(r);
 }
 
 size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big) {
@@ -950,11 +962,15 @@ hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool t
   return hipGetLastError();
 }
 
-hipError_t launch_collect_big(const u8 *need_big, u64 n, u32 *subset, u32 *count, hipStream_t st) {
+hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *class33, u32 *subset, u32 *count,
+                              hipStream_t st) {
   if (n == 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(count, 0, sizeof(u32), st);
+  hipError_t e = hipMemsetAsync(class33, 0, 33 * sizeof(u32), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(collect_big_kernel, dim3(static_cast<u32>((n + 255) / 256)), dim3(256), 0, st, need_big, n, subset, count);
+  const u32 blocks = static_cast<u32>((n + 255) / 256);
+  hipLaunchKernelGGL(big_hist_kernel, dim3(blocks), dim3(256), 0, st, need_big, cls, n, class33);
+  hipLaunchKernelGGL(big_bases_kernel, dim3(1), dim3(64), 0, st, class33, count);
+  hipLaunchKernelGGL(big_scatter_kernel, dim3(blocks), dim3(256), 0, st, need_big, cls, n, class33, subset);
   return hipGetLastError();
 }
 

@@ -53,7 +53,7 @@ struct PeArgs {
   u32 *list_ws;                  // tier 2: [grid][2][cap] positions, then diffs and scores (i16)
   u32 *heap_ws;                  // tier 2: [grid][cap] candidate heap / sort buffer
   u32 cap;
-  u32 *pair_diag;                // optional [n], diagnostic kernel only: largest set << 16 | shader cycles >> 16
+  u32 *pair_diag;                // optional [n], diagnostic kernel only: largest set << 16 | shader cycles >> 20
 };
 
 size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big);

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
       if (!BIG) a.need_big[r] = 0;
       if (TIMED && a.pair_diag)
         a.pair_diag[r] = (min(static_cast<u32>(w.max_set), 0xFFFFu) << 16) |
-                         static_cast<u32>(min((phase_stamp() - t_pair) >> 16, 0xFFFFll));
+                         static_cast<u32>(min((phase_stamp() - t_pair) >> 20, 0xFFFFll));
     }
   }
   if (a.work) {

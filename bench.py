@@ -242,31 +242,49 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     b1, b2 = sample_pairs(genome_words, starts, n, L, 2000 + rank, dev)
     off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
     stride = 16
-    pairs = torch.zeros((n, 5), dtype=torch.int32, device=dev)
-    se1 = torch.zeros((n, 2), dtype=torch.int32, device=dev)
-    se2 = torch.zeros((n, 2), dtype=torch.int32, device=dev)
-    c1 = torch.zeros((n, stride), dtype=torch.int32, device=dev)
-    c2 = torch.zeros((n, stride), dtype=torch.int32, device=dev)
-    n1 = torch.zeros((n,), dtype=torch.int32, device=dev)
-    n2 = torch.zeros((n,), dtype=torch.int32, device=dev)
-    status = torch.zeros((1,), dtype=torch.int32, device=dev)
     params = A.Params()
-    stream = torch.cuda.current_stream().cuda_stream
     import ctypes as C
     lib = A.load_library()
 
-    def step():
-        rc = lib.abm_map_pe_device(ctx.handle, A.PE_NORMAL, C.byref(params), n, b1.data_ptr(), off.data_ptr(),
-                                   b2.data_ptr(), off.data_ptr(), L, pairs.data_ptr(), se1.data_ptr(), se2.data_ptr(),
-                                   c1.data_ptr(), c2.data_ptr(), stride, n1.data_ptr(), n2.data_ptr(),
-                                   status.data_ptr(), stream)
+    # Batches are independent, so consecutive steps go to alternating (context, stream) slots, as
+    # the CLI's mapper threads do: the few pairs whose 32768-entry candidate sets keep one wave
+    # busy long after the rest of a batch is done then overlap with the next batch.
+    class Slot:
+        def __init__(self, c, st):
+            self.ctx, self.tstream = c, st
+            self.stream = st.cuda_stream if st is not None else torch.cuda.current_stream().cuda_stream
+            self.pairs = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+            self.se1 = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+            self.se2 = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+            self.c1 = torch.zeros((n, stride), dtype=torch.int32, device=dev)
+            self.c2 = torch.zeros((n, stride), dtype=torch.int32, device=dev)
+            self.n1 = torch.zeros((n,), dtype=torch.int32, device=dev)
+            self.n2 = torch.zeros((n,), dtype=torch.int32, device=dev)
+            self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    slots = [Slot(ctx, None)]
+    for _ in range(1, max(1, args.streams)):
+        slots.append(Slot(A.Context(index, dev.index or 0), torch.cuda.Stream(device=dev)))
+    pairs, se1, se2, status = slots[0].pairs, slots[0].se1, slots[0].se2, slots[0].status
+    issued = [0]
+
+    def step(slot=None):
+        z = slot or slots[issued[0] % len(slots)]
+        issued[0] += 1
+        rc = lib.abm_map_pe_device(z.ctx.handle, A.PE_NORMAL, C.byref(params), n, b1.data_ptr(), off.data_ptr(),
+                                   b2.data_ptr(), off.data_ptr(), L, z.pairs.data_ptr(), z.se1.data_ptr(),
+                                   z.se2.data_ptr(), z.c1.data_ptr(), z.c2.data_ptr(), stride, z.n1.data_ptr(),
+                                   z.n2.data_ptr(), z.status.data_ptr(), z.stream)
         if rc != 0:
             raise RuntimeError(lib.abm_last_error().decode())
 
-    for _ in range(args.warmup):
+    for z in slots:  # every slot's workspaces are sized before the timed region
+        step(z)
+    for _ in range(max(0, args.warmup - len(slots))):
         step()
     torch.cuda.synchronize()
     barrier()
+    issued[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -281,12 +299,12 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         ctx.set_phase_stamps(True)
         pd = torch.zeros((n,), dtype=torch.int32, device=dev)
         ctx.set_read_cycles(pd.data_ptr())
-        step()
+        step(slots[0])
         torch.cuda.synchronize()
         ctx.set_phase_stamps(False)
         ctx.set_read_cycles(None)
         pdh = pd.cpu().numpy().view(np.uint32)
-        size, cyc = (pdh >> 16).astype(np.int64), (pdh & 0xFFFF).astype(np.int64) << 16
+        size, cyc = (pdh >> 16).astype(np.int64), (pdh & 0xFFFF).astype(np.int64) << 20
         hist = []
         for lo_, hi_ in ((0, 257), (257, 1025), (1025, 4097), (4097, 16385), (16385, 65536)):
             sel = (size >= lo_) & (size < hi_)
@@ -333,7 +351,8 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step"},
+        "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step",
+                   "streams": len(slots)},
         "cpu_baseline": cpu, "kernel_status": int(status.item()), "phase_stamps": diag,
         "mapping": {"pairs": int(stats[0]), "concordant": int(stats[1]), "ends_mapped_single": int(stats[2])}}), flush=True)
 
@@ -352,6 +371,8 @@ def main():
     ap.add_argument("--pe", action="store_true",
                     help="paired-end variant (BASELINE config 3): 2 x --read-len pairs from 150-500 bp fragments; "
                          "not the headline metric -- prints its own JSON line")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="--pe only: consecutive steps alternate over this many (context, stream) slots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-stamps", action="store_true",
                     help="after the timed region, run one extra step of the diagnostic kernel and report phase shares")

@@ -150,6 +150,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : params->valid_frac;
   a.size_frac = size_frac;
   a.GW = abm::se_window_words(eff_len, size_frac);
+  a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.res = reinterpret_cast<abm::Hit *>(d_res);
@@ -238,6 +239,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.n_pairs = n;
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : std::max(params->valid_frac, params->valid_frac);
   a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, size_frac);
+  a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.min_frag = params->min_frag; a.max_frag = params->max_frag;

@@ -72,14 +72,15 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
-  lds.pcache = lds.qbits + 4 * a.WB;
-  lds.gwin = lds.pcache + (1u << kPosCacheBits);
-  lds.ctmp = reinterpret_cast<u32 *>(lds.gwin + kMaxJobs * a.GW);
+  lds.gwin = lds.qbits + 4 * a.WB;
+  lds.pcache = lds.gwin + kMaxJobs * a.GW;
+  // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
+  lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
+  lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
   lds.jpos = lds.ctmp + a.cig_stride;
   lds.jdf = lds.jpos + kSeCap;
   lds.lbest = reinterpret_cast<int *>(lds.jdf + kSeCap);
   lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
-  lds.tb = reinterpret_cast<u8 *>(lds.mark + 64);
 
   // (rc, a_rich) calls per mode, in the reference's order
   // T-rich :1556-1572 | A-rich (-A/-P) | random PBAT :1649-1676
@@ -309,16 +310,22 @@ u32 se_window_words(u32 max_len, double valid_frac) {
   return ((max_len + bw + 15 + 15) >> 4) + 1;
 }
 
-size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac) {
+u32 tb_extra_bytes(u32 GW, u32 max_len, double valid_frac) {
   const int md = static_cast<i16>(valid_frac * max_len);
   int bw = 2 * md + 1;
   if (bw > static_cast<int>(kMaxBand) || bw < 0) bw = kMaxBand;
   if (bw < 1) bw = 1;
+  const size_t need = static_cast<size_t>(max_len + bw) * bw;
+  const size_t have = static_cast<size_t>(kMaxJobs - 1) * GW * 8 + (static_cast<size_t>(8) << kPosCacheBits);
+  return need > have ? static_cast<u32>((need - have + 7) & ~static_cast<size_t>(7)) : 0u;
+}
+
+size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac) {
   const u32 GW = se_window_words(max_len, valid_frac);
   size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) +
              static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
              2 * kSeCap * 4 + 64 * 4 + 64 * 2;
-  b += static_cast<size_t>(max_len + bw) * bw;
+  b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);
 }
 
@@ -329,7 +336,11 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false>, 64,
                                                    se_lds_bytes(W, WB, cig_stride, max_len, valid_frac)) != hipSuccess)
     return 0;
-  return per_cu * prop.multiProcessorCount;
+  // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh): the kernel is bound by random 128-byte
+  // line fetches, and beyond ~20 waves per CU more gathers in flight only evict each other's lines
+  // and translations (1427 ms at 20 waves/CU, 1577 ms at 28, 1681 ms at 32 for 10 M reads).
+  constexpr int kSeWavesPerCu = 20;
+  return min(per_cu, kSeWavesPerCu) * prop.multiProcessorCount;
 }
 
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,

@@ -12,6 +12,7 @@ struct SeArgs {
   const u32 *order;   // [n] processing order (heaviest first), or null
   u64 n_reads;
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
+  u32 tb_extra;       // tb_extra_bytes()
   int mode;           // ABM_SE_*
   double valid_frac;
   double size_frac;   // valid_frac used to size LDS bands (1.0 when the genome has IUPAC codes)
@@ -35,7 +36,7 @@ struct PeArgs {
   const u32 *subset;             // tier 2: ids of the pairs to redo
   const u32 *subset_count;       // tier 2: how many
   u64 n_pairs;
-  u32 W, WB, GW;
+  u32 W, WB, GW, tb_extra;
   int mode;
   double valid_frac;
   u32 min_frag, max_frag;
@@ -56,6 +57,9 @@ struct PeArgs {
   u32 *pair_diag;                // optional [n], diagnostic kernel only: largest set << 16 | shader cycles >> 20
 };
 
+// bytes the traceback table needs beyond the LDS it overlays (genome-window slots 1.. and the
+// window cache, both idle while a traceback runs); the kernels carve exactly this much extra
+u32 tb_extra_bytes(u32 GW, u32 max_len, double valid_frac);
 size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big);
 int pe_resident_waves(size_t lds, bool big);
 hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st);

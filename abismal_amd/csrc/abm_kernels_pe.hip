@@ -696,9 +696,11 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
   lds.W = a.W; lds.WB = a.WB; lds.GW = a.GW;
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.qbits = lds.qpk + 8 * a.W;
-  lds.pcache = lds.qbits + 8 * a.WB;
-  lds.gwin = lds.pcache + (1u << kPosCacheBits);
-  lds.ctmp = reinterpret_cast<u32 *>(lds.gwin + kMaxJobs * a.GW);
+  lds.gwin = lds.qbits + 8 * a.WB;
+  lds.pcache = lds.gwin + kMaxJobs * a.GW;
+  // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
+  lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
+  lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
   lds.jpos = lds.ctmp + a.cig_stride;
   lds.jdf = lds.jpos + kSeCap;
   w.pl.jidx = lds.jdf + kSeCap;
@@ -722,7 +724,6 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
     after_heap = reinterpret_cast<u32 *>(h + 4 * a.cap);
   }
   lds.mark = reinterpret_cast<u16 *>(after_heap);
-  lds.tb = reinterpret_cast<u8 *>(lds.mark + 64);
 
   w.P.heap = w.pl.heap;
   // scratch table for permuting a list: global for tier 2; tier 1 borrows the window cache (idle outside seed passes)
@@ -929,13 +930,10 @@ __global__ __launch_bounds__(256) void big_scatter_kernel(const u8 *__restrict__
 }
 
 size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big) {
-  const int md = static_cast<i16>(valid_frac * max_len);
-  int bw = 2 * md + 1;
-  if (bw > static_cast<int>(kMaxBand) || bw < 1) bw = kMaxBand;
   size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
              static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + 64 * 2;
   if (!big) b += static_cast<size_t>(cap) * (4 + 2 * 4 + 4 * 2);
-  b += static_cast<size_t>(max_len + bw) * bw;
+  b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);
 }
 

@@ -7,8 +7,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -30,9 +33,23 @@ void hip_check(hipError_t e, const char *what) {
 
 template <class F> int guarded(F &&f) {
   try { f(); return 0; }
+  catch (const std::length_error &e) { g_error = e.what(); return ABM_ERR_CAPACITY; }
   catch (const std::exception &e) { g_error = e.what(); return -1; }
   catch (...) { g_error = "unknown error"; return -1; }
 }
+
+// ABM_TRACE_HOST=1: wall-clock of the host entry points' sections on stderr (diagnostic)
+struct HostTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  explicit HostTrace() : on(std::getenv("ABM_TRACE_HOST") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[abm host] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 template <class T> struct DevBuf {  // grow-only device allocation
   T *p = nullptr;
@@ -49,15 +66,25 @@ template <class T> struct DevBuf {  // grow-only device allocation
 
 }  // namespace
 
+// the index arrays resident on one device, shared by every context created on it
+struct DeviceReplica {
+  void *arena = nullptr;  // one allocation holding the seven index arrays
+  abm::DevIndex dix{};
+  int refs = 0;
+};
+
 struct abm_index {
   abm::HostIndex h;
+  mutable std::mutex mu;
+  mutable std::map<int, DeviceReplica> replicas;  // by device ordinal
 };
 
 struct abm_ctx {
   int device = 0;
   const abm_index *ix = nullptr;
   abm::DevIndex dix{};
-  void *arena = nullptr;  // one allocation holding the seven index arrays
+  bool holds_replica = false;
+  hipStream_t stream = nullptr;  // the host-buffer entry points run on the context's own stream
   // per-batch workspaces (grow-only; sized by the largest batch seen)
   DevBuf<abm::u64> packed, packed2;
   DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2, heap2;
@@ -180,25 +207,38 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (e1) HIPCHK(hipEventRecord(e1, st));
 }
 
-// fixed CIGAR slots on the device -> compact blob + offsets in the caller's host buffers
+// fixed CIGAR slots on the device -> compact blob + offsets in the caller's host buffers.  Offsets
+// reserve every read's full op count; a read whose CIGAR outgrew its slot gets only the ops the slot
+// held and is patched by the caller (patch_long_cigars).
 void fetch_cigars(abm_ctx *ctx, const abm::Hit *d_res, const abm::u32 *d_cig, const abm::u32 *d_cig_n, uint64_t n,
                   uint32_t stride, uint32_t *out_blob, uint64_t cap, uint64_t *out_off) {
+  const hipStream_t st = ctx->stream;
   ctx->coff.reserve(n + 1);
   size_t tmp_bytes = 0;
-  HIPCHK(abm::launch_compact_cigars(nullptr, nullptr, nullptr, n, stride, ctx->coff.p, nullptr, nullptr, &tmp_bytes, nullptr));
+  HIPCHK(abm::launch_compact_cigars(nullptr, nullptr, nullptr, n, stride, ctx->coff.p, nullptr, nullptr, &tmp_bytes, st));
   ctx->scan_tmp.reserve(tmp_bytes + 16);
-  HIPCHK(abm::launch_compact_cigars(d_res, d_cig, d_cig_n, n, stride, ctx->coff.p, nullptr, ctx->scan_tmp.p, &tmp_bytes, nullptr));
+  HIPCHK(abm::launch_compact_cigars(d_res, d_cig, d_cig_n, n, stride, ctx->coff.p, nullptr, ctx->scan_tmp.p, &tmp_bytes, st));
   unsigned long long total = 0;
-  HIPCHK(hipMemcpy(&total, ctx->coff.p + n, sizeof(total), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(&total, ctx->coff.p + n, sizeof(total), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   if (total > cap) throw std::length_error("cig_capacity too small");
   ctx->cblob.reserve(std::max<unsigned long long>(total, 1));
   if (total) {
-    // offsets are already scanned: only the gather is left (counts kernel + scan are idempotent to skip)
-    HIPCHK(abm::launch_gather_cigars(d_cig, stride, ctx->coff.p, n, ctx->cblob.p, nullptr));
-    HIPCHK(hipMemcpy(out_blob, ctx->cblob.p, total * 4ull, hipMemcpyDeviceToHost));
+    // offsets are already scanned: only the gather is left
+    HIPCHK(abm::launch_gather_cigars(d_cig, stride, ctx->coff.p, n, ctx->cblob.p, st));
+    HIPCHK(hipMemcpyAsync(out_blob, ctx->cblob.p, total * 4ull, hipMemcpyDeviceToHost, st));
   }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "offset width");
-  HIPCHK(hipMemcpy(out_off, ctx->coff.p, (n + 1) * 8ull, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(out_off, ctx->coff.p, (n + 1) * 8ull, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+}
+
+// reads whose compact CIGAR is longer than the slot it came from
+std::vector<uint64_t> long_cigars(const uint64_t *off, uint64_t n, uint32_t stride) {
+  std::vector<uint64_t> v;
+  for (uint64_t r = 0; r < n; ++r)
+    if (off[r + 1] - off[r] > stride) v.push_back(r);
+  return v;
 }
 
 void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob1,
@@ -351,29 +391,44 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
     try {
       c->device = device;
       c->ix = ix;
-      const abm::HostIndex &h = ix->h;
-      // one arena, 256-byte aligned sub-arrays: genome first (u64), then the u32 tables
-      auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
-      const size_t sz[7] = {h.genome.size() * 8,  h.counter.size() * 4, h.counter_t.size() * 4,
-                            h.counter_a.size() * 4, h.index.size() * 4, h.index_t.size() * 4,
-                            h.index_a.size() * 4};
-      const void *src[7] = {h.genome.data(),    h.counter.data(), h.counter_t.data(), h.counter_a.data(),
-                            h.index.data(),     h.index_t.data(), h.index_a.data()};
-      size_t offs[7], total = 0;
-      for (int k = 0; k < 7; ++k) { offs[k] = total; total += up(sz[k] + 64); }
-      HIPCHK(hipMalloc(&c->arena, total));
-      HIPCHK(hipMemset(c->arena, 0, total));
-      char *base = static_cast<char *>(c->arena);
-      for (int k = 0; k < 7; ++k)
-        if (sz[k]) HIPCHK(hipMemcpy(base + offs[k], src[k], sz[k], hipMemcpyHostToDevice));
-      c->dix.genome = reinterpret_cast<const abm::u64 *>(base + offs[0]);
-      c->dix.counter = reinterpret_cast<const abm::u32 *>(base + offs[1]);
-      c->dix.counter_t = reinterpret_cast<const abm::u32 *>(base + offs[2]);
-      c->dix.counter_a = reinterpret_cast<const abm::u32 *>(base + offs[3]);
-      c->dix.index = reinterpret_cast<const abm::u32 *>(base + offs[4]);
-      c->dix.index_t = reinterpret_cast<const abm::u32 *>(base + offs[5]);
-      c->dix.index_a = reinterpret_cast<const abm::u32 *>(base + offs[6]);
-      c->dix.max_candidates = h.max_candidates;
+      {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        DeviceReplica &rep = ix->replicas[device];
+        if (rep.refs == 0) {
+          const abm::HostIndex &h = ix->h;
+          // one arena, 256-byte aligned sub-arrays: genome first (u64), then the u32 tables
+          auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+          const size_t sz[7] = {h.genome.size() * 8,  h.counter.size() * 4, h.counter_t.size() * 4,
+                                h.counter_a.size() * 4, h.index.size() * 4, h.index_t.size() * 4,
+                                h.index_a.size() * 4};
+          const void *src[7] = {h.genome.data(),    h.counter.data(), h.counter_t.data(), h.counter_a.data(),
+                                h.index.data(),     h.index_t.data(), h.index_a.data()};
+          size_t offs[7], total = 0;
+          for (int k = 0; k < 7; ++k) { offs[k] = total; total += up(sz[k] + 64); }
+          void *arena = nullptr;
+          HIPCHK(hipMalloc(&arena, total));
+          try {
+            HIPCHK(hipMemset(arena, 0, total));
+            char *base = static_cast<char *>(arena);
+            for (int k = 0; k < 7; ++k)
+              if (sz[k]) HIPCHK(hipMemcpy(base + offs[k], src[k], sz[k], hipMemcpyHostToDevice));
+            rep.dix.genome = reinterpret_cast<const abm::u64 *>(base + offs[0]);
+            rep.dix.counter = reinterpret_cast<const abm::u32 *>(base + offs[1]);
+            rep.dix.counter_t = reinterpret_cast<const abm::u32 *>(base + offs[2]);
+            rep.dix.counter_a = reinterpret_cast<const abm::u32 *>(base + offs[3]);
+            rep.dix.index = reinterpret_cast<const abm::u32 *>(base + offs[4]);
+            rep.dix.index_t = reinterpret_cast<const abm::u32 *>(base + offs[5]);
+            rep.dix.index_a = reinterpret_cast<const abm::u32 *>(base + offs[6]);
+            rep.dix.max_candidates = h.max_candidates;
+          }
+          catch (...) { (void)hipFree(arena); throw; }
+          rep.arena = arena;
+        }
+        ++rep.refs;
+        c->holds_replica = true;
+        c->dix = rep.dix;
+      }
+      HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
       c->work.reserve(32);
       HIPCHK(hipMemset(c->work.p, 0, 32 * sizeof(unsigned long long)));
     }
@@ -385,7 +440,15 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
 void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->arena) (void)hipFree(c->arena);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->holds_replica && c->ix) {
+    std::lock_guard<std::mutex> lk(c->ix->mu);
+    auto it = c->ix->replicas.find(c->device);
+    if (it != c->ix->replicas.end() && --it->second.refs == 0) {
+      (void)hipFree(it->second.arena);
+      c->ix->replicas.erase(it);
+    }
+  }
   c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -495,6 +558,7 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     out_cig_off[0] = 0;
     if (n == 0) return;
     HIPCHK(hipSetDevice(ctx->device));
+    const hipStream_t st = ctx->stream;
     const uint64_t base = seq_off[0], bytes = seq_off[n] - base;
     uint32_t max_len = 0;
     std::vector<uint64_t> rel(n + 1);
@@ -506,29 +570,56 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     if (max_len > abm::kMaxReadLen)
       throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
                                   std::to_string(abm::kMaxReadLen));
-    ctx->blob.reserve(std::max<uint64_t>(bytes, 1));
-    ctx->off.reserve(n + 1);
-    ctx->res.reserve(n);
-    ctx->cig_n.reserve(n);
-    ctx->status.reserve(1);
-    if (bytes) HIPCHK(hipMemcpy(ctx->blob.p, seq_blob + base, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-
-    uint32_t stride = 16;
-    for (;;) {  // a CIGAR longer than the slot triggers one rerun with full-size slots
-      ctx->cig.reserve(n * stride);
-      HIPCHK(hipMemset(ctx->status.p, 0, 4));
-      se_device(ctx, mode, params, n, ctx->blob.p, ctx->off.p, max_len, reinterpret_cast<abm_hit *>(ctx->res.p),
-                ctx->cig.p, stride, ctx->cig_n.p, ctx->status.p, nullptr);
-      HIPCHK(hipDeviceSynchronize());
+    // one pass: upload, map, hits + compact CIGARs back
+    auto run = [&](uint64_t m, const char *blob, uint64_t nbytes, const uint64_t *offs, uint32_t stride) {
+      ctx->blob.reserve(std::max<uint64_t>(nbytes, 1));
+      ctx->off.reserve(m + 1);
+      ctx->res.reserve(m);
+      ctx->cig_n.reserve(m);
+      ctx->status.reserve(1);
+      ctx->cig.reserve(m * stride);
+      HostTrace t2;
+      if (nbytes) HIPCHK(hipMemcpyAsync(ctx->blob.p, blob, nbytes, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->off.p, offs, (m + 1) * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4, st));
+      if (t2.on) { HIPCHK(hipStreamSynchronize(st)); t2.mark("  H2D"); }
+      se_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, max_len, reinterpret_cast<abm_hit *>(ctx->res.p),
+                ctx->cig.p, stride, ctx->cig_n.p, ctx->status.p, st);
       uint32_t status = 0;
-      HIPCHK(hipMemcpy(&status, ctx->status.p, 4, hipMemcpyDeviceToHost));
-      if ((status & ABM_STATUS_CIGAR_OVERFLOW) && stride < max_len + 2) { stride = max_len + 2; continue; }
-      if (status) throw std::runtime_error("kernel reported status " + std::to_string(status));
-      break;
-    }
-    HIPCHK(hipMemcpy(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW))
+        throw std::runtime_error("kernel reported status " + std::to_string(status));
+      return status;
+    };
+    const uint32_t stride = 16;
+    HostTrace tr;
+    const uint32_t status = run(n, seq_blob + base, bytes, rel.data(), stride);
+    tr.mark("upload+map");
+    HIPCHK(hipMemcpyAsync(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
     fetch_cigars(ctx, ctx->res.p, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob, cig_capacity, out_cig_off);
+    tr.mark("hits+cigars back");
+    if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) return;
+    // The few reads whose CIGAR has more ops than the slot are mapped again (same hits, the
+    // mapping is deterministic) with full-size slots, and their ops written over the truncated ones.
+    const std::vector<uint64_t> again = long_cigars(out_cig_off, n, stride);
+    if (again.empty()) return;
+    std::string sub;
+    std::vector<uint64_t> sub_off(1, 0);
+    for (uint64_t r : again) { sub.append(seq_blob + seq_off[r], seq_off[r + 1] - seq_off[r]); sub_off.push_back(sub.size()); }
+    const uint32_t wide = max_len + 2;
+    const uint64_t m = again.size();
+    run(m, sub.data(), sub.size(), sub_off.data(), wide);
+    std::vector<uint32_t> slots(m * wide), counts(m);
+    HIPCHK(hipMemcpyAsync(slots.data(), ctx->cig.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(counts.data(), ctx->cig_n.p, m * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint64_t k = 0; k < m; ++k) {
+      const uint64_t r = again[k], have = out_cig_off[r + 1] - out_cig_off[r];
+      if (counts[k] != have || counts[k] > wide) throw std::runtime_error("CIGAR rerun disagrees with the first pass");
+      std::memcpy(out_cig_blob + out_cig_off[r], slots.data() + k * wide, have * 4ull);
+    }
+    tr.mark("long-cigar rerun");
   });
 }
 
@@ -558,6 +649,7 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     out_cig_off1[0] = out_cig_off2[0] = 0;
     if (n == 0) return;
     HIPCHK(hipSetDevice(ctx->device));
+    const hipStream_t st = ctx->stream;
     uint32_t max_len = 0;
     std::vector<uint64_t> rel1(n + 1), rel2(n + 1);
     for (uint64_t i = 0; i <= n; ++i) { rel1[i] = seq_off1[i] - seq_off1[0]; rel2[i] = seq_off2[i] - seq_off2[0]; }
@@ -569,44 +661,80 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     if (max_len > abm::kMaxReadLen)
       throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
                                   std::to_string(abm::kMaxReadLen));
-    const uint64_t bytes1 = rel1[n], bytes2 = rel2[n];
-    ctx->blob.reserve(std::max<uint64_t>(bytes1, 1));
-    ctx->blob2.reserve(std::max<uint64_t>(bytes2, 1));
-    ctx->off.reserve(n + 1);
-    ctx->off2.reserve(n + 1);
-    ctx->pe_out.reserve(n * 5);  // 20 B pairs + 8 B + 8 B, in units of 8 B Hit
-    ctx->cig_n.reserve(n);
-    ctx->cig_n2h.reserve(n);
-    ctx->status.reserve(1);
-    if (bytes1) HIPCHK(hipMemcpy(ctx->blob.p, seq_blob1 + seq_off1[0], bytes1, hipMemcpyHostToDevice));
-    if (bytes2) HIPCHK(hipMemcpy(ctx->blob2.p, seq_blob2 + seq_off2[0], bytes2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->off.p, rel1.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->off2.p, rel2.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    char *outb = reinterpret_cast<char *>(ctx->pe_out.p);
-    abm_pair *d_pair = reinterpret_cast<abm_pair *>(outb);
-    abm_hit *d_se1 = reinterpret_cast<abm_hit *>(outb + n * 20 + (8 - (n * 20) % 8) % 8);
-    abm_hit *d_se2 = d_se1 + n;
-    uint32_t stride = 16;
-    for (;;) {
-      ctx->cig.reserve(n * stride);
-      ctx->cig2h.reserve(n * stride);
-      HIPCHK(hipMemset(ctx->status.p, 0, 4));
-      HIPCHK(hipMemset(ctx->cig_n.p, 0, n * 4));
-      HIPCHK(hipMemset(ctx->cig_n2h.p, 0, n * 4));
-      pe_device(ctx, mode, params, n, ctx->blob.p, ctx->off.p, ctx->blob2.p, ctx->off2.p, max_len, d_pair, d_se1,
-                d_se2, ctx->cig.p, ctx->cig2h.p, stride, ctx->cig_n.p, ctx->cig_n2h.p, ctx->status.p, nullptr);
-      HIPCHK(hipDeviceSynchronize());
+    abm_pair *d_pair = nullptr;
+    abm_hit *d_se1 = nullptr, *d_se2 = nullptr;
+    auto run = [&](uint64_t m, const char *b1, uint64_t nb1, const uint64_t *o1, const char *b2, uint64_t nb2,
+                   const uint64_t *o2, uint32_t stride) {
+      ctx->blob.reserve(std::max<uint64_t>(nb1, 1));
+      ctx->blob2.reserve(std::max<uint64_t>(nb2, 1));
+      ctx->off.reserve(m + 1);
+      ctx->off2.reserve(m + 1);
+      ctx->pe_out.reserve(m * 5);  // 20 B pairs + 8 B + 8 B, in units of 8 B Hit
+      ctx->cig_n.reserve(m);
+      ctx->cig_n2h.reserve(m);
+      ctx->status.reserve(1);
+      ctx->cig.reserve(m * stride);
+      ctx->cig2h.reserve(m * stride);
+      if (nb1) HIPCHK(hipMemcpyAsync(ctx->blob.p, b1, nb1, hipMemcpyHostToDevice, st));
+      if (nb2) HIPCHK(hipMemcpyAsync(ctx->blob2.p, b2, nb2, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->off.p, o1, (m + 1) * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->off2.p, o2, (m + 1) * 8, hipMemcpyHostToDevice, st));
+      char *outb = reinterpret_cast<char *>(ctx->pe_out.p);
+      d_pair = reinterpret_cast<abm_pair *>(outb);
+      d_se1 = reinterpret_cast<abm_hit *>(outb + m * 20 + (8 - (m * 20) % 8) % 8);
+      d_se2 = d_se1 + m;
+      HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4, st));
+      HIPCHK(hipMemsetAsync(ctx->cig_n.p, 0, m * 4, st));
+      HIPCHK(hipMemsetAsync(ctx->cig_n2h.p, 0, m * 4, st));
+      pe_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, ctx->blob2.p, ctx->off2.p, max_len, d_pair, d_se1,
+                d_se2, ctx->cig.p, ctx->cig2h.p, stride, ctx->cig_n.p, ctx->cig_n2h.p, ctx->status.p, st);
       uint32_t status = 0;
-      HIPCHK(hipMemcpy(&status, ctx->status.p, 4, hipMemcpyDeviceToHost));
-      if ((status & ABM_STATUS_CIGAR_OVERFLOW) && stride < max_len + 2) { stride = max_len + 2; continue; }
-      if (status) throw std::runtime_error("kernel reported status " + std::to_string(status));
-      break;
-    }
-    HIPCHK(hipMemcpy(out_pair, d_pair, n * sizeof(abm_pair), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_se1, d_se1, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_se2, d_se2, n * sizeof(abm_hit), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW))
+        throw std::runtime_error("kernel reported status " + std::to_string(status));
+      return status;
+    };
+    const uint32_t stride = 16;
+    const uint32_t status = run(n, seq_blob1 + seq_off1[0], rel1[n], rel1.data(), seq_blob2 + seq_off2[0], rel2[n],
+                                rel2.data(), stride);
+    HIPCHK(hipMemcpyAsync(out_pair, d_pair, n * sizeof(abm_pair), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_se1, d_se1, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_se2, d_se2, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
     fetch_cigars(ctx, nullptr, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob1, cig_capacity, out_cig_off1);
     fetch_cigars(ctx, nullptr, ctx->cig2h.p, ctx->cig_n2h.p, n, stride, out_cig_blob2, cig_capacity, out_cig_off2);
+    if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) return;
+    // pairs with a CIGAR longer than its slot: mapped again with full-size slots, ops patched in
+    std::vector<uint64_t> again = long_cigars(out_cig_off1, n, stride);
+    {
+      const std::vector<uint64_t> b = long_cigars(out_cig_off2, n, stride);
+      std::vector<uint64_t> u;
+      std::set_union(again.begin(), again.end(), b.begin(), b.end(), std::back_inserter(u));
+      again.swap(u);
+    }
+    if (again.empty()) return;
+    std::string s1, s2;
+    std::vector<uint64_t> so1(1, 0), so2(1, 0);
+    for (uint64_t r : again) {
+      s1.append(seq_blob1 + seq_off1[r], seq_off1[r + 1] - seq_off1[r]); so1.push_back(s1.size());
+      s2.append(seq_blob2 + seq_off2[r], seq_off2[r + 1] - seq_off2[r]); so2.push_back(s2.size());
+    }
+    const uint32_t wide = max_len + 2;
+    const uint64_t m = again.size();
+    run(m, s1.data(), s1.size(), so1.data(), s2.data(), s2.size(), so2.data(), wide);
+    std::vector<uint32_t> slots1(m * wide), slots2(m * wide), c1(m), c2(m);
+    HIPCHK(hipMemcpyAsync(slots1.data(), ctx->cig.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(slots2.data(), ctx->cig2h.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c1.data(), ctx->cig_n.p, m * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c2.data(), ctx->cig_n2h.p, m * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint64_t k = 0; k < m; ++k) {
+      const uint64_t r = again[k];
+      const uint64_t h1 = out_cig_off1[r + 1] - out_cig_off1[r], h2 = out_cig_off2[r + 1] - out_cig_off2[r];
+      if (c1[k] != h1 || c2[k] != h2 || h1 > wide || h2 > wide) throw std::runtime_error("CIGAR rerun disagrees with the first pass");
+      std::memcpy(out_cig_blob1 + out_cig_off1[r], slots1.data() + k * wide, h1 * 4ull);
+      std::memcpy(out_cig_blob2 + out_cig_off2[r], slots2.data() + k * wide, h2 * 4ull);
+    }
   });
 }
 

@@ -8,6 +8,8 @@
 // statistics are summed with one RCCL all-reduce at the end.
 #include "../../include/abismal_amd.h"
 
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -49,10 +51,46 @@ struct Stats {
 };
 struct Stats3 { Stats s[3]; };  // SE: s[0]; PE: pairs, read1, read2
 
+// A batch's FASTQ text: grown with realloc (large blocks are remapped, not copied, and never
+// zero-filled) and recycled through a small pool so that its pages stay faulted in.
+struct RawBuf {
+  char *p = nullptr;
+  size_t n = 0, cap = 0;
+  RawBuf() = default;
+  RawBuf(const RawBuf &) = delete;
+  RawBuf &operator=(const RawBuf &) = delete;
+  RawBuf(RawBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+  RawBuf &operator=(RawBuf &&o) noexcept { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); return *this; }
+  ~RawBuf() { std::free(p); }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    char *q = static_cast<char *>(std::realloc(p, want));
+    if (!q) throw std::bad_alloc();
+    p = q; cap = want;
+  }
+  void append(const char *src, size_t len) { reserve(n + len); std::memcpy(p + n, src, len); n += len; }
+};
+struct RawPool {
+  std::mutex mu;
+  std::vector<RawBuf> free_list;
+  RawBuf get() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_list.empty()) return RawBuf();
+    RawBuf b = std::move(free_list.back());
+    free_list.pop_back();
+    b.n = 0;
+    return b;
+  }
+  void put(RawBuf &&b) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_list.size() < 24) free_list.push_back(std::move(b));
+  }
+};
+
 struct Batch {
   uint64_t seq = 0;        // batch number, defines output order
   uint64_t first_line[2] = {0, 0};
-  std::string raw[2];      // the FASTQ text of this batch
+  RawBuf raw[2];           // the FASTQ text of this batch
   std::vector<std::string> names[2];
   std::string blob[2];
   std::vector<uint64_t> off[2];
@@ -62,61 +100,103 @@ struct Batch {
   std::vector<abm_pair> pairs;
   std::vector<uint32_t> cig[2];
   std::vector<uint64_t> cig_off[2];
-  std::string sam;
+  // formatted output: slices of the batch are formatted independently and written in order
+  std::vector<std::string> parts;
+  std::vector<Stats3> part_stats;
+  int parts_left = 0;
   Stats3 stats;
   size_t n() const { return names[0].size(); }
 };
 
+// advances over [p + from, p + len) counting newlines until `need` lines are complete; returns the
+// offset just past the last newline consumed (block counts vectorise; only the block in which the
+// target falls is walked line by line)
+size_t scan_lines(const char *p, size_t from, size_t len, uint64_t need, uint64_t &lines) {
+  size_t i = from, last = from;
+  while (i < len && lines < need) {
+    const size_t blk = std::min<size_t>(len - i, 8192);
+    uint32_t c = 0;
+    for (size_t k = 0; k < blk; ++k) c += (p[i + k] == '\n');
+    if (lines + c < need) {
+      if (c) last = static_cast<size_t>(static_cast<const char *>(memrchr(p + i, '\n', blk)) - p) + 1;
+      lines += c;
+      i += blk;
+      continue;
+    }
+    while (lines < need) {
+      const char *nl = static_cast<const char *>(std::memchr(p + i, '\n', len - i));
+      i = static_cast<size_t>(nl - p) + 1;
+      ++lines;
+    }
+    return i;
+  }
+  return last;
+}
+
 struct RawSplitter {
-  gzFile f = nullptr;  // zlib reads plain and gzip/bgzip-compressed FASTQ alike (bamxx::bgzf_file in the reference)
-  std::string path, carry;
+  gzFile f = nullptr;  // gzip/bgzip-compressed FASTQ goes through zlib (bamxx::bgzf_file in the reference)
+  int fd = -1;         // plain text is read directly
+  std::string path, carry;  // carry: text read past the end of the previous batch
   uint64_t line_no = 0;
   bool eof = false;
-  explicit RawSplitter(const std::string &p) : f(gzopen(p.c_str(), "rb")), path(p) {
-    if (!f) throw std::runtime_error("cannot open reads file: " + p);
-    gzbuffer(f, 1u << 20);
+  explicit RawSplitter(const std::string &p) : path(p) {
+    fd = ::open(p.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open reads file: " + p);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+      ::close(fd);
+      fd = -1;
+      f = gzopen(p.c_str(), "rb");
+      if (!f) throw std::runtime_error("cannot open reads file: " + p);
+      gzbuffer(f, 1u << 20);
+    }
   }
-  ~RawSplitter() { if (f) gzclose(f); }
+  ~RawSplitter() { if (f) gzclose(f); if (fd >= 0) ::close(fd); }
+  size_t fill(char *dst, size_t want) {
+    size_t have = 0;
+    while (have < want) {
+      long got;
+      if (f) got = gzread(f, dst + have, static_cast<unsigned>(std::min<size_t>(want - have, 1u << 30)));
+      else got = static_cast<long>(::read(fd, dst + have, want - have));
+      if (got < 0) throw std::runtime_error("error reading " + path);
+      if (got == 0) break;
+      have += static_cast<size_t>(got);
+    }
+    return have;
+  }
   // up to `want` records (4 lines each) of text; returns the number of complete lines delivered
-  uint64_t next(size_t want, std::string &out, uint64_t &first_line) {
+  uint64_t next(size_t want, RawBuf &out, uint64_t &first_line) {
     first_line = line_no;
-    out.clear();
-    out.swap(carry);
+    out.n = 0;
+    out.append(carry.data(), carry.size());
+    carry.clear();
     const uint64_t need = 4 * static_cast<uint64_t>(want);
     uint64_t lines = 0;
-    size_t scanned = 0;
-    auto scan = [&]() {
-      while (lines < need) {
-        const char *nl = static_cast<const char *>(std::memchr(out.data() + scanned, '\n', out.size() - scanned));
-        if (!nl) { scanned = out.size(); return; }
-        scanned = static_cast<size_t>(nl - out.data()) + 1;
-        ++lines;
-      }
-    };
-    scan();
+    size_t scanned = scan_lines(out.p, 0, out.n, need, lines);  // meaningful once lines == need
     while (lines < need && !eof) {
-      const size_t old = out.size(), chunk = 32u << 20;
-      out.resize(old + chunk);
-      const int got_i = gzread(f, &out[old], static_cast<unsigned>(chunk));
-      if (got_i < 0) throw std::runtime_error("error reading " + path);
-      const size_t got = static_cast<size_t>(got_i);
-      out.resize(old + got);
+      const size_t old = out.n, chunk = 32u << 20;
+      out.reserve(std::max(old + chunk, last_size + chunk));
+      const size_t got = fill(out.p + old, chunk);
+      out.n = old + got;
       if (got < chunk) eof = true;
-      scan();
+      scanned = scan_lines(out.p, old, out.n, need, lines);
     }
-    if (lines == need) { carry.assign(out, scanned, std::string::npos); out.resize(scanned); }
-    else if (scanned < out.size()) ++lines;  // a last line without a newline still counts (getline semantics)
+    if (lines == need) { carry.assign(out.p + scanned, out.n - scanned); out.n = scanned; }
+    else if (out.n && out.p[out.n - 1] != '\n') ++lines;  // a last line without a newline still counts (getline semantics)
+    last_size = out.n;
     line_no += lines;
     return lines;
   }
+  size_t last_size = 0;
   bool exhausted() const { return eof && carry.empty(); }
 };
 
-void parse_raw(const std::string &raw, uint64_t first_line, const std::string &path, std::vector<std::string> &names,
+void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, std::vector<std::string> &names,
                std::string &blob, std::vector<uint64_t> &off) {
   names.clear(); blob.clear(); off.assign(1, 0);
-  blob.reserve(raw.size() / 2);
-  const char *p = raw.data(), *end = p + raw.size();
+  blob.reserve(raw.n / 2);
+  const char *p = raw.p, *end = p + raw.n;
   std::string line;
   for (uint64_t k = 0; p < end; ++k) {
     const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
@@ -287,6 +367,7 @@ void put_bam_record(std::string &o, const Record &r) {
   o[start] = static_cast<char>(bs); o[start + 1] = static_cast<char>(bs >> 8); o[start + 2] = static_cast<char>(bs >> 16); o[start + 3] = static_cast<char>(bs >> 24);
 }
 // raw bytes -> BGZF blocks (each an independent gzip member with the BC extra field)
+int g_bgzf_level = 1;  // deflate level of BAM output (-z): decoded content is the same at every level
 void bgzf_compress(const std::string &raw, std::string &out) {
   constexpr size_t kBlock = 0xff00;
   std::vector<unsigned char> buf(compressBound(kBlock) + 64);
@@ -294,7 +375,7 @@ void bgzf_compress(const std::string &raw, std::string &out) {
     const size_t len = std::min(kBlock, raw.size() - at);
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    if (deflateInit2(&zs, g_bgzf_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
     zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(raw.data() + at));
     zs.avail_in = static_cast<uInt>(len);
     zs.next_out = buf.data();
@@ -397,9 +478,10 @@ struct Options {
   std::string index, genome, out, stats;
   bool bam = false, json = false, ambig = false, pbat = false, rpbat = false, arich = false, verbose = false;
   uint32_t max_candidates = 0, min_frag = 32, max_frag = 3000;
-  uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));  // host parse/format threads
+  uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));  // host parse/format threads
   int gpus = 0;
   size_t batch = 1u << 20;
+  int mappers = 2;  // mapper threads (contexts) per GPU
   double max_distance = 0.1;
   std::vector<std::string> reads;
 };
@@ -429,6 +511,8 @@ Options parse_map(int argc, char **argv) {
     else if (k == "v" || k == "verbose") o.verbose = true;
     else if (k == "gpus") o.gpus = std::stoi(need(i));
     else if (k == "batch") o.batch = std::stoul(need(i));
+    else if (k == "mappers") o.mappers = std::stoi(need(i));
+    else if (k == "z" || k == "bam-level") g_bgzf_level = std::max(0, std::min(9, std::stoi(need(i))));
     else throw std::runtime_error("unknown option " + a);
   }
   return o;
@@ -467,15 +551,22 @@ int cmd_map(int argc, char **argv) {
   for (uint32_t i = 0; i < abm_index_n_chroms(ix); ++i) ch.names.push_back(abm_index_chrom_name(ix, i));
   ch.starts.assign(abm_index_chrom_starts(ix), abm_index_chrom_starts(ix) + ch.names.size() + 1);
 
-  // one context (= one replica of the index in HBM) per GPU
+  // one replica of the index in each GPU's HBM, shared by that GPU's contexts; a context is one
+  // mapper thread's workspaces + stream, and two per GPU keep the device busy while the other
+  // thread's batch is in transit over PCIe
   int n_gpus = opt.gpus;
+  const int per_gpu = std::max(1, opt.mappers);
   std::vector<abm_ctx *> ctxs;
   for (int d = 0; n_gpus <= 0 || d < n_gpus; ++d) {
     abm_ctx *c = nullptr;
     if (abm_ctx_create(ix, d, &c) != 0) { if (n_gpus <= 0 && d > 0) break; die_abm("creating GPU context"); }
     ctxs.push_back(c);
+    for (int k = 1; k < per_gpu; ++k) {
+      if (abm_ctx_create(ix, d, &c) != 0) die_abm("creating GPU context");
+      ctxs.push_back(c);
+    }
   }
-  n_gpus = static_cast<int>(ctxs.size());
+  n_gpus = static_cast<int>(ctxs.size()) / per_gpu;
 
   std::ofstream out(opt.out, std::ios::binary);
   if (!out) throw std::runtime_error("failed to open output file: " + opt.out);
@@ -503,23 +594,31 @@ int cmd_map(int argc, char **argv) {
   // Staged pipeline, every stage order-agnostic except the writer:
   //   splitter (1 thread)   cuts the FASTQ file(s) into raw batches of whole records
   //   parsers  (-t threads) apply ReadLoader's rules and lay reads out for the C ABI
-  //   mappers  (1 per GPU)  abm_map_{se,pe}_batch
+  //   mappers  (-mappers per GPU) abm_map_{se,pe}_batch
   //   formatters (-t)       SAM text + the batch's statistics
   //   writer (this thread)  emits batches in input order
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::unique_ptr<Batch>> q_parse, q_map, q_format;
+  struct Slice { Batch *b; size_t lo, hi; int part; };
+  std::deque<std::unique_ptr<Batch>> q_parse, q_map;
+  std::deque<Slice> q_format;
+  std::map<uint64_t, std::unique_ptr<Batch>> formatting;  // batches whose slices are being formatted
+  const size_t slice_reads = 1u << 16;
   std::map<uint64_t, std::unique_ptr<Batch>> done;
   uint64_t n_batches = 0, next_to_write = 0;
   size_t in_flight = 0;
   bool split_done = false;
   int parsers_live = 0, mappers_live = 0, formatters_live = 0;
   std::exception_ptr failure;
-  const size_t max_in_flight = static_cast<size_t>(4 * n_gpus + 8);
+  const size_t max_in_flight = static_cast<size_t>(4 * n_gpus * per_gpu + 8);
   const unsigned n_host = std::max(1u, opt.threads);
   std::vector<Stats3> gpu_stats(n_gpus);
   const auto t_start = std::chrono::steady_clock::now();
 
+  double busy_split = 0, busy_parse = 0, busy_map = 0, busy_format = 0, busy_write = 0;  // seconds, summed over threads
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  RawPool raw_pool;
   auto fail = [&]() {
     std::lock_guard<std::mutex> lk(mu);
     if (!failure) failure = std::current_exception();
@@ -538,6 +637,9 @@ int cmd_map(int argc, char **argv) {
           if (failure) break;
         }
         std::unique_ptr<Batch> b(new Batch);
+        const auto t0 = now();
+        b->raw[0] = raw_pool.get();
+        if (paired) b->raw[1] = raw_pool.get();
         const uint64_t l1 = s1.next(opt.batch, b->raw[0], b->first_line[0]);
         uint64_t l2 = 0;
         if (paired) l2 = s2->next(opt.batch, b->raw[1], b->first_line[1]);
@@ -546,6 +648,7 @@ int cmd_map(int argc, char **argv) {
         {
           std::lock_guard<std::mutex> lk(mu);
           b->seq = n_batches++;
+          busy_split += since(t0);
           ++in_flight;
           q_parse.push_back(std::move(b));
         }
@@ -570,9 +673,10 @@ int cmd_map(int argc, char **argv) {
           b = std::move(q_parse.front());
           q_parse.pop_front();
         }
+        const auto t0 = now();
         for (int e = 0; e < (paired ? 2 : 1); ++e) {
           parse_raw(b->raw[e], b->first_line[e], opt.reads[e], b->names[e], b->blob[e], b->off[e]);
-          std::string().swap(b->raw[e]);
+          raw_pool.put(std::move(b->raw[e]));
         }
         if (paired && b->names[0].size() != b->names[1].size())
           throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(b->names[0].size()) +
@@ -580,6 +684,7 @@ int cmd_map(int argc, char **argv) {
                                    ". Are you sure your paired-end inputs have the same number of reads?");
         {
           std::lock_guard<std::mutex> lk(mu);
+          busy_parse += since(t0);
           q_map.push_back(std::move(b));
         }
         cv.notify_all();
@@ -591,7 +696,9 @@ int cmd_map(int argc, char **argv) {
     cv.notify_all();
   };
 
-  auto mapper = [&](int g) {
+  auto mapper = [&](int slot) {
+    const int g = slot / per_gpu;
+    abm_ctx *ctx = ctxs[slot];
     try {
       for (;;) {
         std::unique_ptr<Batch> b;
@@ -604,24 +711,42 @@ int cmd_map(int argc, char **argv) {
         }
         b->gpu = g;
         const size_t n = b->n();
+        const auto t0 = now();
         if (n) {
-          const uint64_t cap = std::max<uint64_t>(1, std::max(b->blob[0].size(), b->blob[1].size()) + 2 * n);
-          if (!paired) {
-            b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
-            if (abm_map_se_batch(ctxs[g], se_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->se[0].data(),
-                                 b->cig[0].data(), cap, b->cig_off[0].data()) != 0) die_abm("mapping");
-          }
-          else {
-            b->pairs.resize(n); b->se[0].resize(n); b->se[1].resize(n);
-            for (int e = 0; e < 2; ++e) { b->cig[e].resize(cap); b->cig_off[e].resize(n + 1); }
-            if (abm_map_pe_batch(ctxs[g], pe_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->blob[1].data(),
-                                 b->off[1].data(), b->pairs.data(), b->se[0].data(), b->se[1].data(), b->cig[0].data(),
-                                 b->cig_off[0].data(), b->cig[1].data(), b->cig_off[1].data(), cap) != 0) die_abm("mapping");
+          // a few CIGAR ops per read are typical; the worst case (read length + 2 each) is only
+          // allocated if the first size turns out too small
+          const uint64_t worst = std::max<uint64_t>(1, std::max(b->blob[0].size(), b->blob[1].size()) + 2 * n);
+          uint64_t cap = std::min<uint64_t>(worst, 4 * n + 1024);
+          for (;;) {
+            int rc;
+            if (!paired) {
+              b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
+              rc = abm_map_se_batch(ctx, se_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->se[0].data(),
+                                    b->cig[0].data(), cap, b->cig_off[0].data());
+            }
+            else {
+              b->pairs.resize(n); b->se[0].resize(n); b->se[1].resize(n);
+              for (int e = 0; e < 2; ++e) { b->cig[e].resize(cap); b->cig_off[e].resize(n + 1); }
+              rc = abm_map_pe_batch(ctx, pe_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->blob[1].data(),
+                                    b->off[1].data(), b->pairs.data(), b->se[0].data(), b->se[1].data(), b->cig[0].data(),
+                                    b->cig_off[0].data(), b->cig[1].data(), b->cig_off[1].data(), cap);
+            }
+            if (rc == 0) break;
+            if (rc == ABM_ERR_CAPACITY && cap < worst) { cap = worst; continue; }
+            die_abm("mapping");
           }
         }
         {
+          const int n_parts = static_cast<int>(std::max<size_t>(1, (n + slice_reads - 1) / slice_reads));
+          b->parts.resize(n_parts);
+          b->part_stats.resize(n_parts);
+          b->parts_left = n_parts;
           std::lock_guard<std::mutex> lk(mu);
-          q_format.push_back(std::move(b));
+          busy_map += since(t0);
+          Batch *raw = b.get();
+          formatting[raw->seq] = std::move(b);
+          for (int k = 0; k < n_parts; ++k)
+            q_format.push_back(Slice{raw, k * slice_reads, std::min(n, (k + 1) * slice_reads), k});
         }
         cv.notify_all();
       }
@@ -632,24 +757,22 @@ int cmd_map(int argc, char **argv) {
     cv.notify_all();
   };
 
-  auto format_batch = [&](Batch &bt) {
+  auto format_slice = [&](Batch &bt, size_t lo, size_t hi, std::string &sam, Stats3 &st) {
     Batch *b = &bt;
     t_bam = opt.bam;
-    const size_t n = b->n();
-    Stats3 &st = b->stats;
-    b->sam.reserve(n * (paired ? 2 : 1) * 320);
+    sam.reserve((hi - lo) * (paired ? 2 : 1) * 320);
     if (!paired) {
-      for (size_t i = 0; i < n; ++i) {
+      for (size_t i = lo; i < hi; ++i) {
         abm_hit h = b->se[0][i];
         const size_t len = b->off[0][i + 1] - b->off[0][i];
         const uint32_t *cg = b->cig[0].data() + b->cig_off[0][i];
         const size_t ncg = b->cig_off[0][i + 1] - b->cig_off[0][i];
-        if (len && emit_se(b->sam, opt.ambig, h, ch, b->names[0][i], b->blob[0].data() + b->off[0][i], len, cg, ncg) == UNMAPPED) h.pos = 0;
+        if (len && emit_se(sam, opt.ambig, h, ch, b->names[0][i], b->blob[0].data() + b->off[0][i], len, cg, ncg) == UNMAPPED) h.pos = 0;
         st.s[0].tally(len == 0, h, opt.ambig, ref_len(cg, ncg));
       }
       return;
     }
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = lo; i < hi; ++i) {
       abm_pair p = b->pairs[i];
       abm_hit h1 = b->se[0][i], h2 = b->se[1][i];
       const char *s1 = b->blob[0].data() + b->off[0][i], *s2 = b->blob[1].data() + b->off[1][i];
@@ -657,13 +780,13 @@ int cmd_map(int argc, char **argv) {
       const uint32_t *c1 = b->cig[0].data() + b->cig_off[0][i], *c2 = b->cig[1].data() + b->cig_off[1][i];
       const size_t nc1 = b->cig_off[0][i + 1] - b->cig_off[0][i], nc2 = b->cig_off[1][i + 1] - b->cig_off[1][i];
       // select_output, src/abismal.cpp:1073-1088
-      const Outcome po = emit_pe(b->sam, opt.ambig, p, ch, b->names[0][i], b->names[1][i], s1, l1, s2, l2, c1, nc1, c2, nc2);
+      const Outcome po = emit_pe(sam, opt.ambig, p, ch, b->names[0][i], b->names[1][i], s1, l1, s2, l2, c1, nc1, c2, nc2);
       const bool report = p.r1.pos != 0 && (opt.ambig || !(p.r1.flags & 0x100));
       bool pair_ok = report;
       if (!report || po == UNMAPPED) {
         if (po == UNMAPPED) { p.r1.pos = 0; p.r2.pos = 0; pair_ok = false; }
-        if (emit_se(b->sam, opt.ambig, h1, ch, b->names[0][i], s1, l1, c1, nc1) == UNMAPPED) h1.pos = 0;
-        if (emit_se(b->sam, opt.ambig, h2, ch, b->names[1][i], s2, l2, c2, nc2) == UNMAPPED) h2.pos = 0;
+        if (emit_se(sam, opt.ambig, h1, ch, b->names[0][i], s1, l1, c1, nc1) == UNMAPPED) h1.pos = 0;
+        if (emit_se(sam, opt.ambig, h2, ch, b->names[1][i], s2, l2, c2, nc2) == UNMAPPED) h2.pos = 0;
       }
       // paired_end_mapping_statistics::update, :1039-1057
       Stats &ps = st.s[0];
@@ -681,19 +804,26 @@ int cmd_map(int argc, char **argv) {
   auto formatter = [&]() {
     try {
       for (;;) {
-        std::unique_ptr<Batch> b;
+        Slice sl;
         {
           std::unique_lock<std::mutex> lk(mu);
           cv.wait(lk, [&] { return failure || !q_format.empty() || mappers_live == 0; });
           if (failure || q_format.empty()) break;
-          b = std::move(q_format.front());
+          sl = q_format.front();
           q_format.pop_front();
         }
-        format_batch(*b);
-        if (opt.bam) { std::string z; bgzf_compress(b->sam, z); b->sam.swap(z); }
+        const auto t0 = now();
+        std::string &text = sl.b->parts[sl.part];
+        format_slice(*sl.b, sl.lo, sl.hi, text, sl.b->part_stats[sl.part]);
+        if (opt.bam) { std::string z; bgzf_compress(text, z); text.swap(z); }
         {
           std::lock_guard<std::mutex> lk(mu);
-          done[b->seq] = std::move(b);
+          busy_format += since(t0);
+          if (--sl.b->parts_left == 0) {
+            auto it = formatting.find(sl.b->seq);
+            done[sl.b->seq] = std::move(it->second);
+            formatting.erase(it);
+          }
         }
         cv.notify_all();
       }
@@ -706,11 +836,11 @@ int cmd_map(int argc, char **argv) {
 
   std::vector<std::thread> threads;
   parsers_live = static_cast<int>(n_host);
-  mappers_live = n_gpus;
+  mappers_live = n_gpus * per_gpu;
   formatters_live = static_cast<int>(n_host);
   threads.emplace_back(splitter);
   for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(parser);
-  for (int g = 0; g < n_gpus; ++g) threads.emplace_back(mapper, g);
+  for (int slot = 0; slot < n_gpus * per_gpu; ++slot) threads.emplace_back(mapper, slot);
   for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(formatter);
   uint64_t total_records = 0;
   {  // writer: batches leave in input order
@@ -728,11 +858,14 @@ int cmd_map(int argc, char **argv) {
       ++next_to_write;
       --in_flight;
       lk.unlock();
-      out.write(b->sam.data(), static_cast<std::streamsize>(b->sam.size()));
+      const auto t0 = now();
+      for (const std::string &part : b->parts) out.write(part.data(), static_cast<std::streamsize>(part.size()));
       total_records += b->n();
-      for (int k = 0; k < 3; ++k)
-        for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += b->stats.s[k].v[j];
+      for (const Stats3 &ps : b->part_stats)
+        for (int k = 0; k < 3; ++k)
+          for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += ps.s[k].v[j];
       b.reset();
+      busy_write += since(t0);
       cv.notify_all();
       lk.lock();
     }
@@ -751,7 +884,9 @@ int cmd_map(int argc, char **argv) {
   std::vector<uint64_t *> ptrs;
   for (auto &s : gpu_stats) ptrs.push_back(&s.s[0].v[0]);
   static_assert(sizeof(Stats3) == 18 * sizeof(uint64_t), "18 counters");
-  if (abm_stats_allreduce(ctxs.data(), n_gpus, ptrs.data()) != 0) die_abm("stats all-reduce");
+  std::vector<abm_ctx *> primary;
+  for (int g = 0; g < n_gpus; ++g) primary.push_back(ctxs[static_cast<size_t>(g) * per_gpu]);
+  if (abm_stats_allreduce(primary.data(), n_gpus, ptrs.data()) != 0) die_abm("stats all-reduce");
   const Stats3 &tot = gpu_stats[0];
   if (!opt.stats.empty()) {
     std::ofstream so(opt.stats);
@@ -765,7 +900,10 @@ int cmd_map(int argc, char **argv) {
   }
   if (opt.verbose)
     std::cerr << "[abismal-amd] " << total_records << (paired ? " pairs" : " reads") << " on " << n_gpus << " GPU(s) in "
-              << secs << " s (" << (paired ? 2 : 1) * total_records / secs << " reads/s incl. host I/O)\n";
+              << secs << " s (" << (paired ? 2 : 1) * total_records / secs << " reads/s incl. host I/O)\n"
+              << "[abismal-amd] busy seconds: split " << busy_split << ", parse " << busy_parse << " (" << n_host
+              << " threads), map " << busy_map << " (" << n_gpus * per_gpu << " threads), format " << busy_format << " ("
+              << n_host << " threads), write " << busy_write << "\n";
   for (abm_ctx *c : ctxs) abm_ctx_destroy(c);
   abm_index_close(ix);
   return EXIT_SUCCESS;

@@ -268,7 +268,8 @@ hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32
 __global__ __launch_bounds__(256) void cigar_counts_kernel(const Hit *__restrict__ res, const u32 *__restrict__ cig_n,
                                                            u64 n, u32 stride, unsigned long long *__restrict__ cnt) {
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r < n) cnt[r] = (res == nullptr || res[r].pos != 0) ? min(cig_n[r], stride) : 0u;
+  // the true op count even where the slot held fewer: the caller patches those reads in afterwards
+  if (r < n) cnt[r] = (res == nullptr || res[r].pos != 0) ? cig_n[r] : 0u;
   if (r == n) cnt[r] = 0;
 }
 __global__ __launch_bounds__(256) void cigar_gather_kernel(const u32 *__restrict__ cig, u32 stride,
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void cigar_gather_kernel(const u32 *__restrict
                                                            u32 *__restrict__ blob) {
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  const unsigned long long a = off[r], b = off[r + 1];
+  const unsigned long long a = off[r], b = min(off[r + 1], off[r] + stride);
   for (unsigned long long k = a; k < b; ++k) blob[k] = cig[r * stride + (k - a)];
 }
 

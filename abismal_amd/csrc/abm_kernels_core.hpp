@@ -567,6 +567,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   __syncthreads();
   // final order: [head clip] reversed(ops) [tail clip]
   const u32 body = min(n, cig_stride);
+  const u32 full = n + (clip_head > 0) + (clip_tail > 0);  // the CIGAR's true op count
   u32 total = body + (clip_head > 0) + (clip_tail > 0);
   if (n > cig_stride || total > cig_stride) { overflow = true; total = min(total, cig_stride); }
   for (u32 k = lane; k < total; k += 64) {
@@ -577,7 +578,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
     else v = (static_cast<u32>(clip_tail) << 4) | 4u;
     cig_out[k] = v;
   }
-  n_ops = total;
+  n_ops = full;  // > cig_stride: the slot is incomplete and the caller maps this read again with a wider slot
   aln_len = static_cast<u32>(L - clip_tail - clip_head);
   t_pos = t_pos - static_cast<u32>((bw - 1) / 2) + static_cast<u32>(r);
 }

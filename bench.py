@@ -562,7 +562,7 @@ def main():
         "kernel_status": st_host,
         "kernel_status_note": ("bit 0 = some CIGAR needed more than the %d-op device slot (hits stay exact; the host entry "
                                "point reruns such batches with full-size slots); reads affected: %d" %
-                               (stride, int((cig_n >= stride).sum().item()))) if st_host else None,
+                               (stride, int((cig_n > stride).sum().item()))) if st_host else None,
         "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
     }
     print(json.dumps(line), flush=True)

@@ -73,7 +73,11 @@ void abm_ctx_destroy(abm_ctx *ctx);
  * N-trimmed; empty = skipped), concatenated in seq_blob with n+1 offsets.
  * out_res[i] equals bests[i] and the CIGAR equals r[i].cig just before
  * format_se; CIGAR ops are BAM-encoded (len<<4|op) in out_cig_blob with n+1
- * offsets in out_cig_off (reads without a hit get an empty CIGAR). */
+ * offsets in out_cig_off (reads without a hit get an empty CIGAR).
+ * cig_capacity is out_cig_blob's size in ops: a few ops per read are typical,
+ * at most read length + 2; ABM_ERR_CAPACITY (-2) is returned if it does not
+ * suffice, and the call can be repeated with a larger buffer. */
+#define ABM_ERR_CAPACITY (-2)
 int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                      const char *seq_blob, const uint64_t *seq_off, abm_hit *out_res,
                      uint32_t *out_cig_blob, uint64_t cig_capacity, uint64_t *out_cig_off);
@@ -81,7 +85,10 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
 /* Same computation with every buffer already resident in HBM (d_* are device
  * pointers), enqueued on `stream` (a hipStream_t; NULL = default stream) and
  * not synchronised.  CIGARs land in fixed slots of cig_stride ops per read,
- * their lengths in d_cig_n.  d_status (one uint32) is OR-ed with
+ * their op counts in d_cig_n.  A count above cig_stride (ABM_STATUS_CIGAR_OVERFLOW
+ * is then set) means the slot is incomplete: the hit itself is exact, and mapping
+ * that read again with cig_stride >= max_len + 2 yields its CIGAR, which is what
+ * the host-buffer entry points do.  d_status (one uint32) is OR-ed with
  * ABM_STATUS_* bits. max_len = longest read in the batch. */
 int abm_map_se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                       const char *d_seq_blob, const uint64_t *d_seq_off, uint32_t max_len,

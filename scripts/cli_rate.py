@@ -24,10 +24,10 @@ with open(fq, "wb") as f:
 print("fastq written", time.time() - t, "s", os.path.getsize(fq) / 1e6, "MB")
 del blob
 torch.cuda.empty_cache()
-for extra, outp in (([], f"{wd}/out.sam"), (["-batch", "262144"], f"{wd}/out.sam"), (["-batch", "262144"], "/dev/null"), (["-batch", "262144", "-t", "64"], "/dev/null")):
+for extra, outp in (([], f"{wd}/out.sam"), (["-mappers", "3"], f"{wd}/out.sam"), (["-batch", "524288", "-mappers", "3"], f"{wd}/out.sam"), (["-mappers", "1"], f"{wd}/out.sam"), (["-B"], f"{wd}/out.bam")):
     t = time.time()
     r = subprocess.run(["abismal_amd/abismal-amd", "map", "-v", "-i", idx, "-o", outp, "-s", f"{wd}/out.stats"] + extra + [fq],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     dt = time.time() - t
-    print(extra, outp, "rc", r.returncode, f"wall {dt:.2f}s -> {n/dt/1e6:.2f} M reads/s incl. index load;", r.stdout.strip().split("\n")[-1][:200])
+    print(extra, outp, "rc", r.returncode, f"wall {dt:.2f}s -> {n/dt/1e6:.2f} M reads/s incl. index load;", " | ".join(r.stdout.strip().split("\n")[-2:])[:400])
 print(open(f"{wd}/out.stats").read()[:300])

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -46,7 +47,10 @@ struct HostTrace {
   void mark(const char *what) {
     if (!on) return;
     const auto now = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[abm host] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    static const auto t_proc = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[abm host] t=%9.1f ms thr %04x %-22s %8.2f ms\n", std::chrono::duration<double, std::milli>(now - t_proc).count(),
+                 static_cast<unsigned>(std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xFFFF), what,
+                 std::chrono::duration<double, std::milli>(now - t).count());
     t = now;
   }
 };
@@ -71,6 +75,10 @@ struct DeviceReplica {
   void *arena = nullptr;  // one allocation holding the seven index arrays
   abm::DevIndex dix{};
   int refs = 0;
+  // The single-end host-buffer entry points of the contexts on one device take turns for the mapping
+  // kernel (their transfers overlap freely): the kernels are bound by random line fetches, and two of them
+  // resident together only evict each other's lines (see kSeWavesPerCu).
+  std::mutex kernel_turn;
 };
 
 struct abm_index {
@@ -85,6 +93,9 @@ struct abm_ctx {
   abm::DevIndex dix{};
   bool holds_replica = false;
   hipStream_t stream = nullptr;  // the host-buffer entry points run on the context's own stream
+  std::mutex *kernel_turn = nullptr;
+  abm::u32 *drained = nullptr;   // pinned, device-mapped: the mapping kernel has handed out its last read
+  bool signal_drained = false;  // set by the host-buffer entry point around its launch
   // per-batch workspaces (grow-only; sized by the largest batch seen)
   DevBuf<abm::u64> packed, packed2;
   DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2, heap2;
@@ -192,6 +203,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
   a.next_read = counter;
   a.read_cycles = ctx->phase_stamps ? ctx->read_cycles : nullptr;
+  a.drained = ctx->signal_drained ? ctx->drained : nullptr;
   // the occupancy query costs milliseconds: remember it per launch shape
   const uint64_t shape = (static_cast<uint64_t>(W) << 48) ^ (static_cast<uint64_t>(cig_stride) << 24) ^ (static_cast<uint64_t>(eff_len) << 8) ^
                          static_cast<uint64_t>(size_frac * 255.0);
@@ -427,8 +439,11 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
         ++rep.refs;
         c->holds_replica = true;
         c->dix = rep.dix;
+        c->kernel_turn = &rep.kernel_turn;
       }
       HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->drained), sizeof(abm::u32), hipHostMallocMapped | hipHostMallocCoherent));
+      *c->drained = 0;
       c->work.reserve(32);
       HIPCHK(hipMemset(c->work.p, 0, 32 * sizeof(unsigned long long)));
     }
@@ -441,6 +456,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->drained) (void)hipHostFree(c->drained);
   if (c->holds_replica && c->ix) {
     std::lock_guard<std::mutex> lk(c->ix->mu);
     auto it = c->ix->replicas.find(c->device);
@@ -571,7 +587,7 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
                                   std::to_string(abm::kMaxReadLen));
     // one pass: upload, map, hits + compact CIGARs back
-    auto run = [&](uint64_t m, const char *blob, uint64_t nbytes, const uint64_t *offs, uint32_t stride) {
+    auto run = [&](uint64_t m, const char *blob, uint64_t nbytes, const uint64_t *offs, uint32_t stride, bool take_turn) {
       ctx->blob.reserve(std::max<uint64_t>(nbytes, 1));
       ctx->off.reserve(m + 1);
       ctx->res.reserve(m);
@@ -582,19 +598,34 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       if (nbytes) HIPCHK(hipMemcpyAsync(ctx->blob.p, blob, nbytes, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(ctx->off.p, offs, (m + 1) * 8, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4, st));
-      if (t2.on) { HIPCHK(hipStreamSynchronize(st)); t2.mark("  H2D"); }
-      se_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, max_len, reinterpret_cast<abm_hit *>(ctx->res.p),
-                ctx->cig.p, stride, ctx->cig_n.p, ctx->status.p, st);
-      uint32_t status = 0;
-      HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
+      t2.mark("  H2D");
+      uint32_t status = 0;
+      {
+        // the turn lasts until the kernel has handed out its last read; the few heavy reads still
+        // running by then (hundreds of ms each on one wave) overlap with the next batch's kernel
+        std::unique_lock<std::mutex> turn(*ctx->kernel_turn, std::defer_lock);
+        if (take_turn) turn.lock();  // (the handful of reads of a long-CIGAR rerun just go ahead)
+        __atomic_store_n(ctx->drained, 0u, __ATOMIC_RELAXED);
+        ctx->signal_drained = true;
+        se_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, max_len, reinterpret_cast<abm_hit *>(ctx->res.p),
+                  ctx->cig.p, stride, ctx->cig_n.p, ctx->status.p, st);
+        ctx->signal_drained = false;
+        HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+        while (__atomic_load_n(ctx->drained, __ATOMIC_RELAXED) == 0u && hipStreamQuery(st) == hipErrorNotReady)
+          std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (take_turn) turn.unlock();
+        t2.mark("  map: drained");
+        HIPCHK(hipStreamSynchronize(st));
+        t2.mark("  map: tail");
+      }
       if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW))
         throw std::runtime_error("kernel reported status " + std::to_string(status));
       return status;
     };
     const uint32_t stride = 16;
     HostTrace tr;
-    const uint32_t status = run(n, seq_blob + base, bytes, rel.data(), stride);
+    const uint32_t status = run(n, seq_blob + base, bytes, rel.data(), stride, true);
     tr.mark("upload+map");
     HIPCHK(hipMemcpyAsync(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
     fetch_cigars(ctx, ctx->res.p, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob, cig_capacity, out_cig_off);
@@ -609,7 +640,7 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     for (uint64_t r : again) { sub.append(seq_blob + seq_off[r], seq_off[r + 1] - seq_off[r]); sub_off.push_back(sub.size()); }
     const uint32_t wide = max_len + 2;
     const uint64_t m = again.size();
-    run(m, sub.data(), sub.size(), sub_off.data(), wide);
+    run(m, sub.data(), sub.size(), sub_off.data(), wide, false);
     std::vector<uint32_t> slots(m * wide), counts(m);
     HIPCHK(hipMemcpyAsync(slots.data(), ctx->cig.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(counts.data(), ctx->cig_n.p, m * 4ull, hipMemcpyDeviceToHost, st));
@@ -686,6 +717,8 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4, st));
       HIPCHK(hipMemsetAsync(ctx->cig_n.p, 0, m * 4, st));
       HIPCHK(hipMemsetAsync(ctx->cig_n2h.p, 0, m * 4, st));
+      // (no kernel turn here: a paired-end batch ends in a long tail of a few pairs with huge
+      // candidate sets, which another context's batch fills)
       pe_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, ctx->blob2.p, ctx->off2.p, max_len, d_pair, d_se1,
                 d_se2, ctx->cig.p, ctx->cig2h.p, stride, ctx->cig_n.p, ctx->cig_n2h.p, ctx->status.p, st);
       uint32_t status = 0;

@@ -7,7 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #ifndef ABM_SE_WAVES_PER_SIMD
-#define ABM_SE_WAVES_PER_SIMD 8
+#define ABM_SE_WAVES_PER_SIMD 5  // the launch keeps 20 waves per CU resident (kSeWavesPerCu): up to 100 VGPRs each
 #endif
 
 namespace abm {
@@ -99,7 +99,12 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   // the launch waiting on whichever wave drew the heaviest reads
   auto next_read = [&]() -> u64 {
     unsigned long long v = 0;
-    if (lane == 0) v = atomicAdd(a.next_read, 1ull);
+    if (lane == 0) {
+      v = atomicAdd(a.next_read, 1ull);
+      // exactly one wave draws the first index past the end: from here on only reads already in
+      // flight are left, and the host may let the next batch's kernel in
+      if (v == a.n_reads && a.drained) __hip_atomic_store(a.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) |
            static_cast<u32>(uni(static_cast<int>(v)));
   };

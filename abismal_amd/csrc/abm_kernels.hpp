@@ -22,6 +22,7 @@ struct SeArgs {
   u32 *cig_n;         // [n]
   u32 *status;        // ABM_STATUS_* bits
   unsigned long long *next_read;  // work counter, zero at launch
+  u32 *drained;       // optional host-visible flag, set once every read has been handed to a wave
   u32 *read_cycles;   // optional [n], diagnostic kernel only: per-read shader cycles / 1024
   unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments

@@ -255,6 +255,35 @@ __device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64
   int unused;
   return hamming(genome, qpk, nwords, pos, unused);
 }
+// the same for two windows at once, five genome words of each in flight per step (a lane whose
+// `want` flag is off issues no loads and its results are meaningless)
+__device__ __forceinline__ void hamming2(const u64 *__restrict__ genome, const u64 *qpk, u32 nwords,
+                                         u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a,
+                                         int &dmax_a, int &d_b, int &dmax_b) {
+  const u64 *ga = genome + (pos_a >> 4), *gb = genome + (pos_b >> 4);
+  const u32 sa = (pos_a & 15u) << 2, sb = (pos_b & 15u) << 2;
+  int da = 0, ma = 0, db = 0, mb = 0;
+  for (u32 w0 = 0; w0 < nwords; w0 += 4) {
+    const u32 k = min(4u, nwords - w0);
+    u64 xa[5], xb[5];
+#pragma unroll
+    for (u32 j = 0; j < 5; ++j) {
+      xa[j] = (want_a && j <= k) ? ga[w0 + j] : 0ull;
+      xb[j] = (want_b && j <= k) ? gb[w0 + j] : 0ull;
+    }
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j)
+      if (j < k) {
+        const u64 q = qpk[w0 + j];
+        da += 16 - __popcll(q & ((xa[j] >> sa) | ((xa[j + 1] << (63 - sa)) << 1)));
+        ma = max(ma, da);
+        db += 16 - __popcll(q & ((xb[j] >> sb) | ((xb[j + 1] << (63 - sb)) << 1)));
+        mb = max(mb, db);
+      }
+  }
+  d_a = static_cast<i16>(da); dmax_a = static_cast<i16>(ma);
+  d_b = static_cast<i16>(db); dmax_b = static_cast<i16>(mb);
+}
 
 // One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
@@ -336,9 +365,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     if (TIMED) wt.t_probe += tb_ - ta;
 
     int carry = 0;
-    for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 64) {
-      // which (offset, table) segment does each of these 64 candidates belong to
-      ABM_STAMP(tc);
+    // which (offset, table) segment each of the 64 candidates from c0 on belongs to, and its index entry
+    auto locate = [&](u32 c0, bool &valid, int &owner, u32 &entry_at, bool &three) {
       lds.mark[lane] = 0;
       __syncthreads();
       if (na && start_a - c0 < 64u) lds.mark[start_a - c0] = static_cast<u16>(2 * lane + 1);
@@ -347,40 +375,19 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
       const int seg = m ? m - 1 : carry;
       carry = rdlane(seg, 63);
-      const int owner = seg >> 1;
-      const bool three = seg & 1;
+      owner = seg >> 1;
+      three = seg & 1;
+      const u32 c = c0 + lane;
+      valid = c < total;
+      // (all four exchanges are made by every lane: a shuffle inside a divergent branch would not
+      // see the lanes on the other side)
       const u32 sa = __shfl(start_a, owner), sb = __shfl(start_b, owner);
       const u32 ba = __shfl(lo2, owner), bb = __shfl(lo3, owner);
-      const u32 c = c0 + lane;
-      const bool valid = c < total;
-      u32 pos = 0;
-      int h = 0x7fff, hmax = 0x7fff;
-      if (valid) {
-        const u32 entry = three ? idx3[bb + (c - sb)] : ix.index[ba + (c - sa)];
-        pos = entry - (g0 + static_cast<u32>(owner));
-        // the same genome position is proposed again and again (neighbouring seeds of one
-        // hit, the sensitive pass repeating the specific one): a small per-call cache of
-        // (pos -> distances) saves the 1-2 HBM lines of a window.  Distances are a pure
-        // function of (pos, encoding), so a cache hit is exact by construction.
-        u64 *slot = lds.pcache + ((pos * 2654435761u) >> (32 - kPosCacheBits));
-        const u64 e = *slot;
-        ++wt.cands;
-        wt.words += nwords;
-        if (static_cast<u32>(e) == pos) {
-          h = static_cast<i16>(static_cast<u16>(e >> 32));
-          hmax = static_cast<i16>(static_cast<u16>(e >> 48));
-          ++wt.cache_hits;
-        }
-        else {
-          h = hamming(ix.genome, qpk, nwords, pos, hmax);
-          *slot = static_cast<u64>(pos) | (static_cast<u64>(static_cast<u16>(h)) << 32) |
-                  (static_cast<u64>(static_cast<u16>(hmax)) << 48);
-        }
-      }
-      // ordered replay (check_hits + se_candidates::update, :1133-1149, :394-404)
+      entry_at = three ? bb + (c - sb) : ba + (c - sa);
+    };
+    // ordered replay of one 64-candidate sub-chunk (check_hits + update, :1133-1149, :394-404)
+    auto replay = [&](bool valid, int h, int hmax, u32 pos) {
       u64 todo = __ballot(valid && hmax <= S.cutoff);
-      ABM_STAMP(td);
-      if (TIMED) wt.t_stream += td - tc;
       if constexpr (Set::kAppend) if (SPECIFIC && !S.heaped && todo) {
         // growing paired-end set: every survivor goes in, the whole chunk at once (see PeSet)
         const int offered = __popcll(todo);
@@ -413,6 +420,46 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         todo &= ~(((1ull << l) << 1) - 1);
         if (S.cutoff < before) todo &= __ballot(valid && hmax <= S.cutoff);
       }
+    };
+    // Candidates are taken 128 at a time, two per lane (c0+lane and c0+64+lane): both index entries,
+    // then both genome windows, are in flight together, which halves the dependent round trips of a
+    // read with very many candidates.  The set still sees them strictly in the reference's order.
+    for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
+      ABM_STAMP(tc);
+      bool va, vb = false, ta3, tb3 = false;
+      int oa, ob = 0;
+      u32 ea_at, eb_at = 0;
+      locate(c0, va, oa, ea_at, ta3);
+      if (c0 + 64 < total) locate(c0 + 64, vb, ob, eb_at, tb3);
+      u32 ea = 0, eb = 0;
+      if (va) ea = ta3 ? idx3[ea_at] : ix.index[ea_at];
+      if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
+      const u32 pa = ea - (g0 + static_cast<u32>(oa)), pb = eb - (g0 + static_cast<u32>(ob));
+      // the same genome position is proposed again and again (neighbouring seeds of one hit, the
+      // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
+      // saves the 1-2 HBM lines of a window.  Distances are a pure function of (pos, encoding),
+      // so a cache hit is exact by construction.
+      u64 *slot_a = lds.pcache + ((pa * 2654435761u) >> (32 - kPosCacheBits));
+      u64 *slot_b = lds.pcache + ((pb * 2654435761u) >> (32 - kPosCacheBits));
+      const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
+      const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
+      int ha, hma, hb, hmb;
+      hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
+      if (hit_a) { ha = static_cast<i16>(static_cast<u16>(ca >> 32)); hma = static_cast<i16>(static_cast<u16>(ca >> 48)); }
+      if (hit_b) { hb = static_cast<i16>(static_cast<u16>(cb >> 32)); hmb = static_cast<i16>(static_cast<u16>(cb >> 48)); }
+      if (va && !hit_a)
+        *slot_a = static_cast<u64>(pa) | (static_cast<u64>(static_cast<u16>(ha)) << 32) | (static_cast<u64>(static_cast<u16>(hma)) << 48);
+      if (vb && !hit_b)
+        *slot_b = static_cast<u64>(pb) | (static_cast<u64>(static_cast<u16>(hb)) << 32) | (static_cast<u64>(static_cast<u16>(hmb)) << 48);
+      if (!va) { ha = hma = 0x7fff; }
+      if (!vb) { hb = hmb = 0x7fff; }
+      wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
+      wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * nwords;
+      wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
+      ABM_STAMP(td);
+      if (TIMED) wt.t_stream += td - tc;
+      replay(va, ha, hma, pa);
+      if (!S.sure_ambig) replay(vb, hb, hmb, pb);
       ABM_STAMP(tc);
       if (TIMED) wt.t_replay += tc - td;
     }

@@ -373,6 +373,8 @@ def main():
                          "not the headline metric -- prints its own JSON line")
     ap.add_argument("--streams", type=int, default=2,
                     help="--pe only: consecutive steps alternate over this many (context, stream) slots")
+    ap.add_argument("--distinct-batches", type=int, default=4,
+                    help="SE: number of different synthetic batches the steps cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-stamps", action="store_true",
                     help="after the timed region, run one extra step of the diagnostic kernel and report phase shares")
@@ -428,9 +430,17 @@ def main():
     if args.pe:
         return run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     t0 = time.time()
-    blob, n_skipped = sample_reads(genome_words, starts, n, L, 1000 + rank, dev)
+    # every step maps a batch of its own (as consecutive batches of a run would be): a step that
+    # re-mapped the previous step's reads would find their index lines still in the last-level cache
+    n_batches = max(1, min(args.steps + args.warmup, args.distinct_batches))
+    blobs, n_skipped = [], 0
+    for k in range(n_batches):
+        bk, sk = sample_reads(genome_words, starts, n, L, 1000 + rank + 7919 * k, dev)
+        blobs.append(bk)
+        n_skipped = sk if k == 0 else n_skipped
+    blob = blobs[0]
     off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
-    log(f"{n} reads sampled on GPU in {time.time() - t0:.1f}s ({n_skipped} unseedable)")
+    log(f"{n_batches} x {n} reads sampled on GPU in {time.time() - t0:.1f}s ({n_skipped} unseedable in the first)")
     del genome_words
 
     stride = 16
@@ -441,8 +451,12 @@ def main():
     params = A.Params()
     stream = torch.cuda.current_stream().cuda_stream
 
+    issued = [0]
+
     def step():
-        ctx.map_se_device(A.SE_T_RICH, params, n, blob.data_ptr(), off.data_ptr(), L, res.data_ptr(),
+        bk = blobs[issued[0] % n_batches]
+        issued[0] += 1
+        ctx.map_se_device(A.SE_T_RICH, params, n, bk.data_ptr(), off.data_ptr(), L, res.data_ptr(),
                           cig.data_ptr(), stride, cig_n.data_ptr(), status.data_ptr(), stream)
 
     for _ in range(args.warmup):
@@ -471,6 +485,7 @@ def main():
         if pc:
             phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
 
+    blob = blobs[(issued[0] - 1) % n_batches]  # the batch whose results the output buffers hold
     # mapping statistics (six counters, src/abismal.cpp:865-895) reduced over ranks
     pos = res[:, 1]
     flags = (res[:, 0] >> 16) & 0xFFFF

@@ -24,10 +24,32 @@ with open(fq, "wb") as f:
 print("fastq written", time.time() - t, "s", os.path.getsize(fq) / 1e6, "MB")
 del blob
 torch.cuda.empty_cache()
-for extra, outp in (([], f"{wd}/out.sam"), (["-mappers", "3"], f"{wd}/out.sam"), (["-batch", "524288", "-mappers", "3"], f"{wd}/out.sam"), (["-mappers", "1"], f"{wd}/out.sam"), (["-B"], f"{wd}/out.bam")):
+fqs = [fq]
+if os.environ.get("ABM_CLI_PE"):
+    # paired-end input: n/2 pairs of 2 x 150 bp from 150-500 bp fragments
+    npairs, Lp = n // 2, 150
+    b1, b2 = bench.sample_pairs(gw, starts, npairs, Lp, 2000, dev)
+    fqs = []
+    for tag, bl in (("1", b1), ("2", b2)):
+        hostp = bl.cpu().numpy().reshape(npairs, Lp)
+        path = f"{wd}/pairs_{npairs}_{tag}.fq"
+        with open(path, "wb") as f:
+            for a in range(0, npairs, 200000):
+                b = min(npairs, a + 200000)
+                rec = np.empty((b - a, 2 * Lp + 4), dtype=np.uint8)
+                rec[:, :Lp] = hostp[a:b]; rec[:, Lp] = 10; rec[:, Lp + 1] = ord("+"); rec[:, Lp + 2] = 10; rec[:, Lp + 3:2 * Lp + 3] = ord("B"); rec[:, 2 * Lp + 3] = 10
+                f.write(b"".join(b"@p%d\n" % i + bytes(r) for i, r in zip(range(a, b), rec)))
+        fqs.append(path)
+    del b1, b2
+    torch.cuda.empty_cache()
+    n = 2 * npairs
+for extra, outp in (([], f"{wd}/out.sam"), (["-mappers", "3"], f"{wd}/out.sam"), (["-B"], f"{wd}/out.bam")):
     t = time.time()
-    r = subprocess.run(["abismal_amd/abismal-amd", "map", "-v", "-i", idx, "-o", outp, "-s", f"{wd}/out.stats"] + extra + [fq],
+    r = subprocess.run(["abismal_amd/abismal-amd", "map", "-v", "-i", idx, "-o", outp, "-s", f"{wd}/out.stats"] + extra + fqs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     dt = time.time() - t
+    if os.environ.get("ABM_TRACE_HOST"):
+        print("\n".join(r.stdout.strip().split("\n")[-70:]))
+        break
     print(extra, outp, "rc", r.returncode, f"wall {dt:.2f}s -> {n/dt/1e6:.2f} M reads/s incl. index load;", " | ".join(r.stdout.strip().split("\n")[-2:])[:400])
 print(open(f"{wd}/out.stats").read()[:300])

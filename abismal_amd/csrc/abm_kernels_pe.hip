@@ -777,12 +777,6 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
     w.max_set = 0;
     long long t_pair = 0;
     ABM_STAMP(t_pair);
-#ifdef ABM_DIAG_MONSTER
-    const long long t_pair0 = t_pair;
-    const WorkTally wt0 = w.wt;
-    const long long m0 = w.t_sort, m1 = w.t_score, m2 = w.t_mate, m3 = w.t_single, m4 = t_fb;
-    const u32 na0 = w.n_aln;
-#endif
     w.n_ops[0] = w.n_ops[1] = 0;
     w.ref_len[0] = w.ref_len[1] = 0;
 
@@ -831,22 +825,6 @@ __global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
       ABM_STAMP(tf1);
       if (TIMED) t_fb += tf1 - tf0;
     }
-#ifdef ABM_DIAG_MONSTER
-    if (TIMED && BIG) {
-      const long long tot = phase_stamp() - t_pair0;
-      if (tot > 1000000000ll && lane == 0)
-        printf("pair %llu set %d Mcyc %lld probe %lld stream %lld replay %lld sort %lld score %lld mate %lld single %lld fb %lld | offs %u probes %u cands(l0) %u upd %u aln %u L %u %u\n",
-               (unsigned long long)r, w.max_set, tot >> 20, (w.wt.t_probe - wt0.t_probe) >> 20, (w.wt.t_stream - wt0.t_stream) >> 20,
-               (w.wt.t_replay - wt0.t_replay) >> 20, (w.t_sort - m0) >> 20, (w.t_score - m1) >> 20, (w.t_mate - m2) >> 20,
-               (w.t_single - m3) >> 20, (t_fb - m4) >> 20, w.wt.seed_iters - wt0.seed_iters, w.wt.probes - wt0.probes,
-               w.wt.cands - wt0.cands, w.wt.updates - wt0.updates, w.n_aln - na0, w.L[0], w.L[1]);
-    }
-    if (BIG && w.max_set <= ABM_DIAG_MONSTER) {  // tally only the pairs with very large sets
-      w.wt = wt0; w.t_sort = m0; w.t_score = m1; w.t_mate = m2; w.t_single = m3; t_fb = m4; w.n_aln = na0;
-      ABM_STAMP(t_pair);
-      t_begin += phase_stamp() - t_pair0;
-    }
-#endif
     if (lane == 0) {
       u32 *po = reinterpret_cast<u32 *>(a.pairs) + r * 5;
       po[0] = static_cast<u32>(static_cast<u16>(static_cast<i16>(best.aln_score)));

@@ -61,9 +61,12 @@ uint64_t abm_index_bytes(const abm_index *ix);                  /* bytes residen
  * Host-side, multi-threaded; the file is byte-identical to the reference's. */
 int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_threads);
 
-/* Replicates the index into the HBM of `device` (hipSetDevice ordinal) and
- * allocates per-GPU workspaces.  The index is immutable afterwards and may be
- * shared by any number of streams. */
+/* A context = one host thread's workspaces and stream on `device` (hipSetDevice
+ * ordinal).  The first context on a device replicates the index into its HBM;
+ * later ones share that replica (freed with the last of them).  Calls on one
+ * context are serialised; use one context per mapper thread so that a batch's
+ * transfers overlap another batch's kernels.  Destroy every context before
+ * abm_index_close. */
 int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out);
 void abm_ctx_destroy(abm_ctx *ctx);
 

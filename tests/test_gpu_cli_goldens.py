@@ -77,6 +77,26 @@ def test_map_goldens(chain, args, outs):
         assert md5(chain / o) == g[o], f"{o} differs from the reference golden"
 
 
+@pytest.mark.parametrize("reads,extra", [
+    (["tests/reads_1.fq"], []),
+    (["tests/reads_pe_1.fq", "tests/reads_pe_2.fq"], []),
+    (["tests/reads_rpbat_pe_1.fq", "tests/reads_rpbat_pe_2.fq"], ["-R"]),
+])
+def test_many_small_batches_keep_input_order(chain, reads, extra):
+    """Batches of 700 records over three mapper contexts and several host threads: records must leave in
+    input order and the statistics must add up exactly as in a single-batch run."""
+    def run(tag, flags):
+        r = subprocess.run([CLI, "map"] + extra + flags + ["-s", f"tests/{tag}.stats", "-o", f"tests/{tag}.sam", "-i",
+                           "tests/tRex1.idx"] + reads, cwd=chain, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        return ([l for l in open(chain / f"tests/{tag}.sam") if not l.startswith("@PG")], open(chain / f"tests/{tag}.stats").read())
+    one = run("one_batch", [])
+    many = run("many_batches", ["-batch", "700", "-mappers", "3", "-t", "5"])
+    assert many[0] == one[0]
+    assert many[1] == one[1]
+    assert len(one[0]) > 8000
+
+
 def test_bam_output_carries_the_same_records(chain):
     """-B: decode the BGZF/BAM stream with nothing but gzip + struct and compare every field with the SAM text."""
     import gzip

@@ -140,3 +140,29 @@ def test_device_entry_point_matches_host_entry_point(ctx, reads):
     cn = d_n.cpu().numpy()
     dc = d_cig.cpu().numpy().view(np.uint32)
     assert [tuple(dc[i, :cn[i]].tolist()) for i in range(n)] == cigars(cig, off)
+
+
+def test_small_cigar_capacity_is_reported_not_overrun(ctx, reads):
+    """abm_map_se_batch with too little room for the CIGARs returns ABM_ERR_CAPACITY (-2) and the
+    same call with enough room succeeds (the CLI relies on this to start with a small buffer)."""
+    import ctypes as C
+    import abismal_amd.api as A
+    sub = reads[:2000]
+    sub = [r if isinstance(r, bytes) else r.encode() for r in sub]
+    blob = np.frombuffer(b"".join(sub), dtype=np.uint8).copy()
+    off = np.zeros(len(sub) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in sub])
+    n = len(sub)
+    res = np.zeros(n, dtype=A.HIT_DTYPE)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    lib, p = A.load_library(), A.Params()
+    small = np.zeros(16, dtype=np.uint32)
+    rc = lib.abm_map_se_batch(ctx.handle, 0, C.byref(p), n, blob.ctypes.data, off.ctypes.data, res.ctypes.data,
+                              small.ctypes.data, len(small), co.ctypes.data)
+    assert rc == -2, (rc, lib.abm_last_error())
+    big = np.zeros(n * 102, dtype=np.uint32)
+    rc = lib.abm_map_se_batch(ctx.handle, 0, C.byref(p), n, blob.ctypes.data, off.ctypes.data, res.ctypes.data,
+                              big.ctypes.data, len(big), co.ctypes.data)
+    assert rc == 0, lib.abm_last_error()
+    mapped = int((res["pos"] != 0).sum())
+    assert mapped > 0.8 * n and int(co[-1]) >= mapped

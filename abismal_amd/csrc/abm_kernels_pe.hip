@@ -10,6 +10,10 @@
 #include <climits>
 #include "abm_kernels_core.hpp"
 
+#ifndef ABM_PE_WAVES_PER_SIMD
+#define ABM_PE_WAVES_PER_SIMD 4
+#endif
+
 namespace abm {
 
 struct PeLds {
@@ -688,7 +692,7 @@ template <bool BIG> struct PeWave {
 };
 
 template <bool BIG, bool TIMED>
-__global__ __launch_bounds__(64) void map_pe_kernel(PeArgs a) {
+__global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   PeWave<BIG> w{a};

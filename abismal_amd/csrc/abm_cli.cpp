@@ -481,7 +481,7 @@ struct Options {
   uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));  // host parse/format threads
   int gpus = 0;
   size_t batch = 0;  // reads (pairs) per batch; 0 = default for the input type
-  int mappers = 2;  // mapper threads (contexts) per GPU
+  int mappers = 0;  // mapper threads (contexts) per GPU; 0 = 2 for single-end, 3 for paired-end input
   double max_distance = 0.1;
   std::vector<std::string> reads;
 };
@@ -555,7 +555,7 @@ int cmd_map(int argc, char **argv) {
   // mapper thread's workspaces + stream, and two per GPU keep the device busy while the other
   // thread's batch is in transit over PCIe
   int n_gpus = opt.gpus;
-  const int per_gpu = std::max(1, opt.mappers);
+  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 3 : 2);
   std::vector<abm_ctx *> ctxs;
   for (int d = 0; n_gpus <= 0 || d < n_gpus; ++d) {
     abm_ctx *c = nullptr;

@@ -371,7 +371,7 @@ def main():
     ap.add_argument("--pe", action="store_true",
                     help="paired-end variant (BASELINE config 3): 2 x --read-len pairs from 150-500 bp fragments; "
                          "not the headline metric -- prints its own JSON line")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="--pe only: consecutive steps alternate over this many (context, stream) slots")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="SE: number of different synthetic batches the steps cycle through")

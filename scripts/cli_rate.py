@@ -43,7 +43,10 @@ if os.environ.get("ABM_CLI_PE"):
     del b1, b2
     torch.cuda.empty_cache()
     n = 2 * npairs
-for extra, outp in (([], f"{wd}/out.sam"), (["-mappers", "3"], f"{wd}/out.sam"), (["-B"], f"{wd}/out.bam")):
+variants = (([], f"{wd}/out.sam"), (["-mappers", "3"], f"{wd}/out.sam"), (["-B"], f"{wd}/out.bam"))
+if os.environ.get("ABM_CLI_BATCH"):
+    variants = ((["-batch", os.environ["ABM_CLI_BATCH"]], f"{wd}/out.sam"),)
+for extra, outp in variants:
     t = time.time()
     r = subprocess.run(["abismal_amd/abismal-amd", "map", "-v", "-i", idx, "-o", outp, "-s", f"{wd}/out.stats"] + extra + fqs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

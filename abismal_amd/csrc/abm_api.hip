@@ -189,6 +189,10 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.size_frac = size_frac;
   a.GW = abm::se_window_words(eff_len, size_frac);
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
+  // cooperative window loads (hamming_coop): not for genomes with IUPAC letters, whose admission rule needs
+  // full_compare's word-by-word running sums; ABM_COOP_WINDOWS=0 switches them off (experiments)
+  a.G = ctx->ix->h.multibit_genome ? 0u : (W <= 7 ? 4u : (W <= 15 ? 8u : 0u));
+  if (const char *e = std::getenv("ABM_COOP_WINDOWS")) if (e[0] == '0') a.G = 0;
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.res = reinterpret_cast<abm::Hit *>(d_res);
@@ -292,6 +296,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : std::max(params->valid_frac, params->valid_frac);
   a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, size_frac);
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
+  a.G = 0;  // the paired-end kernels keep one lane per candidate window (their register budget is spent elsewhere)
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.min_frag = params->min_frag; a.max_frag = params->max_frag;

@@ -7,7 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #ifndef ABM_SE_WAVES_PER_SIMD
-#define ABM_SE_WAVES_PER_SIMD 5  // the launch keeps 20 waves per CU resident (kSeWavesPerCu): up to 100 VGPRs each
+#define ABM_SE_WAVES_PER_SIMD 4  // 128 VGPRs per lane: the candidate filter keeps 8 rounds of window loads in flight
 #endif
 
 namespace abm {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
-template <bool TIMED>
+template <bool TIMED, bool COOP>
 __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -81,6 +81,8 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   lds.jdf = lds.jpos + kSeCap;
   lds.lbest = reinterpret_cast<int *>(lds.jdf + kSeCap);
   lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
+  lds.hres = lds.mark + 64;
+  lds.G = a.G;
 
   // (rc, a_rich) calls per mode, in the reference's order
   // T-rich :1556-1572 | A-rich (-A/-P) | random PBAT :1649-1676
@@ -142,11 +144,11 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        seed_pass<true, TIMED>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
+        seed_pass<true, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
         // should_do_sensitive, :367-370
         if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
           S.cutoff = S.top_d();  // set_sensitive
-          seed_pass<false, TIMED>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
+          seed_pass<false, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
         }
       }
       ABM_STAMP(t_a);
@@ -330,7 +332,7 @@ size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_fra
   const u32 GW = se_window_words(max_len, valid_frac);
   size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) +
              static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
-             2 * kSeCap * 4 + 64 * 4 + 64 * 2;
+             2 * kSeCap * 4 + 64 * 4 + 64 * 2 + 128 * 2;
   b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);
 }
@@ -339,13 +341,15 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false>, 64,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true>, 64,
                                                    se_lds_bytes(W, WB, cig_stride, max_len, valid_frac)) != hipSuccess)
     return 0;
-  // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh): the kernel is bound by random 128-byte
-  // line fetches, and beyond ~20 waves per CU more gathers in flight only evict each other's lines
-  // and translations (1427 ms at 20 waves/CU, 1577 ms at 28, 1681 ms at 32 for 10 M reads).
-  constexpr int kSeWavesPerCu = 20;
+  // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): the kernel is bound by
+  // the random line requests a CU can keep outstanding.  With one lane per candidate window the optimum
+  // was 20 waves per CU (more only evicted each other's lines from L1/L2); with cooperative window loads
+  // 16 waves per CU at 128 registers each beat 20 waves at 96 registers with spills
+  // (1037 ms vs 1387 ms for 10 M reads; 14 waves: 1116 ms).
+  constexpr int kSeWavesPerCu = 16;
   return min(per_cu, kSeWavesPerCu) * prop.multiProcessorCount;
 }
 
@@ -362,8 +366,15 @@ hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, 
   if (a.n_reads == 0) return hipSuccess;
   const size_t lds = se_lds_bytes(a.W, a.WB, a.cig_stride, max_len, a.size_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
-  if (timed) hipLaunchKernelGGL(map_se_kernel<true>, dim3(blocks), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL(map_se_kernel<false>, dim3(blocks), dim3(64), lds, st, a);
+  // COOP: G lanes share a candidate's window (a.G != 0); otherwise one lane per window
+  if (a.G != 0) {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
+  }
+  else {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, false>), dim3(blocks), dim3(64), lds, st, a);
+  }
   return hipGetLastError();
 }
 

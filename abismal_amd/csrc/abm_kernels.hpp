@@ -13,6 +13,7 @@ struct SeArgs {
   u64 n_reads;
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
   u32 tb_extra;       // tb_extra_bytes()
+  u32 G;              // lanes sharing one candidate window (WaveLds::G)
   int mode;           // ABM_SE_*
   double valid_frac;
   double size_frac;   // valid_frac used to size LDS bands (1.0 when the genome has IUPAC codes)
@@ -37,7 +38,7 @@ struct PeArgs {
   const u32 *subset;             // tier 2: ids of the pairs to redo
   const u32 *subset_count;       // tier 2: how many
   u64 n_pairs;
-  u32 W, WB, GW, tb_extra;
+  u32 W, WB, GW, tb_extra, G;
   int mode;
   double valid_frac;
   u32 min_frag, max_frag;

@@ -146,7 +146,9 @@ struct WaveLds {
   u32 *jdf;    // [kSeCap] alignment job list: diffs<<16 | flags
   int *lbest;  // [64]
   u64 *pcache; // [1 << kPosCacheBits] candidate cache: pos | diffs<<32 | max-prefix-diffs<<48
+  u16 *hres;   // [128] distances of the candidates of one step (cooperative window loads)
   u32 W, WB, GW;
+  u32 G;       // lanes that share one candidate's window (4 or 8), 0 = one lane per window
 };
 constexpr u32 kPosCacheBits = 8;
 constexpr u32 kMaxJobs = 21;  // 64 lanes / narrowest band (3)
@@ -285,6 +287,71 @@ __device__ __forceinline__ void hamming2(const u64 *__restrict__ genome, const u
   d_b = static_cast<i16>(db); dmax_b = static_cast<i16>(mb);
 }
 
+// ---- candidate filter, cooperative form ----------------------------------------------
+// A lane that fetches its own candidate's window issues one load per word, and with ~20 waves
+// sharing a CU's L1 the line has often been evicted again before the next word asks for it: a
+// window then costs several L1 misses instead of 1.44 lines.  Here G lanes (4 for reads up to
+// 112 bp, 8 up to 240 bp) share a candidate: lane s of the group loads words 2s and 2s+1 of the
+// window in ONE 16-byte load, so a whole window is covered by a single instruction and its lanes
+// coalesce into one or two line requests.  Each lane counts the mismatches of its two words (the
+// word after them comes from the next lane), the group adds up, and the sums travel through LDS
+// to the lanes that own the candidates.  The 128 candidates of a step are slots 0..63 (lane's
+// first) and 64..127 (lane's second); 64/G of them are fetched per round, 8 rounds in flight.
+__device__ __forceinline__ int dpp_row_shl1(int v) {  // lane i <- lane i+1 within a row of 16 (last lane: 0)
+  return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned groups of 4 or 8 lanes, in every lane
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm 1,0,3,2*/, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm 2,3,0,1*/, 0xf, 0xf, false);
+  if (G == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, const WaveLds &lds, const u64 *qpk,
+                                             u32 nwords, u32 pos_a, bool want_a, u32 pos_b, bool want_b,
+                                             int &d_a, int &d_b) {
+  const int lane = lane_id();
+  const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
+  const u64 wa = __ballot(want_a), wb = __ballot(want_b);
+  const bool has0 = 2 * sub < nwords, has1 = 2 * sub + 1 < nwords;
+  const u64 q0 = has0 ? qpk[2 * sub] : 0ull, q1 = has1 ? qpk[2 * sub + 1] : 0ull;
+  for (u32 pass = 0; pass * 8 * per_round < 128; ++pass) {
+    u64 x0[8], x1[8];
+    u32 shifts = 0;  // (pos & 15) of the eight rounds' candidates, four bits each
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+      const u32 slot = (pass * 8 + r) * per_round + grp;  // < 128; a round lies entirely in one half
+      const bool second = (pass * 8 + r) * per_round >= 64;
+      const u32 c = slot & 63u;
+      const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
+      shifts |= (cp & 15u) << (4 * r);
+      const bool act = (((second ? wb : wa) >> c) & 1ull) && 2 * sub <= nwords;
+      x0[r] = 0; x1[r] = 0;
+      if (act) {
+        const u64 *g = genome + (cp >> 4) + 2 * sub;
+        x0[r] = g[0];
+        x1[r] = g[1];
+      }
+    }
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+      const u32 slot = (pass * 8 + r) * per_round + grp;
+      const u32 sh = ((shifts >> (4 * r)) & 15u) << 2;
+      // the word after this lane's pair is the next lane's first word
+      const u64 x2 = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r] >> 32)))) << 32) |
+                     static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r])));
+      int d = 0;
+      if (has0) d += 16 - __popcll(q0 & ((x0[r] >> sh) | ((x1[r] << (63 - sh)) << 1)));
+      if (has1) d += 16 - __popcll(q1 & ((x1[r] >> sh) | ((x2 << (63 - sh)) << 1)));
+      d = group_sum(d, G);
+      if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
+    }
+  }
+  __syncthreads();
+  d_a = static_cast<i16>(lds.hres[lane]);
+  d_b = static_cast<i16>(lds.hres[64 + lane]);
+  __syncthreads();
+}
+
 // One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
 // candidates (all checked buckets of 64 offsets flattened in reference order)
@@ -305,7 +372,7 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-template <bool SPECIFIC, bool TIMED, class Set>
+template <bool SPECIFIC, bool TIMED, bool COOP, class Set>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
                                           u32 flags, u32 L, Set &S, WorkTally &wt) {
   const int lane = lane_id();
@@ -444,7 +511,12 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
       const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
       int ha, hma, hb, hmb;
-      hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
+      if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
+        hamming_coop(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+        hma = ha; hmb = hb;
+      }
+      else
+        hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
       if (hit_a) { ha = static_cast<i16>(static_cast<u16>(ca >> 32)); hma = static_cast<i16>(static_cast<u16>(ca >> 48)); }
       if (hit_b) { hb = static_cast<i16>(static_cast<u16>(cb >> 32)); hmb = static_cast<i16>(static_cast<u16>(cb >> 48)); }
       if (va && !hit_a)

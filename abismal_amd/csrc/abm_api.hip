@@ -296,7 +296,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : std::max(params->valid_frac, params->valid_frac);
   a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, size_frac);
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
-  a.G = 0;  // the paired-end kernels keep one lane per candidate window (their register budget is spent elsewhere)
+  a.G = (W <= 7 ? 4u : 8u);  // only read by a paired-end build with cooperative window loads (ABM_PE_COOP)
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.min_frag = params->min_frag; a.max_frag = params->max_frag;

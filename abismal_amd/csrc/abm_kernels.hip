@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   lds.jdf = lds.jpos + kSeCap;
   lds.lbest = reinterpret_cast<int *>(lds.jdf + kSeCap);
   lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
-  lds.hres = lds.mark + 64;
+  lds.hres = reinterpret_cast<u16 *>(lds.lbest);  // 128 x u16 = the 64 ints of lbest, idle during the seed passes
   lds.G = a.G;
 
   // (rc, a_rich) calls per mode, in the reference's order
@@ -332,7 +332,7 @@ size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_fra
   const u32 GW = se_window_words(max_len, valid_frac);
   size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) +
              static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
-             2 * kSeCap * 4 + 64 * 4 + 64 * 2 + 128 * 2;
+             2 * kSeCap * 4 + 64 * 4 + 64 * 2;
   b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);
 }

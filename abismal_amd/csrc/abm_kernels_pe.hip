@@ -10,6 +10,9 @@
 #include <climits>
 #include "abm_kernels_core.hpp"
 
+#ifndef ABM_PE_COOP
+#define ABM_PE_COOP false
+#endif
 #ifndef ABM_PE_WAVES_PER_SIMD
 #define ABM_PE_WAVES_PER_SIMD 4
 #endif
@@ -291,10 +294,10 @@ template <bool BIG> struct PeWave {
     P.begin_read(L[end]);
     if (L[end] >= kMinReadLen) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, false>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+      seed_pass<true, TIMED, ABM_PE_COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, false>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+        seed_pass<false, TIMED, ABM_PE_COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       }
     }
     need_big |= P.overflow;
@@ -728,8 +731,8 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     after_heap = reinterpret_cast<u32 *>(h + 4 * a.cap);
   }
   lds.mark = reinterpret_cast<u16 *>(after_heap);
-  lds.hres = nullptr;  // (cooperative window loads are a single-end kernel variant)
-  lds.G = 0;
+  lds.hres = reinterpret_cast<u16 *>(lds.lbest);
+  lds.G = a.G;
 
   w.P.heap = w.pl.heap;
   // scratch table for permuting a list: global for tier 2; tier 1 borrows the window cache (idle outside seed passes)

@@ -408,6 +408,7 @@ template <bool BIG> struct PeWave {
     const int ends[2] = {endA, 1 - endA};
     const long long lenB = L[ends[1]];
     // pass 1: mark.  score 0 = cannot pair, 2L = exact hit (align() returns at once), -1 = needs the DP
+    #pragma unroll
     for (int which = 0; which < 2; ++which) {
       const int other = 1 - which, n = lsz[which];
       for (int i = lane; i < n; i += 64) {
@@ -427,6 +428,7 @@ template <bool BIG> struct PeWave {
     }
     __syncthreads();
     // pass 2: run the marked entries through the wavefront DP, up to kSeCap jobs at a time
+    #pragma unroll
     for (int which = 0; which < 2; ++which) {
       const int end = ends[which], n = lsz[which];
       const int md = static_cast<i16>(a.valid_frac * L[end]);
@@ -674,6 +676,7 @@ template <bool BIG> struct PeWave {
     ABM_STAMP(t0);
     // best_single: every entry of each set, in array order, into that end's single-end set
     const int ends[2] = {endA, endB};
+    #pragma unroll
     for (int which = 0; which < 2; ++which) {
       SeSet &S = se[ends[which]];
       const int n = lsz[which];
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     w.L[1] = a.lens2[r];
     if (w.L[0] > kMaxReadLen || w.L[1] > kMaxReadLen) { too_long = true; w.L[0] = w.L[1] = 0; }
     // stage both ends' four encodings and their 2-letter bit strings
+    #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const u64 *src = (e ? a.packed2 : a.packed1) + r * 4 * a.W;
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[e * 4 * a.W + k] = src[k];
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     __syncthreads();
     for (u32 e8 = 0; e8 < 8; ++e8)
       for (u32 wb = 0; wb < a.WB; ++wb) {
-        const u32 j = wb * 64 + lane, Le = w.L[e8 >> 2];
+        const u32 j = wb * 64 + lane, Le = e8 < 4 ? w.L[0] : w.L[1];
         const bool b = j < Le ? bit2(q_nibble(lds.qpk + e8 * a.W, j)) : true;
         const u64 word = __ballot(b);
         if (lane == 0) lds.qbits[e8 * a.WB + wb] = word;
@@ -823,6 +827,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     if (!best.should_report(a.allow_ambig != 0)) {  // single-end fallback at half the error budget
       long long tf0 = 0, tf1 = 0;
       ABM_STAMP(tf0);
+      #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const WaveLds we = w.lds_of(e);
         u32 nops = 0;

@@ -257,31 +257,41 @@ __device__ __forceinline__ int hamming(const u64 *__restrict__ genome, const u64
   int unused;
   return hamming(genome, qpk, nwords, pos, unused);
 }
-// the same for two windows at once, five genome words of each in flight per step (a lane whose
-// `want` flag is off issues no loads and its results are meaningless)
+// the same for two windows at once: the genome words are fetched two at a time (16-byte loads,
+// half as many requests as word-by-word), eight words of each window in flight per step (a lane
+// whose `want` flag is off issues no loads and its results are meaningless)
 __device__ __forceinline__ void hamming2(const u64 *__restrict__ genome, const u64 *qpk, u32 nwords,
                                          u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a,
                                          int &dmax_a, int &d_b, int &dmax_b) {
+  typedef u64 pair_t __attribute__((ext_vector_type(2), aligned(8)));
   const u64 *ga = genome + (pos_a >> 4), *gb = genome + (pos_b >> 4);
   const u32 sa = (pos_a & 15u) << 2, sb = (pos_b & 15u) << 2;
   int da = 0, ma = 0, db = 0, mb = 0;
-  for (u32 w0 = 0; w0 < nwords; w0 += 4) {
-    const u32 k = min(4u, nwords - w0);
-    u64 xa[5], xb[5];
+  u64 last_a = 0, last_b = 0;  // word c-1 of each window, carried into the next step
+  auto word = [&](u32 w, u64 a0, u64 a1, u64 b0, u64 b1) {
+    const u64 q = qpk[w];
+    da += 16 - __popcll(q & ((a0 >> sa) | ((a1 << (63 - sa)) << 1)));
+    ma = max(ma, da);
+    db += 16 - __popcll(q & ((b0 >> sb) | ((b1 << (63 - sb)) << 1)));
+    mb = max(mb, db);
+  };
+  for (u32 c = 0; c <= nwords; c += 8) {
+    u64 xa[8], xb[8];
 #pragma unroll
-    for (u32 j = 0; j < 5; ++j) {
-      xa[j] = (want_a && j <= k) ? ga[w0 + j] : 0ull;
-      xb[j] = (want_b && j <= k) ? gb[w0 + j] : 0ull;
+    for (u32 p = 0; p < 4; ++p) {
+      const bool in = c + 2 * p <= nwords;
+      pair_t va = {0ull, 0ull}, vb = {0ull, 0ull};
+      if (want_a && in) va = *reinterpret_cast<const pair_t *>(ga + c + 2 * p);
+      if (want_b && in) vb = *reinterpret_cast<const pair_t *>(gb + c + 2 * p);
+      xa[2 * p] = va.x; xa[2 * p + 1] = va.y;
+      xb[2 * p] = vb.x; xb[2 * p + 1] = vb.y;
     }
+    if (c > 0 && c - 1 < nwords) word(c - 1, last_a, xa[0], last_b, xb[0]);
 #pragma unroll
-    for (u32 j = 0; j < 4; ++j)
-      if (j < k) {
-        const u64 q = qpk[w0 + j];
-        da += 16 - __popcll(q & ((xa[j] >> sa) | ((xa[j + 1] << (63 - sa)) << 1)));
-        ma = max(ma, da);
-        db += 16 - __popcll(q & ((xb[j] >> sb) | ((xb[j + 1] << (63 - sb)) << 1)));
-        mb = max(mb, db);
-      }
+    for (u32 j = 0; j < 7; ++j)
+      if (c + j < nwords) word(c + j, xa[j], xa[j + 1], xb[j], xb[j + 1]);
+    last_a = xa[7];
+    last_b = xb[7];
   }
   d_a = static_cast<i16>(da); dmax_a = static_cast<i16>(ma);
   d_b = static_cast<i16>(db); dmax_b = static_cast<i16>(mb);

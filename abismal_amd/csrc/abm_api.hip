@@ -98,7 +98,7 @@ struct abm_ctx {
   bool signal_drained = false;  // set by the host-buffer entry point around its launch
   // per-batch workspaces (grow-only; sized by the largest batch seen)
   DevBuf<abm::u64> packed, packed2;
-  DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2, heap2;
+  DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2, heap2, log2;
   DevBuf<abm::u8> need_big;
   DevBuf<abm::Hit> pe_out;  // staging: pairs (20 B each) then se1, se2
   DevBuf<abm::u32> cig2h, cig_n2h;
@@ -335,6 +335,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);
     ctx->list2.reserve(static_cast<size_t>(waves) * 4 * a.cap);
     ctx->heap2.reserve(static_cast<size_t>(waves) * a.cap);
+    ctx->log2.reserve(static_cast<size_t>(waves) * (32 + 12 * static_cast<size_t>(a.cap)));
+    a.log_ws = ctx->log2.p;
     a.heap_ws = ctx->heap2.p;
     a.payload_ws = ctx->payload2.p;
     a.list_ws = ctx->list2.p;
@@ -470,7 +472,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->ix->replicas.erase(it);
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;

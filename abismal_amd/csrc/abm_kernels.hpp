@@ -55,6 +55,7 @@ struct PeArgs {
   u32 *payload_ws;               // [grid][cap]
   u32 *list_ws;                  // tier 2: [grid][2][cap] positions, then diffs and scores (i16)
   u32 *heap_ws;                  // tier 2: [grid][cap] candidate heap / sort buffer
+  u32 *log_ws;                   // tier 2: [grid][32 + 12 cap] lists kept for a deferred best_single
   u32 cap;
   u32 *pair_diag;                // optional [n], diagnostic kernel only: largest set << 16 | shader cycles >> 20
 };

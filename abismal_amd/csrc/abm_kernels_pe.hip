@@ -29,12 +29,10 @@ struct PeLds {
   u32 cap;
 };
 
-template <bool BIG> __device__ __forceinline__ u32 ld_list(const u32 *p) {
-  return BIG ? __builtin_nontemporal_load(p) : *p;
-}
-template <bool BIG> __device__ __forceinline__ int ld_list(const i16 *p) {
-  return BIG ? static_cast<int>(__builtin_nontemporal_load(p)) : static_cast<int>(*p);
-}
+// list element reads (tier 1: LDS; tier 2: this wave's lists in global memory, through L1 -- the
+// binary searches of the mating code revisit the same few lines from every lane)
+template <bool BIG> __device__ __forceinline__ u32 ld_list(const u32 *p) { return *p; }
+template <bool BIG> __device__ __forceinline__ int ld_list(const i16 *p) { return static_cast<int>(*p); }
 
 // pe_candidates, src/abismal.cpp:775-863, one set per wave.
 //
@@ -272,6 +270,7 @@ template <bool BIG> struct PeWave {
   u32 n_ops[2], ref_len[2];
   // diagnostic build only (TIMED): shader cycles per phase
   long long t_sort, t_score, t_mate, t_single;
+  u32 *log_base;  // tier 2: this wave's best_single log
   int max_set;
 
   __device__ __forceinline__ WaveLds lds_of(int end) const {
@@ -642,8 +641,38 @@ template <bool BIG> struct PeWave {
       best.clear();
   }
 
+  // best_single (:1715-1720): every entry of a list, in order, into a single-end set
+  __device__ __forceinline__ void feed_single(SeSet &S, const u32 *lp, const i16 *ldv, int n, u32 flags) {
+    for (int k0 = 0; k0 < n && !S.sure_ambig; k0 += 64) {
+      const int i = k0 + lane_id();
+      const int dl = i < n ? static_cast<int>(ldv[i]) : 0;
+      const u32 pv = i < n ? lp[i] : 0u;
+      const int m = min(64, n - k0);
+      for (int k = 0; k < m && !S.sure_ambig; ++k) {
+        S.admit(false, rdlane(dl, k), flags, rdlane(pv, k));
+        ++wt.updates;
+      }
+    }
+  }
+  // tier 2's log of the lists best_single would have consumed: 8 segments (orientation call x list)
+  __device__ __forceinline__ u32 *log_head(int seg) const { return log_base + seg * 4; }
+  __device__ __forceinline__ u32 *log_pos(int seg) const { return log_base + 32 + static_cast<u64>(seg) * pl.cap; }
+  __device__ __forceinline__ i16 *log_d(int seg) const {
+    return reinterpret_cast<i16 *>(log_base + 32 + 8ull * pl.cap) + static_cast<u64>(seg) * pl.cap;
+  }
+  __device__ __forceinline__ void replay_singles() {
+    for (int seg = 0; seg < 8; ++seg) {
+      const u32 *h = log_head(seg);
+      const int n = uni(static_cast<int>(h[0]));
+      if (n == 0) continue;
+      const u32 flags = static_cast<u32>(uni(static_cast<int>(h[1])));
+      if (uni(static_cast<int>(h[2])) == 0) feed_single(se[0], log_pos(seg), log_d(seg), n, flags);
+      else feed_single(se[1], log_pos(seg), log_d(seg), n, flags);
+    }
+  }
+
   // map_fragments + select_maps + best_single (:1715-1720, :1833-1885)
-  template <bool TIMED> __device__ __forceinline__ bool orientation(int endA, bool ar, u64 r, PairBest &best) {
+  template <bool TIMED, int O> __device__ __forceinline__ bool orientation(int endA, bool ar, u64 r, PairBest &best) {
     const int endB = 1 - endA;
     const bool emptyA = L[endA] < kMinReadLen, emptyB = L[endB] < kMinReadLen;
     if (emptyA && emptyB) {
@@ -674,22 +703,26 @@ template <bool BIG> struct PeWave {
       heap_order_now(1);
     }
     ABM_STAMP(t0);
-    // best_single: every entry of each set, in array order, into that end's single-end set
     const int ends[2] = {endA, endB};
-    #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      SeSet &S = se[ends[which]];
-      const int n = lsz[which];
-      for (int k0 = 0; k0 < n && !S.sure_ambig; k0 += 64) {
-        const int i = k0 + lane_id();
-        const int dl = i < n ? ld_list<BIG>(pl.ld[which] + i) : 0;
-        const u32 pv = i < n ? ld_list<BIG>(pl.lpos[which] + i) : 0u;
-        const int m = min(64, n - k0);
-        for (int k = 0; k < m && !S.sure_ambig; ++k) {
-          S.admit(false, rdlane(dl, k), lflags[which], rdlane(pv, k));
-          ++wt.updates;
-        }
+    if (BIG) {
+      // best_single is only ever needed if the pair ends up without a reportable concordant hit,
+      // which is rare; tier 2 keeps each call's two lists in a per-wave log and replays them into
+      // the single-end sets only then (replay_singles), in the same order
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const int seg = 2 * O + which, n = lsz[which];
+        u32 *lp = log_pos(seg);
+        i16 *ldv = log_d(seg);
+        for (int i = lane_id(); i < n; i += 64) { lp[i] = pl.lpos[which][i]; ldv[i] = pl.ld[which][i]; }
+        if (lane_id() == 0) { u32 *h = log_head(seg); h[0] = static_cast<u32>(n); h[1] = lflags[which]; h[2] = static_cast<u32>(ends[which]); }
       }
+      __syncthreads();
+    }
+    else {
+      // best_single: every entry of each set, in array order, into that end's single-end set
+#pragma unroll
+      for (int which = 0; which < 2; ++which)
+        feed_single(se[ends[which]], pl.lpos[which], pl.ld[which], lsz[which], lflags[which]);
     }
     ABM_STAMP(t1);
     if (TIMED) t_single += t1 - t0;
@@ -738,6 +771,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   lds.G = a.G;
 
   w.P.heap = w.pl.heap;
+  w.log_base = BIG ? a.log_ws + static_cast<u64>(blockIdx.x) * (32ull + 12ull * a.cap) : nullptr;
   // scratch table for permuting a list: global for tier 2; tier 1 borrows the window cache (idle outside seed passes)
   static_assert(kPeTier1Cap * 4 <= (8u << kPosCacheBits), "tier-1 scratch table must fit the window cache");
   w.pl.tmp = BIG ? a.payload_ws + static_cast<u64>(blockIdx.x) * a.cap : reinterpret_cast<u32 *>(lds.pcache);
@@ -787,6 +821,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     w.se[0].begin_read(w.L[0] >= kMinReadLen ? w.L[0] : 0u);
     w.se[1].begin_read(w.L[1] >= kMinReadLen ? w.L[1] : 0u);
     w.need_big = false;
+    if (BIG && lane < 8) w.log_head(lane)[0] = 0;  // no list logged yet for this pair
     w.max_set = 0;
     long long t_pair = 0;
     ABM_STAMP(t_pair);
@@ -796,15 +831,15 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     bool any = false;
     // orientation(endA, alphabet): src/abismal.cpp:1963-1979, :2106-2133
     if (a.mode == 2) {
-      any |= w.template orientation<TIMED>(0, false, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED>(1, true, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED>(0, true, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED>(1, false, r, best);
+      any |= w.template orientation<TIMED, 0>(0, false, r, best);
+      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 1>(1, true, r, best);
+      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 2>(0, true, r, best);
+      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 3>(1, false, r, best);
     }
     else {
       const bool ar = a.mode == 1;
-      any |= w.template orientation<TIMED>(0, ar, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED>(1, !ar, r, best);
+      any |= w.template orientation<TIMED, 0>(0, ar, r, best);
+      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 1>(1, !ar, r, best);
     }
     if (w.need_big && !BIG) {
       if (lane == 0) a.need_big[r] = 1;
@@ -825,6 +860,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     h1.diffs = static_cast<i16>(0.4 * w.L[0]); h1.flags = 0; h1.pos = 0;
     h2.diffs = static_cast<i16>(0.4 * w.L[1]); h2.flags = 0; h2.pos = 0;
     if (!best.should_report(a.allow_ambig != 0)) {  // single-end fallback at half the error budget
+      if (BIG) { __syncthreads(); w.replay_singles(); }
       long long tf0 = 0, tf1 = 0;
       ABM_STAMP(tf0);
       #pragma unroll

@@ -355,18 +355,47 @@ template <bool BIG> struct PeWave {
     while (m < n) m <<= 1;
     for (int i = lane; i < m; i += 64) buf[i] = i < n ? ld_list<BIG>(pl.lpos[which] + i) : 0xFFFFFFFFu;
     __syncthreads();
-    for (int k = 2; k <= m; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = lane; i < m; i += 64) {
-          const int p = i ^ j;
-          if (p > i) {
-            const u32 x = buf[i], y = buf[p];
-            const bool up = (i & k) == 0;
-            if ((x > y) == up) { buf[i] = y; buf[p] = x; }
-          }
+    // one compare-exchange pass of the bitonic network at distance j inside stage k, over
+    // elements [0, cnt) of `v` whose global indices start at `base`
+    auto pass = [&](u32 *v, int cnt, int base, int k, int j) {
+      for (int i = lane; i < cnt; i += 64) {
+        const int p = i ^ j;
+        if (p > i) {
+          const u32 x = v[i], y = v[p];
+          const bool up = ((base + i) & k) == 0;
+          if ((x > y) == up) { v[i] = y; v[p] = x; }
         }
-        __syncthreads();
       }
+      __syncthreads();
+    };
+    if (!BIG) {
+      for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) pass(buf, m, 0, k, j);
+    }
+    else {
+      // tier 2: the buffer is in global memory.  Every pass at distance j < C only pairs elements
+      // of the same aligned block of C, so those passes run on a copy of the block in LDS (the
+      // window slots and the window cache are idle here); only distances >= C touch global memory.
+      u32 *blk = reinterpret_cast<u32 *>(lds.gwin);
+      int C = 256;
+      while (2 * C <= static_cast<int>(2 * (kMaxJobs * lds.GW + (1u << kPosCacheBits))) && 2 * C <= m) C <<= 1;
+      if (C > m) C = m;
+      auto local = [&](int k_from, int k_to, int j_top) {  // stages k_from..k_to, distances j_top..1, block by block
+        for (int b = 0; b < m; b += C) {
+          for (int i = lane; i < C; i += 64) blk[i] = buf[b + i];
+          __syncthreads();
+          for (int k = k_from; k <= k_to; k <<= 1)
+            for (int j = min(k >> 1, j_top); j > 0; j >>= 1) pass(blk, C, b, k, j);
+          for (int i = lane; i < C; i += 64) buf[b + i] = blk[i];
+          __syncthreads();
+        }
+      };
+      local(2, C, C >> 1);  // stages that fit a block entirely
+      for (int k = 2 * C; k <= m; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) pass(buf, m, 0, k, j);
+        local(k, k, C >> 1);
+      }
+    }
     // unique + recompute diffs
     const WaveLds w = lds_of(end);
     const u64 *qpk = w.qpk + enc_of(lflags[which]) * w.W;

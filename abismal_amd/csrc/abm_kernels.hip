@@ -7,7 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #ifndef ABM_SE_WAVES_PER_SIMD
-#define ABM_SE_WAVES_PER_SIMD 4  // 128 VGPRs per lane: the candidate filter keeps 8 rounds of window loads in flight
+#define ABM_SE_WAVES_PER_SIMD 5  // 96 VGPRs per lane, 20 waves per CU
 #endif
 
 namespace abm {
@@ -345,11 +345,11 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
                                                    se_lds_bytes(W, WB, cig_stride, max_len, valid_frac)) != hipSuccess)
     return 0;
   // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): the kernel is bound by
-  // the random line requests a CU can keep outstanding.  With one lane per candidate window the optimum
-  // was 20 waves per CU (more only evicted each other's lines from L1/L2); with cooperative window loads
-  // 16 waves per CU at 128 registers each beat 20 waves at 96 registers with spills
-  // (1037 ms vs 1387 ms for 10 M reads; 14 waves: 1116 ms).
-  constexpr int kSeWavesPerCu = 16;
+  // the random line requests a CU can keep outstanding, and what matters is waves without register
+  // spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
+  // window loads with 8 rounds in flight, 16 waves at 128 registers 1029 ms (20 waves at 96 with spills:
+  // 1386); with 2 rounds in flight 20 waves fit almost without spills: 923 ms (24 waves: 999).
+  constexpr int kSeWavesPerCu = 20;
   return min(per_cu, kSeWavesPerCu) * prop.multiProcessorCount;
 }
 

@@ -306,7 +306,8 @@ __device__ __forceinline__ void hamming2(const u64 *__restrict__ genome, const u
 // coalesce into one or two line requests.  Each lane counts the mismatches of its two words (the
 // word after them comes from the next lane), the group adds up, and the sums travel through LDS
 // to the lanes that own the candidates.  The 128 candidates of a step are slots 0..63 (lane's
-// first) and 64..127 (lane's second); 64/G of them are fetched per round, 8 rounds in flight.
+// first) and 64..127 (lane's second); 64/G of them are fetched per round, kCoopRounds rounds in
+// flight (few: registers are better spent on a fifth wave per SIMD).
 __device__ __forceinline__ int dpp_row_shl1(int v) {  // lane i <- lane i+1 within a row of 16 (last lane: 0)
   return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, false);
 }
@@ -316,6 +317,10 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
   if (G == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false);
   return v;
 }
+#ifndef ABM_COOP_ROUNDS
+#define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (scripts/se_variant.sh): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
+#endif
+constexpr u32 kCoopRounds = ABM_COOP_ROUNDS;  // rounds of window loads in flight per lane
 __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, const WaveLds &lds, const u64 *qpk,
                                              u32 nwords, u32 pos_a, bool want_a, u32 pos_b, bool want_b,
                                              int &d_a, int &d_b) {
@@ -324,13 +329,13 @@ __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, con
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
   const bool has0 = 2 * sub < nwords, has1 = 2 * sub + 1 < nwords;
   const u64 q0 = has0 ? qpk[2 * sub] : 0ull, q1 = has1 ? qpk[2 * sub + 1] : 0ull;
-  for (u32 pass = 0; pass * 8 * per_round < 128; ++pass) {
-    u64 x0[8], x1[8];
+  for (u32 pass = 0; pass * kCoopRounds * per_round < 128; ++pass) {
+    u64 x0[kCoopRounds], x1[kCoopRounds];
     u32 shifts = 0;  // (pos & 15) of the eight rounds' candidates, four bits each
 #pragma unroll
-    for (u32 r = 0; r < 8; ++r) {
-      const u32 slot = (pass * 8 + r) * per_round + grp;  // < 128; a round lies entirely in one half
-      const bool second = (pass * 8 + r) * per_round >= 64;
+    for (u32 r = 0; r < kCoopRounds; ++r) {
+      const u32 slot = (pass * kCoopRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
+      const bool second = (pass * kCoopRounds + r) * per_round >= 64;
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
       shifts |= (cp & 15u) << (4 * r);
@@ -343,8 +348,8 @@ __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, con
       }
     }
 #pragma unroll
-    for (u32 r = 0; r < 8; ++r) {
-      const u32 slot = (pass * 8 + r) * per_round + grp;
+    for (u32 r = 0; r < kCoopRounds; ++r) {
+      const u32 slot = (pass * kCoopRounds + r) * per_round + grp;
       const u32 sh = ((shifts >> (4 * r)) & 15u) << 2;
       // the word after this lane's pair is the next lane's first word
       const u64 x2 = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r] >> 32)))) << 32) |

@@ -32,6 +32,17 @@ traffic = {"round": rnd, "kernel": "map_se_kernel",
                    "per read)." % tag}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv"))))[:6]
+calls_note = ""
+cpath = os.path.join(src, "map_se_calls.csv")
+if os.path.exists(cpath):
+    shutil.copy(cpath, os.path.join(dst, f"{tag}_map_se_calls.csv"))
+    cr = list(csv.DictReader(open(cpath)))
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in cr]
+    if len(durs) > line["steps"]:
+        timed = durs[-line["steps"]:]
+        calls_note = (f"  Per launch (`{tag}_map_se_calls.csv`): " + ", ".join(f"{d:.1f}" for d in durs) +
+                      f" ms -- every step maps a different batch; the first launch is the warm-up, and the {line['steps']} timed "
+                      f"launches average {sum(timed) / len(timed):.1f} ms in the rocprofv3 trace.")
 rf, cb = line["roofline"], line["cpu_baseline"]
 with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
     f.write(f"# Round {rnd} profiles\n\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py` (default flags: 3100 Mbp "
@@ -42,7 +53,7 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
     f.write(f"\nbench.py's own line from that run (`{tag}_bench_line_under_rocprof.json`): value {line['value']:.0f} reads/s, HIP-event "
             f"average of map_se_kernel {rf['avg_kernel_ms']} ms (compare the rocprofv3 average above), algorithmic {rf['achieved']} GB/s = "
             f"{rf['frac']} of 8 TB/s, cpu_baseline {cb['value']} reads/s on {cb['cores']} threads ({cb['positions_identical_to_gpu']} "
-            "positions identical).\n\n"
+            "positions identical)." + calls_note + "\n\n"
             f"HBM traffic (`{tag}_traffic.json`, separate `--pmc` pass, `{tag}_pmc_rdreq_map_se.csv`): {nbytes / 1e12:.2f} TB of 128-byte "
             f"line reads per launch = {nbytes / secs / 1e12:.2f} TB/s during the kernel ({secs * 1e3:.0f} ms under the counters).\n\n"
             "Work per read in that run: " + ", ".join(f"{k} {v}" for k, v in line["work_per_read"].items()) + ".\n\n"

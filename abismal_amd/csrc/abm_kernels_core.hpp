@@ -506,16 +506,28 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     // Candidates are taken 128 at a time, two per lane (c0+lane and c0+64+lane): both index entries,
     // then both genome windows, are in flight together, which halves the dependent round trips of a
     // read with very many candidates.  The set still sees them strictly in the reference's order.
+    // The index entries of the NEXT 128 candidates are requested before this step's windows, so a
+    // step costs one dependent memory round trip instead of two (what a read with millions of
+    // candidates -- one wave, no other latency hiding at the end of a launch -- is made of).
+    bool nva = false, nvb = false;
+    int noa = 0, nob = 0;
+    u32 nea = 0, neb = 0;
+    auto fetch_entries = [&](u32 c0) {
+      bool ta3, tb3 = false;
+      u32 ea_at, eb_at = 0;
+      nvb = false; nob = 0; nea = 0; neb = 0;
+      locate(c0, nva, noa, ea_at, ta3);
+      if (c0 + 64 < total) locate(c0 + 64, nvb, nob, eb_at, tb3);
+      if (nva) nea = ta3 ? idx3[ea_at] : ix.index[ea_at];
+      if (nvb) neb = tb3 ? idx3[eb_at] : ix.index[eb_at];
+    };
+    if (total) fetch_entries(0);
     for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
       ABM_STAMP(tc);
-      bool va, vb = false, ta3, tb3 = false;
-      int oa, ob = 0;
-      u32 ea_at, eb_at = 0;
-      locate(c0, va, oa, ea_at, ta3);
-      if (c0 + 64 < total) locate(c0 + 64, vb, ob, eb_at, tb3);
-      u32 ea = 0, eb = 0;
-      if (va) ea = ta3 ? idx3[ea_at] : ix.index[ea_at];
-      if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
+      const bool va = nva, vb = nvb;
+      const int oa = noa, ob = nob;
+      const u32 ea = nea, eb = neb;
+      if (c0 + 128 < total) fetch_entries(c0 + 128);
       const u32 pa = ea - (g0 + static_cast<u32>(oa)), pb = eb - (g0 + static_cast<u32>(ob));
       // the same genome position is proposed again and again (neighbouring seeds of one hit, the
       // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)

@@ -112,6 +112,9 @@ struct abm_ctx {
   DevBuf<unsigned long long> work;
   DevBuf<unsigned long long> next_read;
   unsigned launch_seq = 0;
+  // every device entry point reuses this context's workspaces: a call first makes its stream wait for
+  // the previous call's work (whatever stream that ran on), so consecutive calls never overlap
+  hipEvent_t last_done = nullptr;
   std::map<uint64_t, int> se_waves;
   // staging for the host-buffer entry points
   DevBuf<char> blob;
@@ -160,6 +163,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (cig_stride == 0) throw std::invalid_argument("cig_stride must be > 0");
   if (n == 0) return;
   HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamWaitEvent(st, ctx->last_done, 0));
   const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kMaxReadLen);
   const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
   ctx->packed.reserve(n * 4 * W);
@@ -221,6 +225,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
   HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventRecord(ctx->last_done, st));
 }
 
 // fixed CIGAR slots on the device -> compact blob + offsets in the caller's host buffers.  Offsets
@@ -267,6 +272,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (n == 0) return;
   if (n >= (1ull << 32)) throw std::invalid_argument("batch too large (>= 2^32 pairs)");
   HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamWaitEvent(st, ctx->last_done, 0));
   const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kMaxReadLen);
   const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
   ctx->packed.reserve(n * 4 * W);
@@ -348,6 +354,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, ctx->phase_stamps, st));
     if (e1) HIPCHK(hipEventRecord(e1, st));
   }
+  HIPCHK(hipEventRecord(ctx->last_done, st));
 }
 
 }  // namespace
@@ -449,6 +456,7 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
         c->kernel_turn = &rep.kernel_turn;
       }
       HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming));
       HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->drained), sizeof(abm::u32), hipHostMallocMapped | hipHostMallocCoherent));
       *c->drained = 0;
       c->work.reserve(32);
@@ -463,6 +471,7 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->last_done) (void)hipEventDestroy(c->last_done);
   if (c->drained) (void)hipHostFree(c->drained);
   if (c->holds_replica && c->ix) {
     std::lock_guard<std::mutex> lk(c->ix->mu);

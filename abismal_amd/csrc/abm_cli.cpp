@@ -864,6 +864,11 @@ int cmd_map(int argc, char **argv) {
       lk.unlock();
       const auto t0 = now();
       for (const std::string &part : b->parts) out.write(part.data(), static_cast<std::streamsize>(part.size()));
+      if (!out) {  // a full disk must not end in a truncated file and exit code 0
+        lk.lock();
+        if (!failure) failure = std::make_exception_ptr(std::runtime_error("failed writing output file: " + opt.out));
+        break;
+      }
       total_records += b->n();
       for (const Stats3 &ps : b->part_stats)
         for (int k = 0; k < 3; ++k)
@@ -882,16 +887,34 @@ int cmd_map(int argc, char **argv) {
     out.write(reinterpret_cast<const char *>(eof_block), 28);
   }
   out.close();
+  if (!out) throw std::runtime_error("failed writing output file: " + opt.out);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
-  // statistics: one RCCL all-reduce over the GPUs that took part
-  std::vector<uint64_t *> ptrs;
-  for (auto &s : gpu_stats) ptrs.push_back(&s.s[0].v[0]);
+  // statistics (6 counters x 3 structs, src/abismal.cpp:865-895, :1034-1037).  Every GPU's counters
+  // already sit in this process, so the total is a host sum; with more than one GPU the same sum is
+  // also taken with the path's one collective (RCCL all-reduce over xGMI, abm_stats_allreduce) and
+  // the two must agree.  A collective that cannot run (no RCCL transport on this box) costs a
+  // warning, never the statistics file of a finished run.
   static_assert(sizeof(Stats3) == 18 * sizeof(uint64_t), "18 counters");
-  std::vector<abm_ctx *> primary;
-  for (int g = 0; g < n_gpus; ++g) primary.push_back(ctxs[static_cast<size_t>(g) * per_gpu]);
-  if (abm_stats_allreduce(primary.data(), n_gpus, ptrs.data()) != 0) die_abm("stats all-reduce");
-  const Stats3 &tot = gpu_stats[0];
+  Stats3 tot;
+  for (const Stats3 &g : gpu_stats)
+    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 6; ++j) tot.s[k].v[j] += g.s[k].v[j];
+  if (n_gpus > 1 && !std::getenv("ABM_CLI_NO_RCCL")) {
+    std::vector<Stats3> reduced(gpu_stats);
+    std::vector<uint64_t *> ptrs;
+    for (auto &s : reduced) ptrs.push_back(&s.s[0].v[0]);
+    std::vector<abm_ctx *> primary;
+    for (int g = 0; g < n_gpus; ++g) primary.push_back(ctxs[static_cast<size_t>(g) * per_gpu]);
+    if (abm_stats_allreduce(primary.data(), n_gpus, ptrs.data()) != 0)
+      std::cerr << "[abismal-amd] warning: RCCL statistics all-reduce failed (" << abm_last_error() << "); using the host sum\n";
+    else {
+      for (int g = 0; g < n_gpus; ++g)
+        if (std::memcmp(&reduced[g], &tot, sizeof(Stats3)) != 0)
+          throw std::runtime_error("statistics all-reduce disagrees with the host sum on GPU " + std::to_string(g));
+      if (opt.verbose) std::cerr << "[abismal-amd] statistics summed over " << n_gpus << " GPUs with one RCCL all-reduce\n";
+    }
+  }
   if (!opt.stats.empty()) {
     std::ofstream so(opt.stats);
     if (!so) std::cerr << "failed to open stats out file: " << opt.stats << '\n';
@@ -901,6 +924,8 @@ int cmd_map(int argc, char **argv) {
     }
     else if (!paired) so << tot.s[0].yaml("read1");
     else { so << tot.s[0].yaml("pairs"); if (!opt.ambig) so << tot.s[1].yaml("read1") << tot.s[2].yaml("read2"); }
+    so.close();
+    if (!so) throw std::runtime_error("failed writing stats file: " + opt.stats);
   }
   if (opt.verbose)
     std::cerr << "[abismal-amd] " << total_records << (paired ? " pairs" : " reads") << " on " << n_gpus << " GPU(s) in "

@@ -68,7 +68,10 @@ int pe_resident_waves(size_t lds, bool big);
 hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st);
 hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *class33, u32 *subset, u32 *count,
                               hipStream_t st);
-constexpr u32 kPeTier1Cap = 128;
+#ifndef ABM_PE_TIER1_CAP
+#define ABM_PE_TIER1_CAP 128
+#endif
+constexpr u32 kPeTier1Cap = ABM_PE_TIER1_CAP;
 
 u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);

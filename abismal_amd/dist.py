@@ -29,3 +29,20 @@ def reduce_stats(stats_tensor, elapsed_tensor=None):
     if elapsed_tensor is not None:
         dist.all_reduce(elapsed_tensor, op=dist.ReduceOp.MAX)
     return stats_tensor, elapsed_tensor
+
+
+def ranks_and_rates(n_reads_rank, elapsed_rank):
+    """(ranks that took part, [reads/s of every rank]) -- an all-reduced 1 and an all-gather of each
+    rank's own rate; (1, [own rate]) without a process group."""
+    import torch
+    import torch.distributed as dist
+    own = n_reads_rank / elapsed_rank if elapsed_rank > 0 else 0.0
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1, [round(own, 1)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([own], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return int(one.item()), [round(float(t.item()), 1) for t in every]

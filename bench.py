@@ -14,7 +14,12 @@ abm_map_se_device) over one batch of --reads reads already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch with torch.distributed.run (one rank per GPU); reads shard
+With N > 1 and no launcher in the environment this script starts the N ranks
+itself: the parent only parses the arguments and spawns N fresh worker
+processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment)
+before it has made any GPU call, forwards rank 0's JSON line and exits with the
+workers' status.  Under `python -m torch.distributed.run --nproc-per-node N`
+the same workers run directly (WORLD_SIZE must then equal --gpus).  Reads shard
 across ranks with the index replicated per GPU; the only collective is the
 end-of-run RCCL all-reduce of the mapping statistics.
 """
@@ -237,7 +242,7 @@ def sample_reads(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, c
 def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier):
     """Paired-end measurement (abm_map_pe_device); same timing protocol as the SE path."""
     import torch
-    from abismal_amd.dist import reduce_stats
+    from abismal_amd.dist import reduce_stats, ranks_and_rates
     n, L = args.reads, args.read_len
     b1, b2 = sample_pairs(genome_words, starts, n, L, 2000 + rank, dev)
     off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
@@ -324,6 +329,7 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     fallback = (~concordant).unsqueeze(1) & torch.stack([se1[:, 1] != 0, se2[:, 1] != 0], 1)
     stats = torch.tensor([n, int(concordant.sum()), int(fallback.sum()), 0, 0, 0], dtype=torch.int64, device=dev)
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ranks_seen, rank_rates = ranks_and_rates(2 * n * args.steps, elapsed)
     reduce_stats(stats, t_el)
     if rank != 0:
         return
@@ -348,13 +354,80 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                "pair_positions_identical_to_gpu": f"{same}/{ns}"}
     print(json.dumps({
         "metric": "mapped reads/sec (whole node), paired-end", "value": round(2 * n * args.steps * world / elapsed, 1),
-        "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen, "per_rank_reads_per_s": rank_rates,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step",
                    "streams": len(slots)},
         "cpu_baseline": cpu, "kernel_status": int(status.item()), "phase_stamps": diag,
         "mapping": {"pairs": int(stats[0]), "concordant": int(stats[1]), "ends_mapped_single": int(stats[2])}}), flush=True)
+
+
+# --------------------------------------------------------------------------- launcher
+def launch_ranks(n_ranks):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: spawns one fresh worker
+    process per GPU and waits.  Nothing here touches the GPU (no torch import, no HIP call): a
+    process that has initialised the GPU must never be replaced or forked on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ABM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[bench] rank {procs.index(p)} exited with {code}; stopping the others", file=sys.stderr, flush=True)
+                    for q in live:
+                        q.terminate()  # exact PIDs we started
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dist_dry_run(args, rank, world):
+    """--dist-dry-run: the launcher, the rendezvous and the statistics collective with the gloo backend
+    and made-up counters -- what the CPU test suite can exercise of the N > 1 path without a GPU."""
+    import torch
+    import torch.distributed as dist
+    from abismal_amd.dist import reduce_stats, ranks_and_rates, shard_bounds
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = args.reads
+    lo, hi = shard_bounds(n * world, rank, world)
+    ids = torch.arange(lo, hi, dtype=torch.int64)
+    stats = torch.stack([torch.tensor(hi - lo), (ids % 3 == 0).sum(), (ids % 7 == 0).sum(), (ids % 11 == 0).sum(),
+                         ids.sum(), (ids * 100).sum()]).to(torch.int64)
+    elapsed = 0.5 + 0.25 * rank
+    t_el = torch.tensor([elapsed], dtype=torch.float64)
+    ranks_seen, rates = ranks_and_rates(n * args.steps, elapsed)
+    reduce_stats(stats, t_el)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the multi-GPU plumbing (no mapping)", "value": n * args.steps * world / float(t_el),
+                          "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+                          "warmup": args.warmup, "per_rank_reads_per_s": rates, "dry_run": True, "backend": "gloo",
+                          "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
+                                      "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------- main
@@ -379,45 +452,63 @@ def main():
     ap.add_argument("--phase-stamps", action="store_true",
                     help="after the timed region, run one extra step of the diagnostic kernel and report phase shares")
     ap.add_argument("--workdir", default=os.environ.get("ABM_BENCH_DIR", "/tmp/abismal_bench"))
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
     args = ap.parse_args()
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (this process never touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         "pass --gpus equal to --nproc-per-node (or run plain `python bench.py --gpus N`)")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dist_dry_run:
+        return dist_dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
     import abismal_amd as A
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the mapping path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     os.makedirs(args.workdir, exist_ok=True)
     tag = f"g{int(args.genome_mbp)}"
     fasta = os.path.join(args.workdir, tag + ".fa")
     idx = os.path.join(args.workdir, tag + ".idx")
     t_build = 0.0
+    # the index file is shared: rank 0 builds it (once per box), the others wait for the FILE -- no rank
+    # sits in a collective while another works for minutes
     if rank == 0 and not os.path.exists(idx):
         t0 = time.time()
         synth_genome_fasta(fasta, args.genome_mbp, 1234, dev)
         log(f"synthetic genome written in {time.time() - t0:.1f}s")
         t0 = time.time()
         A.index_build(fasta, idx + ".tmp", os.cpu_count() or 1)
-        os.replace(idx + ".tmp", idx)
+        os.replace(idx + ".tmp", idx)  # atomic: a waiting rank never sees a partial file
         t_build = time.time() - t0
         log(f"index built in {t_build:.1f}s ({os.path.getsize(idx) / 1e9:.2f} GB)")
         os.remove(fasta)
-    barrier()
+    t_wait = time.time()
+    while not os.path.exists(idx):
+        if time.time() - t_wait > 3600:
+            raise SystemExit(f"bench.py: rank {rank} waited an hour for {idx}")
+        time.sleep(0.5)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
     t0 = time.time()
     index = A.Index(idx)
@@ -500,7 +591,8 @@ def main():
     stats = torch.tensor([n, int(uniq.sum()), int(ambig.sum()), n_skipped, int(diffs[uniq].sum()),
                           int(bases[uniq].sum())], dtype=torch.int64, device=dev)
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    from abismal_amd.dist import reduce_stats
+    from abismal_amd.dist import reduce_stats, ranks_and_rates
+    ranks_seen, rank_rates = ranks_and_rates(n * args.steps, elapsed)
     reduce_stats(stats, t_el)  # the path's single collective: RCCL sum of the counters (+ max of the time)
     elapsed = float(t_el.item())
     st_host = int(status.item())
@@ -561,7 +653,8 @@ def main():
 
     line = {
         "metric": "mapped reads/sec (whole node), 100 bp SE on hg38-scale index",
-        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
+        "per_rank_reads_per_s": rank_rates, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",

@@ -92,7 +92,12 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
  * is then set) means the slot is incomplete: the hit itself is exact, and mapping
  * that read again with cig_stride >= max_len + 2 yields its CIGAR, which is what
  * the host-buffer entry points do.  d_status (one uint32) is OR-ed with
- * ABM_STATUS_* bits. max_len = longest read in the batch. */
+ * ABM_STATUS_* bits. max_len = longest read in the batch.
+ * A context owns ONE set of workspaces: a device call first makes `stream` wait
+ * for the context's previous device call (on whatever stream that ran), so calls
+ * on one context execute one after the other; use one context per stream to
+ * overlap batches.  Growing a workspace frees the old one, which synchronises
+ * the device once -- size-stable batches never pay that. */
 int abm_map_se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                       const char *d_seq_blob, const uint64_t *d_seq_off, uint32_t max_len,
                       abm_hit *d_res, uint32_t *d_cig, uint32_t cig_stride, uint32_t *d_cig_n,

@@ -25,6 +25,10 @@ for _ in range(2):
 c = rc.cpu().numpy().astype(np.float64) * 1024 / 2.1e3  # microseconds at 2.1 GHz
 print("per-read us: mean %.1f p50 %.1f p90 %.1f p99 %.1f p99.9 %.1f max %.1f ; sum %.2f s; top-100 sum %.3f s" % (
     c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), np.percentile(c, 99.9), c.max(), c.sum() / 1e6, np.sort(c)[-100:].sum() / 1e6))
+edges = [0, 10, 30, 100, 300, 1000, 3000, 10000, 30000, 100000, 1e9]
+for lo_, hi_ in zip(edges[:-1], edges[1:]):
+    sel = (c >= lo_) & (c < hi_)
+    print("  reads with %7.0f <= us < %7.0f : %9d reads, %8.3f wave-seconds (%.1f %%)" % (lo_, hi_, int(sel.sum()), c[sel].sum() / 1e6, 100 * c[sel].sum() / c.sum()))
 worst = np.argsort(c)[-8:][::-1]
 o = ob.load(); oix = o.index_load(idx)
 host = blob.cpu().numpy().reshape(n, L)

@@ -450,7 +450,9 @@ def main():
                     help="SE: number of different synthetic batches the steps cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-stamps", action="store_true",
-                    help="after the timed region, run one extra step of the diagnostic kernel and report phase shares")
+                    help="after the timed region, run one extra step of the diagnostic kernel and report phase shares "
+                         "(single-end: on by default at N=1, see --no-stage-split)")
+    ap.add_argument("--no-stage-split", action="store_true", help="single-end: skip the per-stage roofline rows")
     ap.add_argument("--workdir", default=os.environ.get("ABM_BENCH_DIR", "/tmp/abismal_bench"))
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
@@ -566,16 +568,6 @@ def main():
     launches, kernel_ms = ctx.take_kernel_time()
     work = ctx.take_work()
     ctx.set_timing(False)
-    phases = None
-    if args.phase_stamps:
-        ctx.set_phase_stamps(True)
-        step()
-        torch.cuda.synchronize()
-        pc = ctx.take_work().get("phase_cycles")
-        ctx.set_phase_stamps(False)
-        if pc:
-            phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
-
     blob = blobs[(issued[0] - 1) % n_batches]  # the batch whose results the output buffers hold
     # mapping statistics (six counters, src/abismal.cpp:865-895) reduced over ranks
     pos = res[:, 1]
@@ -604,34 +596,50 @@ def main():
 
     total_reads = n * args.steps * world
     value = total_reads / elapsed
+    # ---- roofline of the dominant kernel (map_se_kernel), HBM-bound ------------------------------
     # algorithmic bytes per read:
     #   L + S*16 + P*4.5 + C*4 + (W+C)*8 + A*(L+bw)/2 + 8*(1+ops/2)
+    # S seed offsets probed, P narrowing probes, C candidates compared, W read words compared,
+    # A alignments, ops CIGAR ops written.  Two sets of counts are reported:
+    #  * "kernel tally": what the kernel itself did in the timed launches -- every candidate's full
+    #    window (no early exit: W = ceil(L/16) per candidate), minus the candidates served by the
+    #    per-call position cache (no window fetched for them);
+    #  * "strict": the counts of the reference algorithm -- the oracle's counters on the cpu-baseline
+    #    sample of this very batch, full_compare's early exit included (W = words touched before the
+    #    running sum passes the cutoff).  `achieved`/`frac` use the strict figure when it is available.
     per_launch = {k: v / max(1, launches) for k, v in work.items() if not isinstance(v, dict)}
     bw_band = 2 * int(0.1 * L) + 1
-    tot_ops = float(cig_n[mapped].sum().item())
-    alg_bytes = (n * L + per_launch["seed_offsets"] * 16 + per_launch["search_probes"] * 4.5 +
-                 per_launch["candidates"] * 4 + (per_launch["read_words"] + per_launch["candidates"]) * 8 +
-                 per_launch["alignments"] * (L + bw_band) / 2 + 8 * (n + tot_ops / 2))
+    nwords = (L + 15) // 16
+    ops_per_read = float(cig_n[mapped].sum().item()) / n
+
+    def alg_bytes_per_read(S, P, C, W, Aln, ops, C_windows=None):
+        Cw = C if C_windows is None else C_windows  # candidates whose genome window was fetched
+        stage = {"probe_narrow": L + S * 16 + P * 4.5,
+                 "filter": C * 4 + (W + Cw) * 8,
+                 "align": Aln * (L + bw_band) / 2 + 8 * (1 + ops / 2)}
+        return sum(stage.values()), stage
+
+    fetched = per_launch["candidates"] - per_launch["window_cache_hits"]
+    k_bytes, k_stage = alg_bytes_per_read(per_launch["seed_offsets"] / n, per_launch["search_probes"] / n,
+                                          per_launch["candidates"] / n, fetched * nwords / n,
+                                          per_launch["alignments"] / n, ops_per_read, C_windows=fetched / n)
+    n_long_cigars = int((cig_n > stride).sum().item())
     avg_ms = kernel_ms / max(1, launches)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    # HBM bytes per launch come from a separate rocprofv3 --pmc pass over this same command
+    # L2->fabric read requests per launch come from a separate rocprofv3 --pmc pass over this same command
     # (profiles/r*_traffic.json, newest round first); reported only when the workload matches
-    traffic = None
+    traffic, traffic_source = None, None
     for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         t = json.load(open(os.path.join(ROOT, "profiles", tf)))
         wl = t.get("workload", {})
         if (wl.get("genome_mbp"), wl.get("reads"), wl.get("read_len")) == (int(args.genome_mbp), n, L):
             traffic = t["hbm_read_bytes_per_launch"]
+            traffic_source = (f"profiles/{tf}: NOT measured in this run -- a separate rocprofv3 --pmc pass of the same command "
+                              f"(build {t.get('build', 'n/a')}); TCC_EA0_RDREQ_sum x 128 B = read requests the L2s sent to the "
+                              "fabric, Infinity-Cache hits included, so an upper bound on HBM bytes")
             break
-    roofline = {"bound": "hbm", "kernel": "map_se_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
-                "avg_kernel_ms": round(avg_ms, 3), "alg_bytes_per_read": round(alg_bytes / n, 1),
-                "gathers_per_s": round((per_launch["seed_offsets"] * 2 + per_launch["candidates"] * 2 +
-                                        per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
 
-    cpu = None
+    cpu, strict = None, None
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
         from tests import oracle_binding as ob  # cpu_baseline leg: the oracle is the thing timed here
         o = ob.load(build=not os.path.exists(ob.LIB))
@@ -642,14 +650,94 @@ def main():
         oix = o.index_load(idx)
         cores = os.cpu_count() or 1
         t0 = time.perf_counter()
-        o_res, o_cig, o_cn, _ = o.map_se(oix, seqs, mode=0, threads=cores, cig_stride=L + 2)
+        o_res, o_cig, o_cn, o_work = o.map_se(oix, seqs, mode=0, threads=cores, cig_stride=L + 2)
         t_cpu = time.perf_counter() - t0
         o.index_free(oix)
+        # full comparison on the sample: position, then diffs + flags, then the CIGAR op for op
         g_res = res[:ns].cpu().numpy().view(np.uint32)
-        same = int((g_res[:, 1] == o_res["pos"]).sum())
+        g_cn = cig_n[:ns].cpu().numpy().view(np.uint32)
+        g_cig = cig[:ns].cpu().numpy().view(np.uint32)
+        g_pos, g_diffs, g_flags = g_res[:, 1], (g_res[:, 0] & 0xFFFF).astype(np.int16), (g_res[:, 0] >> 16).astype(np.uint16)
+        same_pos = g_pos == o_res["pos"]
+        hit = o_res["pos"] != 0
+        same_df = same_pos & (~hit | ((g_diffs == o_res["diffs"]) & (g_flags == o_res["flags"])))
+        k = np.arange(stride, dtype=np.uint32)[None, :]
+        in_slot = g_cn <= stride
+        ops_equal = ((g_cig == o_cig[:, :stride]) | (k >= np.minimum(g_cn, stride)[:, None])).all(1)
+        same_cig = same_df & (~hit | ((g_cn == o_cn) & ops_equal))
+        # CIGARs longer than the device slot: the hit is exact, the ops come from the host entry point
+        long_ids = np.nonzero(hit & ~in_slot)[0]
+        long_ok = 0
+        if len(long_ids):
+            h_res, h_cig, h_off = ctx.map_se([seqs[i] for i in long_ids], mode=A.SE_T_RICH)
+            for j, i in enumerate(long_ids):
+                full = h_cig[int(h_off[j]):int(h_off[j + 1])].tolist()
+                good = same_df[i] and full == o_cig[i, :int(o_cn[i])].tolist() and int(h_res[j]["pos"]) == int(o_res[i]["pos"])
+                same_cig[i] = good
+                long_ok += int(good)
         cpu = {"value": round(ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": f"first {ns} reads of rank 0's batch, oracle restatement, {cores} threads, {t_cpu:.1f}s",
-               "positions_identical_to_gpu": f"{same}/{ns}"}
+               "sample": f"first {ns} reads of rank 0's batch, oracle restatement (-O3 -DNDEBUG), {cores} threads, {t_cpu:.1f}s",
+               "positions_identical_to_gpu": f"{int(same_pos.sum())}/{ns}",
+               "pos_diffs_flags_identical_to_gpu": f"{int(same_df.sum())}/{ns}",
+               "pos_diffs_flags_cigar_identical_to_gpu": f"{int(same_cig.sum())}/{ns}",
+               "long_cigars_checked_through_host_entry_point": f"{long_ok}/{len(long_ids)}"}
+        nr = max(1, o_work["reads"])
+        o_ops = float(o_cn[hit].sum()) / nr
+        s_bytes, s_stage = alg_bytes_per_read(o_work["seed_iters"] / nr, o_work["search_probes"] / nr, o_work["candidates"] / nr,
+                                              o_work["words"] / nr, (o_work["aligns"] + o_work["aligns_tb"]) / nr, o_ops)
+        strict = {"bytes_per_read": s_bytes, "stage": s_stage,
+                  "counts_per_read": {"S": round(o_work["seed_iters"] / nr, 2), "P": round(o_work["search_probes"] / nr, 2),
+                                      "C": round(o_work["candidates"] / nr, 2), "W": round(o_work["words"] / nr, 2),
+                                      "A": round((o_work["aligns"] + o_work["aligns_tb"]) / nr, 2), "ops": round(o_ops, 3)},
+                  "words_per_candidate": round(o_work["words"] / max(1, o_work["candidates"]), 3)}
+
+    # per-stage shares: one more step through the diagnostic (s_memtime-stamped) build of the kernel,
+    # after the timed region; its SHARES are applied to the real kernel's duration
+    phases = None
+    if (args.phase_stamps or (not args.no_stage_split and world == 1)) and rank == 0:
+        ctx.take_work()
+        ctx.set_phase_stamps(True)
+        step()
+        torch.cuda.synchronize()
+        pc = ctx.take_work().get("phase_cycles")
+        ctx.set_phase_stamps(False)
+        if pc:
+            phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
+
+    basis = "strict" if strict else "kernel_tally"
+    use_bytes, use_stage = (strict["bytes_per_read"], strict["stage"]) if strict else (k_bytes, k_stage)
+    achieved = use_bytes * n / (avg_ms * 1e-3) / 1e9
+    k_achieved = k_bytes * n / (avg_ms * 1e-3) / 1e9
+    stages = None
+    if phases:
+        share = {"probe_narrow": phases.get("probe_narrow", 0.0), "filter": phases.get("gather_hamming", 0.0) + phases.get("replay", 0.0),
+                 "align": phases.get("align", 0.0)}
+        stages = []
+        for name in ("probe_narrow", "filter", "align"):
+            ms = share[name] * avg_ms
+            gbps = use_stage[name] * n / (ms * 1e-3) / 1e9 if ms > 0 else None
+            stages.append({"stage": name, "time_share": round(share[name], 4), "ms": round(ms, 2),
+                           "alg_bytes_per_read": round(use_stage[name], 1), "kernel_tally_bytes_per_read": round(k_stage[name], 1),
+                           "achieved_GBps": round(gbps, 1) if gbps else None, "frac": round(gbps / 8000.0, 5) if gbps else None})
+    roofline = {"bound": "hbm", "kernel": "map_se_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "basis": basis,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+                "avg_kernel_ms": round(avg_ms, 3),
+                "alg_bytes_per_read": round(use_bytes, 1),
+                "alg_bytes_per_read_strict": round(strict["bytes_per_read"], 1) if strict else None,
+                "alg_bytes_per_read_kernel_tally": round(k_bytes, 1),
+                "frac_strict": round(strict["bytes_per_read"] * n / (avg_ms * 1e-3) / 1e9 / 8000.0, 5) if strict else None,
+                "frac_kernel_tally": round(k_achieved / 8000.0, 5),
+                "strict_counts_per_read": strict["counts_per_read"] if strict else None,
+                "strict_words_per_candidate": strict["words_per_candidate"] if strict else None,
+                "strict_note": ("S,P,C,W,A,ops per read = the oracle's counters (reference algorithm, early-exit full_compare) on the "
+                                "cpu_baseline sample of this batch; bytes/read x reads per launch / avg kernel time") if strict else None,
+                "stages": stages,
+                "stage_shares_source": "one extra step of the s_memtime-stamped diagnostic kernel after the timed region; "
+                                       "shares applied to avg_kernel_ms (filter = window gather + Hamming + ordered replay)" if stages else None,
+                "gathers_per_s": round((per_launch["seed_offsets"] * 2 + per_launch["candidates"] * 2 +
+                                        per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
 
     line = {
         "metric": "mapped reads/sec (whole node), 100 bp SE on hg38-scale index",
@@ -670,7 +758,7 @@ def main():
         "kernel_status": st_host,
         "kernel_status_note": ("bit 0 = some CIGAR needed more than the %d-op device slot (hits stay exact; the host entry "
                                "point reruns such batches with full-size slots); reads affected: %d" %
-                               (stride, int((cig_n > stride).sum().item()))) if st_host else None,
+                               (stride, n_long_cigars)) if st_host else None,
         "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
     }
     print(json.dumps(line), flush=True)

@@ -1,0 +1,79 @@
+"""Two GPUs (skipped where fewer are visible): the path's one collective and the read sharding.
+ * abm_stats_allreduce over two contexts (RCCL, in-process communicators) == the host sum;
+ * `abismal-amd map -gpus 2` writes the same SAM body and statistics as `-gpus 1`;
+ * `python bench.py --gpus 2` starts two ranks itself and reports ranks_seen == 2."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "abismal_amd", "abismal-amd")
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+needs_two = pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs")
+
+
+@needs_two
+def test_stats_allreduce_two_contexts(trex_index):
+    import abismal_amd as A
+    lib = A.load_library()
+    lib.abm_stats_allreduce.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.POINTER(C.c_uint64))]
+    ix = A.Index(trex_index)
+    ctxs = [A.Context(ix, d) for d in range(2)]
+    try:
+        rng = np.random.default_rng(7)
+        mine = [rng.integers(0, 1 << 40, 18, dtype=np.uint64) for _ in range(2)]
+        want = mine[0] + mine[1]
+        bufs = [m.copy() for m in mine]
+        handles = (C.c_void_p * 2)(*[c.handle for c in ctxs])
+        ptrs = (C.POINTER(C.c_uint64) * 2)(*[b.ctypes.data_as(C.POINTER(C.c_uint64)) for b in bufs])
+        rc = lib.abm_stats_allreduce(handles, 2, ptrs)
+        assert rc == 0, lib.abm_last_error().decode()
+        assert (bufs[0] == want).all() and (bufs[1] == want).all()
+    finally:
+        for c in ctxs:
+            c.close()
+        ix.close()
+
+
+@needs_two
+def test_cli_two_gpus_same_output_as_one(oracle, trex_index, tmp_path):
+    fa = os.path.join(ROOT, "tests", "golden", "tRex1.fa")
+    oracle.simulate(fa, str(tmp_path / "r"), 40000, single_end=True, seed=11)
+    body = {}
+    for g in (1, 2):
+        out, st = tmp_path / f"g{g}.sam", tmp_path / f"g{g}.mstats"
+        # small batches so that both GPUs get several
+        r = subprocess.run([CLI, "map", "-v", "-gpus", str(g), "-batch", "4096", "-s", str(st), "-o", str(out), "-i", trex_index,
+                            str(tmp_path / "r_1.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        if g == 2:
+            assert "one RCCL all-reduce" in r.stderr, r.stderr
+        body[g] = ([ln for ln in open(out) if not ln.startswith("@PG")], open(st).read())
+    assert body[1] == body[2] and len(body[1][0]) > 30000
+
+
+@needs_two
+def test_bench_self_launch_two_gpus(tmp_path):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mbp", "40",
+                        "--reads", "200000", "--no-cpu-baseline", "--workdir", str(tmp_path)], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_reads_per_s"]) == 2
+    assert d["mapping"]["total"] == 2 * 200000
+    assert d["value"] > max(d["per_rank_reads_per_s"])

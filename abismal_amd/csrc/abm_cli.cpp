@@ -475,7 +475,7 @@ std::string Stats::json() const {
 }
 
 struct Options {
-  std::string index, genome, out, stats;
+  std::string index, genome, out, stats, timing;
   bool bam = false, json = false, ambig = false, pbat = false, rpbat = false, arich = false, verbose = false;
   uint32_t max_candidates = 0, min_frag = 32, max_frag = 3000;
   uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));  // host parse/format threads
@@ -512,6 +512,7 @@ Options parse_map(int argc, char **argv) {
     else if (k == "gpus") o.gpus = std::stoi(need(i));
     else if (k == "batch") o.batch = std::stoul(need(i));
     else if (k == "mappers") o.mappers = std::stoi(need(i));
+    else if (k == "timing") o.timing = need(i);  // JSON: reads, seconds (first batch submitted -> last byte written), stage busy times
     else if (k == "z" || k == "bam-level") g_bgzf_level = std::max(0, std::min(9, std::stoi(need(i))));
     else throw std::runtime_error("unknown option " + a);
   }
@@ -545,6 +546,7 @@ int cmd_map(int argc, char **argv) {
     if (abm_index_build(opt.genome.c_str(), index_path.c_str(), std::max(1u, std::thread::hardware_concurrency())) != 0) die_abm("indexing genome");
   }
   abm_index *ix = nullptr;
+  const auto t_index = std::chrono::steady_clock::now();
   if (abm_index_open(index_path.c_str(), &ix) != 0) die_abm("loading index");
   if (opt.index.empty()) std::remove(index_path.c_str());
   Chroms ch;
@@ -567,6 +569,7 @@ int cmd_map(int argc, char **argv) {
     }
   }
   n_gpus = static_cast<int>(ctxs.size()) / per_gpu;
+  const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();  // file -> host -> HBM
 
   std::ofstream out(opt.out, std::ios::binary);
   if (!out) throw std::runtime_error("failed to open output file: " + opt.out);
@@ -926,6 +929,14 @@ int cmd_map(int argc, char **argv) {
     else { so << tot.s[0].yaml("pairs"); if (!opt.ambig) so << tot.s[1].yaml("read1") << tot.s[2].yaml("read2"); }
     so.close();
     if (!so) throw std::runtime_error("failed writing stats file: " + opt.stats);
+  }
+  if (!opt.timing.empty()) {
+    std::ofstream tj(opt.timing);
+    tj << "{\"records\": " << total_records << ", \"reads\": " << (paired ? 2 : 1) * total_records << ", \"seconds\": " << secs
+       << ", \"index_load_s\": " << index_load_s << ", \"gpus\": " << n_gpus << ", \"mappers_per_gpu\": " << per_gpu
+       << ", \"host_threads\": " << n_host << ", \"batch_reads\": " << batch_reads << ", \"busy_s\": {\"split\": " << busy_split
+       << ", \"parse\": " << busy_parse << ", \"map\": " << busy_map << ", \"format\": " << busy_format << ", \"write\": "
+       << busy_write << "}}\n";
   }
   if (opt.verbose)
     std::cerr << "[abismal-amd] " << total_records << (paired ? " pairs" : " reads") << " on " << n_gpus << " GPU(s) in "

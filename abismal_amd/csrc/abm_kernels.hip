@@ -9,6 +9,9 @@
 #ifndef ABM_SE_WAVES_PER_SIMD
 #define ABM_SE_WAVES_PER_SIMD 5  // 96 VGPRs per lane, 20 waves per CU
 #endif
+#ifndef ABM_SE_HEAVY_WAVES_PER_SIMD
+#define ABM_SE_HEAVY_WAVES_PER_SIMD 4  // heavy kernel: 128 VGPRs per lane (its waves are few and latency-bound)
+#endif
 
 namespace abm {
 
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
-template <bool TIMED, bool COOP>
-__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) {
+template <bool TIMED, bool COOP, bool HEAVY>
+__device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   WaveLds lds;
@@ -91,6 +94,22 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
   WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr bool HELP = HEAVY && COOP && ABM_HEAVY_HELP != 0;
+  constexpr int MODE = HEAVY ? kHeavy : kMain;
+  HelpWave hw;
+  hw.h = a.help;
+  hw.grid = gridDim.x;
+  hw.slot = blockIdx.x;
+  hw.r = 0;
+  hw.epoch = 0;
+  hw.registered = hw.on = hw.failed = hw.mismatch = false;
+  PassCtl pc;
+  pc.hw = &hw;
+  pc.gave_up = false;
+  const u32 budget = (!HEAVY && a.budget) ? a.budget : 0xFFFFFFFFu;
+  // the reads of this launch: order[first .. first + n_items)
+  const u64 first = a.list_begin ? static_cast<u64>(*a.list_begin) : 0ull;
+  const u64 n_items = (a.list_end ? static_cast<u64>(*a.list_end) : a.n_reads) - first;
   long long t_begin = 0, t_a = 0, t_b = 0;
   ABM_STAMP(t_begin);
   u32 n_aln = 0;
@@ -105,14 +124,14 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
       v = atomicAdd(a.next_read, 1ull);
       // exactly one wave draws the first index past the end: from here on only reads already in
       // flight are left, and the host may let the next batch's kernel in
-      if (v == a.n_reads && a.drained) __hip_atomic_store(a.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (v == n_items && a.drained) __hip_atomic_store(a.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) |
            static_cast<u32>(uni(static_cast<int>(v)));
   };
   u64 r_next = next_read();
-  while (r_next < a.n_reads) {
-    const u64 r = a.order ? static_cast<u64>(a.order[r_next]) : r_next;
+  while (r_next < n_items) {
+    const u64 r = a.order ? static_cast<u64>(a.order[first + r_next]) : r_next;
     r_next = next_read();  // fetched early; its latency hides under this read's work
     long long t_read = 0;
     if (TIMED) t_read = clock64();
@@ -138,18 +157,26 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
 
       SeSet S;
       S.begin_read(L);
+      pc.budget_left = budget;
+      pc.gave_up = false;
       for (u32 cidx = 0; cidx < n_calls; ++cidx) {
         const bool rc = (call_rc >> cidx) & 1u, ar = (call_ar >> cidx) & 1u;
         const bool g_to_a = rc != ar;  // get_conv_type, src/abismal.cpp:1261-1267
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        seed_pass<true, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
+        hw.r = r;
+        seed_pass<true, TIMED, COOP, MODE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, &pc);
         // should_do_sensitive, :367-370
-        if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
+        if (!pc.gave_up && (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff)) {
           S.cutoff = S.top_d();  // set_sensitive
-          seed_pass<false, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt);
+          seed_pass<false, TIMED, COOP, MODE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, &pc);
         }
+        if (pc.gave_up) break;
+      }
+      if (pc.gave_up) {  // too many candidates for this kernel: the heavy kernel maps the read from scratch
+        if (lane == 0) a.need_big[r] = 1;
+        continue;
       }
       ABM_STAMP(t_a);
       choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, a.cig_stride, n_ops, overflow, n_aln);
@@ -161,6 +188,11 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
       a.cig_n[r] = best.pos != 0 ? n_ops : 0u;
       if (TIMED && a.read_cycles) a.read_cycles[r] = static_cast<u32>((clock64() - t_read) >> 10);
     }
+  }
+  // no reads left: this wave's slot takes no more jobs, and it works for the waves still busy
+  if constexpr (HELP) {
+    hw.retire_owner();
+    help_others(a.ix, lds, a.packed, hw);
   }
   if (a.work) {  // exact per-launch work tallies for the roofline model
     auto wsum = [&](u32 v) { u32 t; (void)wave_excl_sum(v, t); return t; };
@@ -183,9 +215,15 @@ __global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArg
       }
     }
   }
-  if (lane == 0 && (overflow || too_long))
-    atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u));
+  if (lane == 0 && (overflow || too_long || hw.failed || hw.mismatch))
+    atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u) | (hw.failed ? 8u : 0u) | (hw.mismatch ? 16u : 0u));
 }
+
+template <bool TIMED, bool COOP>
+__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false>(a); }
+// the same per-read body for the reads with very many candidates (see PassMode)
+template <bool TIMED, bool COOP>
+__global__ __launch_bounds__(64, ABM_SE_HEAVY_WAVES_PER_SIMD) void map_se_heavy_kernel(SeArgs a) { map_se_body<TIMED, COOP, true>(a); }
 
 // =============================================================================
 // Heaviest-first ordering.  Work per read spans four orders of magnitude and is
@@ -310,6 +348,22 @@ hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned lon
   return hipGetLastError();
 }
 
+// ---- tail-help workspace ------------------------------------------------------
+void se_help_bytes(u32 n_waves, u32 cap, size_t &zeroed, size_t &total) {
+  const size_t ctl_words = 64 + ((static_cast<size_t>(n_waves) + 31) & ~static_cast<size_t>(31));
+  zeroed = (ctl_words + 32ull * n_waves) * 4;
+  total = zeroed + (static_cast<size_t>(kHelpDescWords) + cap / 2 + cap) * n_waves * 4;
+}
+void se_help_carve(char *base, u32 n_waves, u32 cap, HelpArgs &h) {
+  const size_t ctl_words = 64 + ((static_cast<size_t>(n_waves) + 31) & ~static_cast<size_t>(31));
+  h.ctl = reinterpret_cast<u32 *>(base);
+  h.tick = h.ctl + ctl_words;
+  h.desc = h.tick + 32ull * n_waves;
+  h.res = h.desc + static_cast<size_t>(kHelpDescWords) * n_waves;
+  h.stats = nullptr;
+  h.cap = cap;
+}
+
 // ---- launchers ----------------------------------------------------------------
 u32 se_window_words(u32 max_len, double valid_frac) {
   const int md = static_cast<i16>(valid_frac * max_len);
@@ -362,10 +416,21 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
   return hipGetLastError();
 }
 
-hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st) {
+hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st, bool heavy) {
   if (a.n_reads == 0) return hipSuccess;
   const size_t lds = se_lds_bytes(a.W, a.WB, a.cig_stride, max_len, a.size_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
+  if (heavy) {
+    if (a.G != 0) {
+      if (timed) hipLaunchKernelGGL((map_se_heavy_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
+      else hipLaunchKernelGGL((map_se_heavy_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
+    }
+    else {
+      if (timed) hipLaunchKernelGGL((map_se_heavy_kernel<true, false>), dim3(blocks), dim3(64), lds, st, a);
+      else hipLaunchKernelGGL((map_se_heavy_kernel<false, false>), dim3(blocks), dim3(64), lds, st, a);
+    }
+    return hipGetLastError();
+  }
   // COOP: G lanes share a candidate's window (a.G != 0); otherwise one lane per window
   if (a.G != 0) {
     if (timed) hipLaunchKernelGGL((map_se_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);

@@ -321,6 +321,7 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
 #define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (scripts/se_variant.sh): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
 #endif
 constexpr u32 kCoopRounds = ABM_COOP_ROUNDS;  // rounds of window loads in flight per lane
+template <u32 kRounds = kCoopRounds>
 __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, const WaveLds &lds, const u64 *qpk,
                                              u32 nwords, u32 pos_a, bool want_a, u32 pos_b, bool want_b,
                                              int &d_a, int &d_b) {
@@ -329,13 +330,13 @@ __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, con
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
   const bool has0 = 2 * sub < nwords, has1 = 2 * sub + 1 < nwords;
   const u64 q0 = has0 ? qpk[2 * sub] : 0ull, q1 = has1 ? qpk[2 * sub + 1] : 0ull;
-  for (u32 pass = 0; pass * kCoopRounds * per_round < 128; ++pass) {
-    u64 x0[kCoopRounds], x1[kCoopRounds];
+  for (u32 pass = 0; pass * kRounds * per_round < 128; ++pass) {
+    u64 x0[kRounds], x1[kRounds];
     u32 shifts = 0;  // (pos & 15) of the eight rounds' candidates, four bits each
 #pragma unroll
-    for (u32 r = 0; r < kCoopRounds; ++r) {
-      const u32 slot = (pass * kCoopRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
-      const bool second = (pass * kCoopRounds + r) * per_round >= 64;
+    for (u32 r = 0; r < kRounds; ++r) {
+      const u32 slot = (pass * kRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
+      const bool second = (pass * kRounds + r) * per_round >= 64;
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
       shifts |= (cp & 15u) << (4 * r);
@@ -348,8 +349,8 @@ __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, con
       }
     }
 #pragma unroll
-    for (u32 r = 0; r < kCoopRounds; ++r) {
-      const u32 slot = (pass * kCoopRounds + r) * per_round + grp;
+    for (u32 r = 0; r < kRounds; ++r) {
+      const u32 slot = (pass * kRounds + r) * per_round + grp;
       const u32 sh = ((shifts >> (4 * r)) & 15u) << 2;
       // the word after this lane's pair is the next lane's first word
       const u64 x2 = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r] >> 32)))) << 32) |
@@ -365,6 +366,221 @@ __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, con
   d_a = static_cast<i16>(lds.hres[lane]);
   d_b = static_cast<i16>(lds.hres[64 + lane]);
   __syncthreads();
+}
+
+// ---- flattened candidates of one 64-offset block ---------------------------------------
+// Per lane (= seed offset g0 + lane): its checked 2-letter bucket [lo2, lo2 + na) and 3-letter bucket
+// [lo3, lo3 + nb), laid end to end in the reference's visiting order (offset ascending, 2-letter
+// before 3-letter, index order): candidate c of the block is entry start_a + ... of whichever
+// segment contains c.
+struct Segs {
+  u32 start_a, na, lo2, nb, lo3;
+  __device__ __forceinline__ u32 start_b() const { return start_a + na; }
+};
+// the segment (2 * lane + is_three) that holds candidate c0 - 1, i.e. the one still open when the
+// 64-candidate window starting at c0 begins (needed when a window is not reached sequentially)
+__device__ __forceinline__ int seg_before(const Segs &sg, u32 c0) {
+  const int lane = lane_id();
+  int m = 0;
+  if (sg.na && sg.start_a < c0) m = 2 * lane + 1;
+  if (sg.nb && sg.start_b() < c0) m = 2 * lane + 2;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+  return m ? m - 1 : 0;
+}
+// which (offset, table) segment each of the 64 candidates from c0 on belongs to, and where its index
+// entry is.  `carry` = the segment open at c0 (0 at c0 == 0; seg_before otherwise; updated for c0 + 64)
+__device__ __forceinline__ void locate(const WaveLds &lds, const Segs &sg, u32 c0, u32 total, int &carry,
+                                       bool &valid, int &owner, u32 &entry_at, bool &three) {
+  const int lane = lane_id();
+  lds.mark[lane] = 0;
+  __syncthreads();
+  if (sg.na && sg.start_a - c0 < 64u) lds.mark[sg.start_a - c0] = static_cast<u16>(2 * lane + 1);
+  if (sg.nb && sg.start_b() - c0 < 64u) lds.mark[sg.start_b() - c0] = static_cast<u16>(2 * lane + 2);
+  __syncthreads();
+  const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
+  const int seg = m ? m - 1 : carry;
+  carry = rdlane(seg, 63);
+  owner = seg >> 1;
+  three = seg & 1;
+  const u32 c = c0 + lane;
+  valid = c < total;
+  // (all four exchanges are made by every lane: a shuffle inside a divergent branch would not
+  // see the lanes on the other side)
+  const u32 sa = __shfl(sg.start_a, owner), sb = __shfl(sg.start_b(), owner);
+  const u32 ba = __shfl(sg.lo2, owner), bb = __shfl(sg.lo3, owner);
+  entry_at = three ? bb + (c - sb) : ba + (c - sa);
+}
+
+// ---- tail help: idle waves take filter chunks of a heavy read --------------------------
+// Reads differ in cost by four orders of magnitude: a homopolymer or satellite read puts one to two
+// million candidates through the filter, 128 per dependent memory round trip, and keeps its wave
+// busy for 0.2-0.3 s -- long after a small batch's other reads are done.  Once some wave has run out
+// of reads (ctl.retired > 0), a wave that meets a block with many candidates ("owner") publishes the
+// block's segment table as a job; retired waves ("helpers") claim 128-candidate chunks of it, run
+// the same filter_chunk as the owner does, and write distance + position per candidate into the
+// owner's result buffer.  The owner takes chunks too, waits until all are in, and then replays the
+// results IN ORDER through the candidate set exactly as before -- distances are a pure function of
+// (read, position), so which wave computed them cannot show in the output.
+//
+// Protocol (placement-independent; cdna_hip_programming.md, Guideline 16, recipe R1): payload
+// stores are agent-scope (write-through), drained with s_waitcnt vmcnt(0) before the signalling
+// atomic; the consumer polls ONE word relaxed, then one agent-scope acquire, then loads.  Every
+// counter is an atomic RMW.  All control words are zeroed by the launch function before every launch.
+#define ABM_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ABM_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ABM_AGENT_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+constexpr u32 kHelpMin = 1024;        // candidates in a block from which its owner asks for help
+constexpr u32 kHelpChunk = 128;       // candidates per claimed chunk (one filter step)
+constexpr u64 kTickRetired = 0xFFFFFull;  // epoch field of an owner that has no reads left
+constexpr u32 kHelpHeaderWords = 32, kHelpDescWords = kHelpHeaderWords + 5 * 64;
+constexpr u32 kHelpSpinLimit = 1u << 24;
+constexpr u32 kHelpRounds = 8;          // rounds of window loads in flight per lane in a claimed chunk (the machine is mostly idle then)  // polls before a wait gives up and flags the launch
+
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifndef ABM_HELP_FENCES
+#define ABM_HELP_FENCES 1
+#endif
+// Every load of handed-off bytes here is an agent-scope load (bypasses this CU's L1); the acquire of
+// recipe R1 is kept on top of that unless a build switches it off for measurement.
+__device__ __forceinline__ void acquire_agent() {
+  if (ABM_HELP_FENCES) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ u64 uni64(u64 v) {
+  return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) | static_cast<u32>(uni(static_cast<int>(v)));
+}
+
+struct HelpWave {  // one wave's view of the help workspace (see HelpArgs)
+  HelpArgs h;
+  u32 grid, slot;
+  u64 r;            // read being mapped (owner side)
+  u32 epoch;        // jobs this wave has published
+  bool registered;  // this wave's slot is on the owners' list
+  bool on;          // some wave has retired: help can arrive
+  bool failed;      // a bounded wait gave up
+  bool mismatch;    // ABM_HELP_SELFCHECK build only: a result read back differs from the owner's own computation
+
+  __device__ __forceinline__ unsigned long long *tick(u32 s) const { return reinterpret_cast<unsigned long long *>(h.tick + 32ull * s); }
+  __device__ __forceinline__ u32 *done(u32 s) const { return h.tick + 32ull * s + 2; }
+  __device__ __forceinline__ u32 *desc(u32 s) const { return h.desc + static_cast<u64>(kHelpDescWords) * s; }
+  __device__ __forceinline__ u32 *res_d(u32 s) const { return h.res + static_cast<u64>(s) * (h.cap / 2 + h.cap); }
+  __device__ __forceinline__ u32 *res_p(u32 s) const { return res_d(s) + h.cap / 2; }
+
+  __device__ __forceinline__ bool available() {
+    if (h.ctl == nullptr || epoch >= 0xFFFF0u) return false;
+    if (!on) on = uni(static_cast<int>(ABM_AGENT_LOAD(h.ctl))) != 0;
+    return on;
+  }
+  // owner: make candidates [c_base, c_base + n_chunks * 128) of the block a job
+  __device__ __forceinline__ void publish(const Segs &sg, u32 enc, bool g_to_a, u32 g0, u32 total, u32 c_base, u32 L,
+                                          u32 n_chunks) {
+    const int lane = lane_id();
+    u32 *d = desc(slot);
+    u32 hv = 0;
+    if (lane == 0) hv = static_cast<u32>(r);
+    if (lane == 1) hv = static_cast<u32>(r >> 32);
+    if (lane == 2) hv = enc | (g_to_a ? 256u : 0u);
+    if (lane == 3) hv = g0;
+    if (lane == 4) hv = total;
+    if (lane == 5) hv = c_base;
+    if (lane == 6) hv = L;
+    if (lane < 8) ABM_AGENT_STORE(d + lane, hv);
+    u32 *sv = d + kHelpHeaderWords + lane;
+    ABM_AGENT_STORE(sv, sg.start_a);
+    ABM_AGENT_STORE(sv + 64, sg.na);
+    ABM_AGENT_STORE(sv + 128, sg.lo2);
+    ABM_AGENT_STORE(sv + 192, sg.nb);
+    ABM_AGENT_STORE(sv + 256, sg.lo3);
+    if (lane == 0) ABM_AGENT_STORE(done(slot), 0u);
+    drain_stores();
+    ++epoch;
+    if (lane == 0) ABM_AGENT_STORE(tick(slot), (static_cast<unsigned long long>(epoch) << 44) | (static_cast<unsigned long long>(n_chunks) << 22));
+    if (!registered) {
+      if (lane == 0) {
+        const u32 at = ABM_AGENT_ADD(h.ctl + 32, 1u);
+        ABM_AGENT_STORE(h.ctl + 64 + at, slot + 1u);
+      }
+      registered = true;
+    }
+  }
+  // next unclaimed chunk of slot s's current job: returns the ticket as it was before the claim
+  __device__ __forceinline__ u64 claim(u32 s) const {
+    unsigned long long t = 0;
+    if (lane_id() == 0) t = ABM_AGENT_ADD(tick(s), 1ull);
+    return uni64(t);
+  }
+  __device__ __forceinline__ void store_chunk(u32 s, u32 chunk, int ha, int hb, u32 pa, u32 pb) const {
+    const int lane = lane_id();
+    ABM_AGENT_STORE(res_d(s) + chunk * 64u + lane, (static_cast<u32>(ha) & 0xFFFFu) | (static_cast<u32>(hb) << 16));
+    ABM_AGENT_STORE(res_p(s) + chunk * 128u + lane, pa);
+    ABM_AGENT_STORE(res_p(s) + chunk * 128u + 64u + lane, pb);
+    drain_stores();
+    if (lane == 0) ABM_AGENT_ADD(done(s), 1u);
+  }
+  __device__ __forceinline__ void wait_done(u32 n_chunks) {
+    for (u32 spins = 0;; ++spins) {
+      const u32 d = static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(done(slot)))));
+      if (d >= n_chunks) break;
+      if (spins > kHelpSpinLimit) { failed = true; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    acquire_agent();
+  }
+  __device__ __forceinline__ void retire_owner() const {
+    if (h.ctl != nullptr && lane_id() == 0) ABM_AGENT_STORE(tick(slot), static_cast<unsigned long long>(kTickRetired << 44));
+  }
+};
+
+// distances and positions of candidates [c0, c0 + 128) of a flattened block (two per lane: c0 + lane
+// and c0 + 64 + lane), reached out of sequence -- what a claimed chunk of a job computes
+__device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qpk, const u32 *idx3,
+                                             u32 nwords, const Segs &sg, u32 g0, u32 total, u32 c0, int &ha, int &hb,
+                                             u32 &pa, u32 &pb) {
+  int carry = seg_before(sg, c0);
+  bool va, vb = false, ta3, tb3 = false;
+  int oa, ob = 0;
+  u32 ea_at, eb_at = 0, ea = 0, eb = 0;
+  locate(lds, sg, c0, total, carry, va, oa, ea_at, ta3);
+  if (c0 + 64 < total) locate(lds, sg, c0 + 64, total, carry, vb, ob, eb_at, tb3);
+  if (va) ea = ta3 ? idx3[ea_at] : ix.index[ea_at];
+  if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
+  pa = ea - (g0 + static_cast<u32>(oa));
+  pb = eb - (g0 + static_cast<u32>(ob));
+  hamming_coop<kHelpRounds>(ix.genome, lds, qpk, nwords, pa, va, pb, vb, ha, hb);
+  if (!va) ha = 0x7fff;
+  if (!vb) hb = 0x7fff;
+}
+
+// Owner side of a job: publish candidates [c_base, c_base + n_chunks * 128) of the block, take chunks
+// like any helper, and return once every chunk's results are in this wave's buffer.  Out of line on
+// purpose: it runs only in the tail of a launch and must not cost the mapping loop registers.
+// Everything is passed by value (nothing of the caller's has its address taken: its state stays in
+// registers); returns the wave's new job count | failed << 31.
+__device__ __attribute__((noinline)) u32 help_fill_job(DevIndex ix, WaveLds lds, HelpWave hw, const u64 *qpk,
+                                                      const u32 *idx3, u32 nwords, u32 start_a, u32 na, u32 lo2, u32 nb,
+                                                      u32 lo3, u32 enc, bool g_to_a, u32 g0, u32 total, u32 c_base, u32 L,
+                                                      u32 n_chunks) {
+  Segs sg;
+  sg.start_a = start_a; sg.na = na; sg.lo2 = lo2; sg.nb = nb; sg.lo3 = lo3;
+  hw.publish(sg, enc, g_to_a, g0, total, c_base, L, n_chunks);
+  u32 mine = 0;
+  for (;;) {
+    const u32 idx = static_cast<u32>(hw.claim(hw.slot)) & ((1u << 22) - 1);
+    if (idx >= n_chunks) break;
+    int ha, hb;
+    u32 pa, pb;
+    filter_chunk(ix, lds, qpk, idx3, nwords, sg, g0, total, c_base + idx * kHelpChunk, ha, hb, pa, pb);
+    hw.store_chunk(hw.slot, idx, ha, hb, pa, pb);
+    ++mine;
+  }
+  hw.wait_done(n_chunks);
+  if (hw.h.stats != nullptr && lane_id() == 0) {  // diagnostics: jobs, chunks, chunks the owner did itself
+    ABM_AGENT_ADD(hw.h.stats, 1ull);
+    ABM_AGENT_ADD(hw.h.stats + 1, static_cast<unsigned long long>(n_chunks));
+    ABM_AGENT_ADD(hw.h.stats + 2, static_cast<unsigned long long>(mine));
+  }
+  return hw.epoch | (hw.failed ? 0x80000000u : 0u);
 }
 
 // One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
@@ -387,9 +603,28 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-template <bool SPECIFIC, bool TIMED, bool COOP, class Set>
+// How a seed pass is run: kPlain (paired-end), kMain (single-end kernel for ordinary reads: a read
+// whose candidates exceed a budget is given up and left to the heavy kernel), kHeavy (single-end
+// kernel for the few reads with very many candidates: more window loads in flight per lane, and,
+// in an ABM_HEAVY_HELP build, idle waves share the filter work).
+enum PassMode { kPlain = 0, kMain = 1, kHeavy = 2 };
+struct PassCtl {
+  u32 budget_left;  // kMain: candidates this read may still put through the filter
+  bool gave_up;     // kMain: the budget ran out; the read's state is meaningless from here on
+  HelpWave *hw;     // kHeavy with help
+};
+#ifndef ABM_HEAVY_HELP
+#define ABM_HEAVY_HELP 0
+#endif
+#ifndef ABM_HEAVY_ROUNDS
+#define ABM_HEAVY_ROUNDS 8
+#endif
+template <bool SPECIFIC, bool TIMED, bool COOP, int MODE, class Set>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
-                                          u32 flags, u32 L, Set &S, WorkTally &wt) {
+                                          u32 flags, u32 L, Set &S, WorkTally &wt, PassCtl *pc = nullptr) {
+  constexpr bool HELP = MODE == kHeavy && ABM_HEAVY_HELP != 0;
+  constexpr u32 kRoundsHere = MODE == kHeavy ? ABM_HEAVY_ROUNDS : kCoopRounds;
+  HelpWave *hw = HELP ? pc->hw : nullptr;
   const int lane = lane_id();
   const u64 *qpk = lds.qpk + enc * lds.W;
   const u64 *qb = lds.qbits + enc * lds.WB;
@@ -440,33 +675,21 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       }
       ++wt.seed_iters;
     }
-    const u32 na = chk2 ? hi2 - lo2 : 0u, nb = chk3 ? hi3 - lo3 : 0u;
+    Segs sg;
+    sg.na = chk2 ? hi2 - lo2 : 0u;
+    sg.nb = chk3 ? hi3 - lo3 : 0u;
+    sg.lo2 = lo2;
+    sg.lo3 = lo3;
     u32 total;
-    const u32 start_a = wave_excl_sum(na + nb, total), start_b = start_a + na;
+    sg.start_a = wave_excl_sum(sg.na + sg.nb, total);
     ABM_STAMP(tb_);
     if (TIMED) wt.t_probe += tb_ - ta;
+    if constexpr (MODE == kMain) {
+      // a read with this many candidates belongs to the heavy kernel: stop here, it is mapped again there
+      if (total > pc->budget_left) { pc->gave_up = true; S.sure_ambig = true; break; }
+      pc->budget_left -= total;
+    }
 
-    int carry = 0;
-    // which (offset, table) segment each of the 64 candidates from c0 on belongs to, and its index entry
-    auto locate = [&](u32 c0, bool &valid, int &owner, u32 &entry_at, bool &three) {
-      lds.mark[lane] = 0;
-      __syncthreads();
-      if (na && start_a - c0 < 64u) lds.mark[start_a - c0] = static_cast<u16>(2 * lane + 1);
-      if (nb && start_b - c0 < 64u) lds.mark[start_b - c0] = static_cast<u16>(2 * lane + 2);
-      __syncthreads();
-      const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
-      const int seg = m ? m - 1 : carry;
-      carry = rdlane(seg, 63);
-      owner = seg >> 1;
-      three = seg & 1;
-      const u32 c = c0 + lane;
-      valid = c < total;
-      // (all four exchanges are made by every lane: a shuffle inside a divergent branch would not
-      // see the lanes on the other side)
-      const u32 sa = __shfl(start_a, owner), sb = __shfl(start_b, owner);
-      const u32 ba = __shfl(lo2, owner), bb = __shfl(lo3, owner);
-      entry_at = three ? bb + (c - sb) : ba + (c - sa);
-    };
     // ordered replay of one 64-candidate sub-chunk (check_hits + update, :1133-1149, :394-404)
     auto replay = [&](bool valid, int h, int hmax, u32 pos) {
       u64 todo = __ballot(valid && hmax <= S.cutoff);
@@ -503,6 +726,52 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         if (S.cutoff < before) todo &= __ballot(valid && hmax <= S.cutoff);
       }
     };
+
+    if constexpr (HELP && COOP) {
+      // A block with very many candidates while some wave sits idle: its distances are computed as jobs
+      // that idle waves share (help_fill_job: out of line, it needs none of the set's state), in sub-jobs
+      // that fit this wave's result buffer; the results are then replayed here in the reference's order.
+      if (total >= kHelpMin && hw != nullptr && hw->available()) {
+        ABM_STAMP(tc);
+        for (u32 c_base = 0; c_base < total && !S.sure_ambig; c_base += hw->h.cap) {
+          const u32 cnt = min(hw->h.cap, total - c_base);
+          const u32 n_chunks = (cnt + kHelpChunk - 1) / kHelpChunk;
+          const u32 hs = help_fill_job(ix, lds, *hw, qpk, idx3, nwords, sg.start_a, sg.na, sg.lo2, sg.nb, sg.lo3, enc, g_to_a, g0,
+                                       total, c_base, L, n_chunks);
+          hw->epoch = hs & 0x7FFFFFFFu;
+          hw->registered = true;
+          hw->failed |= (hs >> 31) != 0;
+          wt.cands += cnt / 64 + (static_cast<u32>(lane) < cnt % 64 ? 1u : 0u);  // (tallies are per lane and summed at the end)
+          wt.words += (cnt / 64 + (static_cast<u32>(lane) < cnt % 64 ? 1u : 0u)) * nwords;
+          const u32 *rd = hw->res_d(hw->slot), *rp = hw->res_p(hw->slot);
+          u32 nd = ABM_AGENT_LOAD(rd + lane), npa = ABM_AGENT_LOAD(rp + lane), npb = ABM_AGENT_LOAD(rp + 64 + lane);
+          for (u32 k = 0; k < n_chunks && !S.sure_ambig; ++k) {
+            const u32 dd = nd, pa = npa, pb = npb;
+            if (k + 1 < n_chunks) {
+              nd = ABM_AGENT_LOAD(rd + (k + 1) * 64u + lane);
+              npa = ABM_AGENT_LOAD(rp + (k + 1) * 128u + lane);
+              npb = ABM_AGENT_LOAD(rp + (k + 1) * 128u + 64u + lane);
+            }
+            const int ha = static_cast<int>(dd & 0xFFFFu), hb = static_cast<int>(dd >> 16);
+#ifdef ABM_HELP_SELFCHECK  // test build: every result read back is recomputed by the owner and must agree
+            {
+              int xa, xb;
+              u32 ya, yb;
+              filter_chunk(ix, lds, qpk, idx3, nwords, sg, g0, total, c_base + k * kHelpChunk, xa, xb, ya, yb);
+              if (__any(xa != ha || xb != hb || (xa != 0x7fff && ya != pa) || (xb != 0x7fff && yb != pb))) hw->mismatch = true;
+            }
+#endif
+            replay(ha != 0x7fff, ha, ha, pa);
+            if (!S.sure_ambig) replay(hb != 0x7fff, hb, hb, pb);
+          }
+        }
+        ABM_STAMP(td);
+        if (TIMED) wt.t_stream += td - tc;
+        continue;
+      }
+    }
+
+    int carry = 0;
     // Candidates are taken 128 at a time, two per lane (c0+lane and c0+64+lane): both index entries,
     // then both genome windows, are in flight together, which halves the dependent round trips of a
     // read with very many candidates.  The set still sees them strictly in the reference's order.
@@ -516,8 +785,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       bool ta3, tb3 = false;
       u32 ea_at, eb_at = 0;
       nvb = false; nob = 0; nea = 0; neb = 0;
-      locate(c0, nva, noa, ea_at, ta3);
-      if (c0 + 64 < total) locate(c0 + 64, nvb, nob, eb_at, tb3);
+      locate(lds, sg, c0, total, carry, nva, noa, ea_at, ta3);
+      if (c0 + 64 < total) locate(lds, sg, c0 + 64, total, carry, nvb, nob, eb_at, tb3);
       if (nva) nea = ta3 ? idx3[ea_at] : ix.index[ea_at];
       if (nvb) neb = tb3 ? idx3[eb_at] : ix.index[eb_at];
     };
@@ -539,7 +808,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
       int ha, hma, hb, hmb;
       if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
-        hamming_coop(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+        hamming_coop<kRoundsHere>(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
         hma = ha; hmb = hb;
       }
       else
@@ -563,6 +832,87 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       if (TIMED) wt.t_replay += tc - td;
     }
   }
+}
+
+// A retired wave (no reads left) works for the owners that asked for help until every wave of the
+// launch has retired.  It attaches to one registered owner at a time (spread by its retirement
+// number), polls that owner's ticket -- one word, with sleeps in between: idle pollers must not
+// load the memory system the owners are waiting on -- and claims chunks of whatever job is open.
+__device__ __attribute__((noinline)) void help_others(DevIndex ix, WaveLds lds, const u64 *packed, HelpWave hw) {
+  const int lane = lane_id();
+  if (hw.h.ctl == nullptr) return;
+  u32 my_seq = 0;
+  if (lane == 0) my_seq = ABM_AGENT_ADD(hw.h.ctl, 1u);
+  my_seq = static_cast<u32>(uni(static_cast<int>(my_seq)));
+  u32 attempt = 0, idle_polls = 0, n_reg = 0, s = 0xFFFFFFFFu;
+  u32 cur_slot = 0xFFFFFFFFu, cur_epoch = 0;
+  unsigned long long n_done = 0;
+  // the job being worked on (wave-uniform header + this lane's segment record)
+  Segs sg = {0, 0, 0, 0, 0};
+  u32 j_enc = 0, j_g0 = 0, j_total = 0, j_cbase = 0, j_L = 0;
+  bool j_g2a = false;
+  for (u32 spins = 0; spins < kHelpSpinLimit; ++spins) {
+    if (s == 0xFFFFFFFFu) {  // (re)attach: look at the launch-wide words only here
+      if (static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(hw.h.ctl)))) >= hw.grid) break;  // nobody owns a read any more
+      n_reg = static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(hw.h.ctl + 32))));
+      if (n_reg == 0) { __builtin_amdgcn_s_sleep(127); continue; }
+      const u32 s1 = static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(hw.h.ctl + 64 + (my_seq + attempt) % n_reg))));
+      if (s1 == 0) { __builtin_amdgcn_s_sleep(32); continue; }  // registration in flight
+      s = s1 - 1;
+      idle_polls = 0;
+    }
+    u64 t = 0;
+    if (lane == 0) t = ABM_AGENT_LOAD(hw.tick(s));
+    t = uni64(t);
+    const u64 epoch = t >> 44;
+    const u32 n_chunks = static_cast<u32>(t >> 22) & ((1u << 22) - 1), next = static_cast<u32>(t) & ((1u << 22) - 1);
+    if (epoch == kTickRetired) {
+      ++attempt; s = 0xFFFFFFFFu;
+      if (attempt % max(n_reg, 1u) == 0) __builtin_amdgcn_s_sleep(127);
+      continue;
+    }
+    if (epoch == 0 || next >= n_chunks) {
+      // nothing open here right now: the owner is narrowing or replaying, its next job comes soon.
+      // After a while look elsewhere (owners differ in how much work they have left).
+      __builtin_amdgcn_s_sleep(64);
+      if (++idle_polls >= 256) { ++attempt; s = 0xFFFFFFFFu; }
+      continue;
+    }
+    idle_polls = 0;
+    const u64 got = hw.claim(s);
+    const u64 g_epoch = got >> 44;
+    const u32 g_n = static_cast<u32>(got >> 22) & ((1u << 22) - 1), idx = static_cast<u32>(got) & ((1u << 22) - 1);
+    if (g_epoch == kTickRetired || g_epoch == 0 || idx >= g_n) continue;
+    if (s != cur_slot || static_cast<u32>(g_epoch) != cur_epoch) {  // a job not seen yet: fetch its descriptor
+      acquire_agent();
+      const u32 *d = hw.desc(s);
+      const u32 hv = lane < 8 ? ABM_AGENT_LOAD(d + lane) : 0u;
+      const u64 jr = (static_cast<u64>(rdlane(hv, 1)) << 32) | rdlane(hv, 0);
+      const u32 e = rdlane(hv, 2);
+      j_enc = e & 255u; j_g2a = (e & 256u) != 0;
+      j_g0 = rdlane(hv, 3); j_total = rdlane(hv, 4); j_cbase = rdlane(hv, 5); j_L = rdlane(hv, 6);
+      const u32 *sv = d + kHelpHeaderWords + lane;
+      sg.start_a = ABM_AGENT_LOAD(sv);
+      sg.na = ABM_AGENT_LOAD(sv + 64);
+      sg.lo2 = ABM_AGENT_LOAD(sv + 128);
+      sg.nb = ABM_AGENT_LOAD(sv + 192);
+      sg.lo3 = ABM_AGENT_LOAD(sv + 256);
+      // the owner's read, in the encoding of this call, into this wave's (idle) LDS
+      const u64 *src = packed + (jr * 4 + j_enc) * lds.W;
+      __syncthreads();
+      for (u32 k = lane; k < lds.W; k += 64) lds.qpk[j_enc * lds.W + k] = src[k];
+      __syncthreads();
+      cur_slot = s; cur_epoch = static_cast<u32>(g_epoch);
+    }
+    int ha, hb;
+    u32 pa, pb;
+    filter_chunk(ix, lds, lds.qpk + j_enc * lds.W, j_g2a ? ix.index_a : ix.index_t, (j_L + 15) >> 4, sg, j_g0, j_total,
+                 j_cbase + idx * kHelpChunk, ha, hb, pa, pb);
+    hw.store_chunk(s, idx, ha, hb, pa, pb);
+    ++n_done;
+    spins = 0;
+  }
+  if (hw.h.stats != nullptr && lane == 0 && n_done) ABM_AGENT_ADD(hw.h.stats + 3, n_done);
 }
 
 // =============================================================================

@@ -293,10 +293,10 @@ template <bool BIG> struct PeWave {
     P.begin_read(L[end]);
     if (L[end] >= kMinReadLen) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, ABM_PE_COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+      seed_pass<true, TIMED, ABM_PE_COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, ABM_PE_COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+        seed_pass<false, TIMED, ABM_PE_COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       }
     }
     need_big |= P.overflow;

@@ -364,6 +364,88 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "mapping": {"pairs": int(stats[0]), "concordant": int(stats[1]), "ends_mapped_single": int(stats[2])}}), flush=True)
 
 
+
+# ---------------------------------------------------------------------------------- e2e
+def run_e2e(args, idx, fasta, L):
+    """SURVEY.md section 8(d)'s window: FASTQ on disk -> SAM on disk through the product CLI, timed from the
+    first batch submitted to the last SAM byte written (index load/upload excluded and reported).  The
+    FASTQ comes from the product's own `sim` (md5-pinned restatement of `abismal sim`) on the bench
+    genome; a prefix of it also goes through the oracle's CLI and the SAM bodies must be identical."""
+    import hashlib
+    import shutil
+    import subprocess
+    cli = os.path.join(ROOT, "abismal_amd", "abismal-amd")
+    if not os.path.exists(fasta):
+        return {"skipped": f"{fasta} is gone (index built by an earlier run without the e2e leg)"}
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else args.workdir
+    wd = os.path.join(shm, f"abismal_e2e_{os.getpid()}")
+    os.makedirs(wd, exist_ok=True)
+    out = {}
+    try:
+        n = args.e2e_reads
+        t0 = time.time()
+        subprocess.run([cli, "sim", "-single", "-seed", "1", "-n", str(n), "-l", str(L), "-m", "0.01", "-b", "0.98",
+                        "-o", os.path.join(wd, "reads"), fasta], check=True, stdout=subprocess.DEVNULL)
+        t_sim = time.time() - t0
+        fq = os.path.join(wd, "reads_1.fq")
+        sam, tj = os.path.join(wd, "out.sam"), os.path.join(wd, "timing.json")
+        best = None
+        for rep in range(2):  # the second run has the page cache and the GPU clocks of a run in progress
+            r = subprocess.run([cli, "map", "-i", idx, "-o", sam, "-s", os.path.join(wd, "out.stats"), "-timing", tj, fq],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                return {"error": r.stderr[-2000:]}
+            t = json.load(open(tj))
+            if best is None or t["seconds"] < best["seconds"]:
+                best = t
+        out = {"value": round(best["reads"] / best["seconds"], 1), "unit": "reads/s",
+               "window": "first batch submitted -> last SAM byte written (abismal-amd map, plain FASTQ in, SAM text out, tmpfs)",
+               "reads": best["reads"], "seconds": round(best["seconds"], 3), "index_load_s": round(best["index_load_s"], 2),
+               "fastq_bytes": os.path.getsize(fq), "sam_bytes": os.path.getsize(sam), "sim_s": round(t_sim, 1),
+               "cli": {k: best[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "batch_reads")},
+               "busy_s": {k: round(v, 3) for k, v in best["busy_s"].items()}}
+        # parity on a prefix: product CLI vs oracle CLI, SAM body (everything but the @PG line) byte for byte
+        nchk = min(n, args.e2e_check)
+        if nchk > 0:
+            from tests import oracle_binding as ob
+            if not os.path.exists(ob.CLI):
+                ob.build_oracle()
+            pfq = os.path.join(wd, "prefix.fq")
+            with open(fq, "rb") as fi, open(pfq, "wb") as fo:
+                for k, line in enumerate(fi):
+                    if k >= 4 * nchk:
+                        break
+                    fo.write(line)
+
+            def body_md5(path, limit=None):
+                h, k = hashlib.md5(), 0
+                with open(path, "rb") as f:
+                    for line in f:
+                        if line.startswith(b"@PG"):
+                            continue
+                        if limit is not None and k >= limit:
+                            break
+                        h.update(line)
+                        k += 1
+                return h.hexdigest(), k
+
+            subprocess.run([cli, "map", "-i", idx, "-o", os.path.join(wd, "p_gpu.sam"), pfq], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t0 = time.time()
+            subprocess.run([ob.CLI, "map", "-t", str(os.cpu_count() or 1), "-i", idx, "-o", os.path.join(wd, "p_oracle.sam"), pfq],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t_or = time.time() - t0
+            m_g, k_g = body_md5(os.path.join(wd, "p_gpu.sam"))
+            m_o, k_o = body_md5(os.path.join(wd, "p_oracle.sam"))
+            m_f, _ = body_md5(sam, limit=k_g)  # the full run starts with the very same records
+            out["parity"] = {"prefix_reads": nchk, "sam_lines": k_g, "md5_product": m_g, "md5_oracle_cli": m_o,
+                             "md5_full_run_prefix": m_f, "identical": bool(m_g == m_o == m_f and k_g == k_o),
+                             "oracle_cli_s": round(t_or, 1)}
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+    return out
+
+
 # --------------------------------------------------------------------------- launcher
 def launch_ranks(n_ranks):
     """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: spawns one fresh worker
@@ -454,6 +536,11 @@ def main():
                          "(single-end: on by default at N=1, see --no-stage-split)")
     ap.add_argument("--no-stage-split", action="store_true", help="single-end: skip the per-stage roofline rows")
     ap.add_argument("--workdir", default=os.environ.get("ABM_BENCH_DIR", "/tmp/abismal_bench"))
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end leg (product sim -> FASTQ -> abismal-amd map -> SAM on tmpfs) at N=1")
+    ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("ABM_BENCH_E2E_READS", 10_000_000)))
+    ap.add_argument("--e2e-check", type=int, default=int(os.environ.get("ABM_BENCH_E2E_CHECK", 1_000_000)),
+                    help="reads of the FASTQ prefix mapped by the oracle CLI too (SAM body md5 must agree)")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
     args = ap.parse_args()
@@ -499,7 +586,8 @@ def main():
         os.replace(idx + ".tmp", idx)  # atomic: a waiting rank never sees a partial file
         t_build = time.time() - t0
         log(f"index built in {t_build:.1f}s ({os.path.getsize(idx) / 1e9:.2f} GB)")
-        os.remove(fasta)
+        if args.no_e2e or args.pe:
+            os.remove(fasta)  # (the end-to-end leg simulates its FASTQ from this file)
     t_wait = time.time()
     while not os.path.exists(idx):
         if time.time() - t_wait > 3600:
@@ -739,6 +827,16 @@ def main():
                 "gathers_per_s": round((per_launch["seed_offsets"] * 2 + per_launch["candidates"] * 2 +
                                         per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
 
+    e2e = None
+    if not args.no_e2e and world == 1:
+        # free this process's HBM first: the CLI is a process of its own on the same GPU
+        del blobs, blob, res, cig, cig_n
+        ctx.close()
+        index.close()
+        torch.cuda.empty_cache()
+        e2e = run_e2e(args, idx, fasta, L)
+        log(f"e2e: {e2e}")
+
     line = {
         "metric": "mapped reads/sec (whole node), 100 bp SE on hg38-scale index",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -750,10 +848,11 @@ def main():
                                f"{n} sim-like reads x {L} bp SE per GPU per step, T-rich mode",
                    "reads_per_step_per_gpu": n, "read_len": L, "index_gb": round(index.device_bytes / 1e9, 2),
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated"},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e,
         "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                     "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])},
         "work_per_read": {k: round(v / n, 2) for k, v in per_launch.items()},
+        "tail_help_per_launch": {k: round(v / max(1, launches), 1) for k, v in work["help"].items()} if "help" in work else None,
         "phase_shares_diagnostic": phases,
         "kernel_status": st_host,
         "kernel_status_note": ("bit 0 = some CIGAR needed more than the %d-op device slot (hits stay exact; the host entry "

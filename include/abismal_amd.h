@@ -123,7 +123,9 @@ int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t
 enum {
   ABM_STATUS_CIGAR_OVERFLOW = 1u, /* a CIGAR needed more than cig_stride ops */
   ABM_STATUS_READ_TOO_LONG = 2u,  /* a read exceeded the kernel's length cap */
-  ABM_STATUS_SET_OVERFLOW = 4u    /* PE candidate set outgrew its workspace */
+  ABM_STATUS_SET_OVERFLOW = 4u,   /* PE candidate set outgrew its workspace */
+  ABM_STATUS_HELP_TIMEOUT = 8u,   /* a wave waited too long for chunks handed to idle waves (results invalid) */
+  ABM_STATUS_HELP_MISMATCH = 16u  /* self-check build only: a handed-off result differed from the owner's own */
 };
 uint32_t abm_max_read_length(void); /* longest read the kernels accept */
 

@@ -190,6 +190,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.n_reads = n;
   a.W = W;
   a.WB = WB;
+  a.max_len = eff_len;
   // IUPAC genome letters can drive a Hamming sum below zero, which the reference turns into the
   // widest band (61); size the LDS for it only when such letters exist
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : params->valid_frac;
@@ -363,7 +364,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.subset = ctx->subset.p; a.subset_count = ctx->subset_count.p;
   a.n_pairs = n;
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : std::max(params->valid_frac, params->valid_frac);
-  a.W = W; a.WB = WB; a.GW = abm::se_window_words(eff_len, size_frac);
+  a.W = W; a.WB = WB; a.max_len = eff_len; a.GW = abm::se_window_words(eff_len, size_frac);
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
   a.G = (W <= 7 ? 4u : 8u);  // only read by a paired-end build with cooperative window loads (ABM_PE_COOP)
   a.mode = mode;

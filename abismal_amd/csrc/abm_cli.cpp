@@ -9,6 +9,7 @@
 #include "../../include/abismal_amd.h"
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -16,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,25 +89,42 @@ struct RawPool {
   }
 };
 
-struct Batch {
-  uint64_t seq = 0;        // batch number, defines output order
+struct NameRef {  // a read name inside its slice's FASTQ text
+  const char *p;
+  uint32_t n;
+};
+struct Batch;
+
+// The unit of host work: up to `slice_reads` records of the input, in file order.  Slices are cut,
+// parsed, formatted and written independently; a batch handed to a GPU is a run of consecutive slices.
+struct Slice {
+  uint64_t g = 0;                    // slice number = output order
   uint64_t first_line[2] = {0, 0};
-  RawBuf raw[2];           // the FASTQ text of this batch
-  std::vector<std::string> names[2];
-  std::string blob[2];
+  uint64_t byte_lo[2] = {0, 0}, byte_hi[2] = {0, 0};  // plain files: the slice's text in each file
+  RawBuf raw[2];                     // the FASTQ text (names point into it)
+  std::vector<NameRef> names[2];
+  std::string blob[2];               // reads as ReadLoader hands them over, concatenated
   std::vector<uint64_t> off[2];
-  // results
+  size_t n() const { return names[0].size(); }
+  Batch *batch = nullptr;            // once mapped: the batch whose arrays hold this slice's results ...
+  size_t base = 0;                   // ... from this index on
+  std::string text;                  // formatted output
+  Stats3 stats;
+};
+
+struct Batch {
+  uint64_t seq = 0;
   int gpu = 0;
+  std::vector<std::unique_ptr<Slice>> slices;
+  size_t n = 0;
+  std::vector<std::string> carry[2]; // reads of the input just before this batch, mapped along for their side effects only
+  std::string blob[2];               // carry + the slices' reads concatenated, as the C ABI takes them
+  std::vector<uint64_t> off[2];
   std::vector<abm_hit> se[2];
   std::vector<abm_pair> pairs;
   std::vector<uint32_t> cig[2];
   std::vector<uint64_t> cig_off[2];
-  // formatted output: slices of the batch are formatted independently and written in order
-  std::vector<std::string> parts;
-  std::vector<Stats3> part_stats;
-  int parts_left = 0;
-  Stats3 stats;
-  size_t n() const { return names[0].size(); }
+  int slices_left = 0;               // not yet written
 };
 
 // advances over [p + from, p + len) counting newlines until `need` lines are complete; returns the
@@ -192,10 +211,12 @@ struct RawSplitter {
   bool exhausted() const { return eof && carry.empty(); }
 };
 
-void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, std::vector<std::string> &names,
+void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, std::vector<NameRef> &names,
                std::string &blob, std::vector<uint64_t> &off) {
   names.clear(); blob.clear(); off.assign(1, 0);
   blob.reserve(raw.n / 2);
+  names.reserve(raw.n / 200 + 16);
+  off.reserve(raw.n / 200 + 16);
   const char *p = raw.p, *end = p + raw.n;
   std::string line;
   for (uint64_t k = 0; p < end; ++k) {
@@ -206,7 +227,7 @@ void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, 
         throw std::runtime_error("file " + path + " contains an empty read name at line " + std::to_string(first_line + k));
       const char *q = p + 1;
       while (q < le && *q != ' ' && *q != '\t') ++q;
-      names.emplace_back(p + 1, q);
+      names.push_back(NameRef{p + 1, static_cast<uint32_t>(q - (p + 1))});
     }
     else if (k % 4 == 1) {
       const size_t len = static_cast<size_t>(le - p);
@@ -281,7 +302,7 @@ inline void put_int(std::string &o, int64_t v) {
 }
 
 struct Record {
-  const std::string *name;
+  const NameRef *name;
   uint16_t flag;
   int32_t tid, mtid;
   uint32_t pos, mpos;
@@ -299,7 +320,7 @@ void put_bam_record(std::string &o, const Record &r);
 thread_local bool t_bam = false;  // formatter threads switch put_record to BAM encoding
 void put_record(std::string &o, const Chroms &ch, const Record &r) {
   if (t_bam) { put_bam_record(o, r); return; }
-  o += *r.name; o += '\t'; put_uint(o, r.flag); o += '\t';
+  o.append(r.name->p, r.name->n); o += '\t'; put_uint(o, r.flag); o += '\t';
   o += ch.names[r.tid + 1]; o += '\t'; put_uint(o, static_cast<uint64_t>(r.pos) + 1); o.append("\t255\t", 5);
   for (size_t i = 0; i < r.n_cig; ++i) { put_uint(o, r.cig[i] >> 4); o += "MIDNSHP=XB"[std::min<uint32_t>(r.cig[i] & 15u, 9)]; }
   o += '\t';
@@ -338,7 +359,7 @@ void put_bam_record(std::string &o, const Record &r) {
   put_le32(o, static_cast<uint32_t>(r.tid));
   put_le32(o, r.pos);
   const uint32_t rl = ref_len(r.cig, r.n_cig);
-  o += static_cast<char>(r.name->size() + 1);
+  o += static_cast<char>(r.name->n + 1);
   o += static_cast<char>(255);
   put_le16(o, static_cast<uint16_t>(reg2bin(r.pos, static_cast<int64_t>(r.pos) + (rl ? rl : 1))));
   put_le16(o, static_cast<uint16_t>(r.n_cig));
@@ -347,7 +368,7 @@ void put_bam_record(std::string &o, const Record &r) {
   put_le32(o, static_cast<uint32_t>(r.mtid));
   put_le32(o, r.mtid < 0 ? 0xFFFFFFFFu : r.mpos);
   put_le32(o, static_cast<uint32_t>(r.tlen));
-  o.append(*r.name); o += '\0';
+  o.append(r.name->p, r.name->n); o += '\0';
   for (size_t i = 0; i < r.n_cig; ++i) put_le32(o, r.cig[i]);
   auto code = [&](size_t i) -> int {
     const char c = r.rc ? kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])] : kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
@@ -407,7 +428,7 @@ std::string bam_header_bytes(const std::string &text, const Chroms &ch) {
 
 enum Outcome { UNMAPPED, UNIQUE, AMBIG };
 
-Outcome emit_se(std::string &o, bool allow_ambig, const abm_hit &h, const Chroms &ch, const std::string &name,
+Outcome emit_se(std::string &o, bool allow_ambig, const abm_hit &h, const Chroms &ch, const NameRef &name,
                 const char *seq, size_t n_seq, const uint32_t *cig, size_t n_cig) {
   const bool ambig = h.flags & 0x100;
   if (!allow_ambig && ambig) return AMBIG;
@@ -421,8 +442,8 @@ Outcome emit_se(std::string &o, bool allow_ambig, const abm_hit &h, const Chroms
   return ambig ? AMBIG : UNIQUE;
 }
 
-Outcome emit_pe(std::string &o, bool allow_ambig, const abm_pair &p, const Chroms &ch, const std::string &n1,
-                const std::string &n2, const char *s1, size_t l1, const char *s2, size_t l2, const uint32_t *c1,
+Outcome emit_pe(std::string &o, bool allow_ambig, const abm_pair &p, const Chroms &ch, const NameRef &n1,
+                const NameRef &n2, const char *s1, size_t l1, const char *s2, size_t l2, const uint32_t *c1,
                 size_t nc1, const uint32_t *c2, size_t nc2) {
   if (p.r1.pos == 0) return UNMAPPED;
   const bool ambig = p.r1.flags & 0x100;
@@ -571,8 +592,19 @@ int cmd_map(int argc, char **argv) {
   n_gpus = static_cast<int>(ctxs.size()) / per_gpu;
   const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();  // file -> host -> HBM
 
-  std::ofstream out(opt.out, std::ios::binary);
-  if (!out) throw std::runtime_error("failed to open output file: " + opt.out);
+  // ---- output file: written with pwrite at offsets fixed in slice order, so that many threads write ----
+  const int out_fd = ::open(opt.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (out_fd < 0) throw std::runtime_error("failed to open output file: " + opt.out);
+  struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) ::close(fd); } } out_closer{out_fd};
+  const bool seekable = ::lseek(out_fd, 0, SEEK_CUR) >= 0;
+  auto write_all = [&](const char *p, size_t len, uint64_t at) {
+    while (len) {
+      const ssize_t w = seekable ? ::pwrite(out_fd, p, len, static_cast<off_t>(at)) : ::write(out_fd, p, len);
+      if (w < 0) { if (errno == EINTR) continue; throw std::runtime_error("failed writing output file: " + opt.out); }
+      p += w; at += static_cast<uint64_t>(w); len -= static_cast<size_t>(w);
+    }
+  };
+  uint64_t file_offset = 0;  // bytes of output whose place is fixed
   {  // header, src/abismal.cpp:2265-2293
     std::ostringstream h;
     h << "@HD\tVN:1.0\n";
@@ -580,8 +612,11 @@ int cmd_map(int argc, char **argv) {
     h << "@PG\tID:ABISMAL\tVN:" << kVersion << "\tCL:\"";
     for (int i = 0; i < argc; ++i) h << argv[i] << ' ';
     h << "\"\n";
-    if (!opt.bam) out << h.str();
-    else { std::string z; bgzf_compress(bam_header_bytes(h.str(), ch), z); out.write(z.data(), static_cast<std::streamsize>(z.size())); }
+    std::string z;
+    if (!opt.bam) z = h.str();
+    else bgzf_compress(bam_header_bytes(h.str(), ch), z);
+    write_all(z.data(), z.size(), 0);
+    file_offset = z.size();
   }
 
   abm_params par;
@@ -594,105 +629,295 @@ int cmd_map(int argc, char **argv) {
   const int se_mode = opt.rpbat ? ABM_SE_RANDOM : ((opt.arich || opt.pbat) ? ABM_SE_A_RICH : ABM_SE_T_RICH);
   const int pe_mode = opt.rpbat ? ABM_PE_RANDOM : (opt.pbat ? ABM_PE_PBAT : ABM_PE_NORMAL);
 
-  // Staged pipeline, every stage order-agnostic except the writer:
-  //   splitter (1 thread)   cuts the FASTQ file(s) into raw batches of whole records
-  //   parsers  (-t threads) apply ReadLoader's rules and lay reads out for the C ABI
-  //   mappers  (-mappers per GPU) abm_map_{se,pe}_batch
-  //   formatters (-t)       SAM text + the batch's statistics
-  //   writer (this thread)  emits batches in input order
+  // Pipeline.  The unit of host work is a SLICE (64 k records, in file order); every stage runs on many
+  // slices at once and only the assignment of output offsets looks at their order:
+  //   cut      plain files: a pool counts newlines chunk by chunk (pread), one thread turns the counts into
+  //            slice byte ranges -- record j starts at line 4j, so no guessing at record boundaries;
+  //            gzip files: one thread per file inflates and cuts (inherently serial)
+  //   parse    (-t threads) pread the slice's text, apply ReadLoader's rules, lay the reads out for the C ABI
+  //   map      (-mappers per GPU) a mapper takes EVERY consecutive parsed slice that is ready, up to -batch
+  //            reads: batches start small (the GPU is busy a few ms after the first slice is cut) and grow
+  //            to the size at which the kernel is efficient once the host runs ahead
+  //   format   (-t) SAM text / BAM blocks and statistics per slice
+  //   write    a slice's place in the file is known once every earlier slice's size is; pwrite from any thread
   std::mutex mu;
   std::condition_variable cv;
-  struct Slice { Batch *b; size_t lo, hi; int part; };
-  std::deque<std::unique_ptr<Batch>> q_parse, q_map;
-  std::deque<Slice> q_format;
-  std::map<uint64_t, std::unique_ptr<Batch>> formatting;  // batches whose slices are being formatted
-  const size_t slice_reads = 1u << 16;
-  std::map<uint64_t, std::unique_ptr<Batch>> done;
-  uint64_t n_batches = 0, next_to_write = 0;
-  size_t in_flight = 0;
-  bool split_done = false;
-  int parsers_live = 0, mappers_live = 0, formatters_live = 0;
-  std::exception_ptr failure;
-  // Reads differ in cost by four orders of magnitude and the costliest ones keep a single wave busy
-  // for hundreds of milliseconds, so a batch must be large enough to amortise them (measured on
-  // MI355X at hg38 scale: 281 ms per 1 M reads, 589 ms per 4 M, 1437 ms per 10 M)
-  const size_t batch_reads = opt.batch ? opt.batch : (paired ? (1u << 21) : (1u << 22));
-  const size_t max_in_flight = static_cast<size_t>(2 * n_gpus * per_gpu + 3);
+  // (test hooks: ABM_CLI_SLICE_READS / ABM_CLI_CHUNK_BYTES / ABM_CLI_MARK_LINES shrink the units so that small
+  // fixtures cross many slice, chunk and mark boundaries)
+  auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
+  const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 16));
+  const bool plain_input = [&] {
+    for (const std::string &path : opt.reads) {
+      const int fd = ::open(path.c_str(), O_RDONLY);
+      if (fd < 0) throw std::runtime_error("cannot open reads file: " + path);
+      unsigned char magic[2] = {0, 0};
+      const ssize_t got = ::pread(fd, magic, 2, 0);
+      struct stat sb;
+      const bool regular = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+      ::close(fd);
+      if (!regular || (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) return false;
+    }
+    return true;
+  }();
+  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
   const unsigned n_host = std::max(1u, opt.threads);
+  const size_t max_reads_in_flight = 3 * batch_reads + 4 * slice_reads * n_host;
+  std::deque<std::unique_ptr<Slice>> q_parse;               // cut, waiting for a parser
+  std::map<uint64_t, std::unique_ptr<Slice>> parsed;        // parsed, waiting for a mapper (by slice number)
+  std::deque<Slice *> q_format;                             // mapped, waiting for a formatter
+  std::deque<Slice *> q_write;                              // formatted and placed, waiting to be written
+  std::map<uint64_t, Slice *> formatted;                    // formatted, place not yet known
+  std::map<uint64_t, uint64_t> place;                       // slice -> file offset
+  std::vector<std::unique_ptr<Batch>> live_batches;
+  std::vector<std::string> carry[2];                        // tail of the input already handed to a batch (see the mapper)
+  uint64_t n_slices = 0, next_to_map = 0, next_to_place = 0, slices_written = 0, n_batches = 0;
+  size_t reads_in_flight = 0;
+  bool cut_done = false;
+  int parsers_live = 0, mappers_live = 0;
+  std::exception_ptr failure;
   std::vector<Stats3> gpu_stats(n_gpus);
+  uint64_t total_records = 0;
   const auto t_start = std::chrono::steady_clock::now();
 
   double busy_split = 0, busy_parse = 0, busy_map = 0, busy_format = 0, busy_write = 0;  // seconds, summed over threads
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   RawPool raw_pool;
+  // ABM_CLI_TRACE=1: one line per pipeline event on stderr (milliseconds since the pipeline started)
+  const bool tracing = std::getenv("ABM_CLI_TRACE") != nullptr;
+  auto trace = [&](const char *what, uint64_t a, uint64_t b) {
+    if (!tracing) return;
+    std::fprintf(stderr, "[abm cli] t=%9.2f ms %-14s %llu %llu\n", since(t_start) * 1e3, what, static_cast<unsigned long long>(a),
+                 static_cast<unsigned long long>(b));
+  };
   auto fail = [&]() {
     std::lock_guard<std::mutex> lk(mu);
     if (!failure) failure = std::current_exception();
     cv.notify_all();
   };
+  // hands a cut slice to the parsers (blocks while too much is in flight)
+  auto emit_slice = [&](std::unique_ptr<Slice> sl, size_t records) -> bool {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return failure || reads_in_flight < max_reads_in_flight; });
+    if (failure) return false;
+    sl->g = n_slices++;
+    trace("cut", sl->g, records);
+    reads_in_flight += records;
+    q_parse.push_back(std::move(sl));
+    cv.notify_all();
+    return true;
+  };
 
-  auto splitter = [&]() {
+  // ---- cut, gzip (or non-regular) input: one inflating reader, slices carry their text
+  auto cutter_stream = [&]() {
     try {
       RawSplitter s1(opt.reads[0]);
       std::unique_ptr<RawSplitter> s2;
       if (paired) s2.reset(new RawSplitter(opt.reads[1]));
       for (;;) {
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || in_flight < max_in_flight; });
-          if (failure) break;
-        }
-        std::unique_ptr<Batch> b(new Batch);
+        std::unique_ptr<Slice> sl(new Slice);
         const auto t0 = now();
-        b->raw[0] = raw_pool.get();
-        if (paired) b->raw[1] = raw_pool.get();
-        const uint64_t l1 = s1.next(batch_reads, b->raw[0], b->first_line[0]);
+        sl->raw[0] = raw_pool.get();
+        if (paired) sl->raw[1] = raw_pool.get();
+        const uint64_t l1 = s1.next(slice_reads, sl->raw[0], sl->first_line[0]);
         uint64_t l2 = 0;
-        if (paired) l2 = s2->next(batch_reads, b->raw[1], b->first_line[1]);
+        if (paired) l2 = s2->next(slice_reads, sl->raw[1], sl->first_line[1]);
         const bool last = s1.exhausted() || (paired && s2->exhausted());
         if (l1 == 0 && (!paired || l2 == 0)) break;
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          b->seq = n_batches++;
-          busy_split += since(t0);
-          ++in_flight;
-          q_parse.push_back(std::move(b));
-        }
-        cv.notify_all();
+        { std::lock_guard<std::mutex> lk(mu); busy_split += since(t0); }
+        if (!emit_slice(std::move(sl), (l1 + 3) / 4)) break;
         if (last) break;
       }
     }
     catch (...) { fail(); }
     std::lock_guard<std::mutex> lk(mu);
-    split_done = true;
+    cut_done = true;
+    cv.notify_all();
+  };
+
+  // ---- cut, plain files: newline counts per chunk (parallel), then slice byte ranges (serial, cheap)
+  struct ChunkInfo { uint64_t lines = 0; std::vector<uint32_t> marks; bool ready = false; };  // marks: offset just past every kMark-th newline
+  const uint64_t kChunk = env_or("ABM_CLI_CHUNK_BYTES", 8u << 20), kMark = env_or("ABM_CLI_MARK_LINES", 1024);
+  struct LineFile {
+    int fd = -1;
+    uint64_t size = 0, n_chunks = 0;
+    std::vector<ChunkInfo> chunks;
+    uint64_t next_chunk = 0;  // next chunk a counter thread takes
+    bool ends_with_newline = true;
+  };
+  std::vector<LineFile> lf(plain_input ? opt.reads.size() : 0);
+  for (size_t e = 0; e < lf.size(); ++e) {
+    lf[e].fd = ::open(opt.reads[e].c_str(), O_RDONLY);
+    if (lf[e].fd < 0) throw std::runtime_error("cannot open reads file: " + opt.reads[e]);
+    struct stat sb;
+    if (::fstat(lf[e].fd, &sb) != 0) throw std::runtime_error("cannot stat reads file: " + opt.reads[e]);
+    lf[e].size = static_cast<uint64_t>(sb.st_size);
+    lf[e].n_chunks = (lf[e].size + kChunk - 1) / kChunk;
+    lf[e].chunks.resize(lf[e].n_chunks);
+    if (lf[e].size) { char c = 0; if (::pread(lf[e].fd, &c, 1, static_cast<off_t>(lf[e].size - 1)) == 1) lf[e].ends_with_newline = c == '\n'; }
+  }
+  auto read_range = [&](int fd, const std::string &path, char *dst, uint64_t lo, uint64_t hi) {
+    while (lo < hi) {
+      const ssize_t got = ::pread(fd, dst, hi - lo, static_cast<off_t>(lo));
+      if (got < 0) { if (errno == EINTR) continue; throw std::runtime_error("error reading " + path); }
+      if (got == 0) throw std::runtime_error("unexpected end of " + path);
+      dst += got; lo += static_cast<uint64_t>(got);
+    }
+  };
+  auto counter = [&]() {  // counts the newlines of whole chunks, in file order per file, ahead of the cutter
+    try {
+      std::vector<char> buf(kChunk);
+      for (;;) {
+        size_t e = 0; uint64_t k = 0; bool got = false;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          if (failure) break;
+          // the file whose index is least advanced (both files of a pair are cut in step)
+          size_t best = lf.size();
+          for (size_t f = 0; f < lf.size(); ++f)
+            if (lf[f].next_chunk < lf[f].n_chunks && (best == lf.size() || lf[f].next_chunk < lf[best].next_chunk)) best = f;
+          if (best != lf.size()) { e = best; k = lf[e].next_chunk++; got = true; }
+        }
+        if (!got) break;
+        const auto t0 = now();
+        const uint64_t lo = k * kChunk, hi = std::min(lf[e].size, lo + kChunk);
+        read_range(lf[e].fd, opt.reads[e], buf.data(), lo, hi);
+        ChunkInfo ci;
+        const char *p = buf.data(), *end = p + (hi - lo);
+        uint64_t until_mark = kMark;
+        while (p < end) {  // block counts vectorise; a block holding a mark is walked newline by newline
+          const size_t blk = std::min<size_t>(static_cast<size_t>(end - p), 4096);
+          uint32_t c = 0;
+          for (size_t i = 0; i < blk; ++i) c += (p[i] == '\n');
+          if (c < until_mark) { until_mark -= c; ci.lines += c; p += blk; continue; }
+          const char *q = p, *bend = p + blk;
+          while (q < bend) {
+            const char *nl = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(bend - q)));
+            if (!nl) break;
+            ++ci.lines;
+            q = nl + 1;
+            if (--until_mark == 0) { ci.marks.push_back(static_cast<uint32_t>(q - buf.data())); until_mark = kMark; }
+          }
+          p = bend;
+        }
+        ci.ready = true;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          lf[e].chunks[k] = std::move(ci);
+          busy_split += since(t0);
+        }
+        cv.notify_all();
+      }
+    }
+    catch (...) { fail(); }
+  };
+  // byte offset just past newline number `line` (1-based count of newlines) of file e; chunks up to the one
+  // holding it must be ready.  cum[k] = newlines before chunk k.
+  struct Cursor { uint64_t chunk = 0, cum = 0; };  // first chunk not yet passed, newlines before it
+  auto offset_after_line = [&](size_t e, Cursor &cur, uint64_t line, uint64_t &off_out) -> bool {
+    // returns false if the file has fewer newlines
+    LineFile &F = lf[e];
+    for (;;) {
+      if (cur.chunk >= F.n_chunks) return false;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failure || F.chunks[cur.chunk].ready; });
+        if (failure) throw std::runtime_error("aborted");
+      }
+      const ChunkInfo &ci = F.chunks[cur.chunk];
+      if (cur.cum + ci.lines >= line) break;
+      cur.cum += ci.lines;
+      ++cur.chunk;
+    }
+    const ChunkInfo &ci = F.chunks[cur.chunk];
+    const uint64_t local = line - cur.cum;          // the local-th newline of this chunk, 1-based
+    const uint64_t mark = local / kMark;            // marks[m - 1] = offset past newline m * kMark
+    uint64_t at = mark ? ci.marks[mark - 1] : 0, seen = mark * kMark;
+    const uint64_t base = cur.chunk * kChunk, hi = std::min(F.size, base + kChunk);
+    std::vector<char> buf;
+    while (seen < local) {  // walk the <= kMark lines after the mark
+      const uint64_t want = std::min<uint64_t>(hi - (base + at), 1u << 16);
+      if (want == 0) return false;
+      buf.resize(want);
+      read_range(F.fd, opt.reads[e], buf.data(), base + at, base + at + want);
+      const char *p = buf.data(), *end = p + want;
+      while (p < end && seen < local) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        if (!nl) { p = end; break; }
+        ++seen;
+        p = nl + 1;
+      }
+      at += static_cast<uint64_t>(p - buf.data());
+    }
+    off_out = base + at;
+    return true;
+  };
+  auto cutter_plain = [&]() {
+    try {
+      Cursor cur[2];
+      uint64_t lo[2] = {0, 0}, line = 0;
+      bool done[2] = {false, false};
+      const size_t nf = lf.size();
+      for (;;) {
+        std::unique_ptr<Slice> sl(new Slice);
+        const uint64_t target = line + 4 * slice_reads;  // newlines before the next slice
+        uint64_t recs = 0;
+        bool any = false;
+        for (size_t e = 0; e < nf; ++e) {
+          sl->first_line[e] = line;
+          sl->byte_lo[e] = lo[e];
+          uint64_t hi = 0;
+          if (!done[e] && offset_after_line(e, cur[e], target, hi)) sl->byte_hi[e] = hi;
+          else { sl->byte_hi[e] = lf[e].size; done[e] = true; }
+          lo[e] = sl->byte_hi[e];
+          any |= sl->byte_hi[e] > sl->byte_lo[e];
+        }
+        if (!any) break;
+        recs = slice_reads;  // (the last slice may hold fewer; the figure only bounds memory in flight)
+        const bool last = done[0] || (nf == 2 && done[1]);
+        if (!emit_slice(std::move(sl), recs)) break;
+        line = target;
+        if (last) break;
+      }
+    }
+    catch (...) { fail(); }
+    std::lock_guard<std::mutex> lk(mu);
+    cut_done = true;
     cv.notify_all();
   };
 
   auto parser = [&]() {
     try {
       for (;;) {
-        std::unique_ptr<Batch> b;
+        std::unique_ptr<Slice> sl;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || !q_parse.empty() || split_done; });
+          cv.wait(lk, [&] { return failure || !q_parse.empty() || cut_done; });
           if (failure || q_parse.empty()) break;
-          b = std::move(q_parse.front());
+          sl = std::move(q_parse.front());
           q_parse.pop_front();
         }
         const auto t0 = now();
         for (int e = 0; e < (paired ? 2 : 1); ++e) {
-          parse_raw(b->raw[e], b->first_line[e], opt.reads[e], b->names[e], b->blob[e], b->off[e]);
-          raw_pool.put(std::move(b->raw[e]));
+          if (plain_input) {
+            sl->raw[e] = raw_pool.get();
+            const uint64_t len = sl->byte_hi[e] - sl->byte_lo[e];
+            sl->raw[e].reserve(len + 1);
+            read_range(lf[e].fd, opt.reads[e], sl->raw[e].p, sl->byte_lo[e], sl->byte_hi[e]);
+            sl->raw[e].n = len;
+          }
+          parse_raw(sl->raw[e], sl->first_line[e], opt.reads[e], sl->names[e], sl->blob[e], sl->off[e]);
         }
-        if (paired && b->names[0].size() != b->names[1].size())
-          throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(b->names[0].size()) +
-                                   ", batch 2: " + std::to_string(b->names[1].size()) +
+        if (paired && sl->names[0].size() != sl->names[1].size())
+          throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(sl->names[0].size()) +
+                                   ", batch 2: " + std::to_string(sl->names[1].size()) +
                                    ". Are you sure your paired-end inputs have the same number of reads?");
         {
           std::lock_guard<std::mutex> lk(mu);
           busy_parse += since(t0);
-          q_map.push_back(std::move(b));
+          const uint64_t g = sl->g;
+          trace("parsed", g, static_cast<uint64_t>(since(t0) * 1e6));
+          parsed[g] = std::move(sl);
         }
         cv.notify_all();
       }
@@ -708,52 +933,124 @@ int cmd_map(int argc, char **argv) {
     abm_ctx *ctx = ctxs[slot];
     try {
       for (;;) {
-        std::unique_ptr<Batch> b;
+        std::unique_ptr<Batch> owned(new Batch);
+        Batch *b = owned.get();
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || !q_map.empty() || parsers_live == 0; });
-          if (failure || q_map.empty()) break;
-          b = std::move(q_map.front());
-          q_map.pop_front();
+          cv.wait(lk, [&] { return failure || parsed.count(next_to_map) || (parsers_live == 0 && parsed.empty()); });
+          if (failure || !parsed.count(next_to_map)) break;
+          // every consecutive slice that is ready, up to the batch size
+          while (b->n < batch_reads) {
+            auto it = parsed.find(next_to_map);
+            if (it == parsed.end()) break;
+            if (!b->slices.empty() && b->n + it->second->n() > batch_reads) break;
+            b->n += it->second->n();
+            b->slices.push_back(std::move(it->second));
+            parsed.erase(it);
+            ++next_to_map;
+          }
+          b->seq = n_batches++;
+          b->gpu = g;
+          b->slices_left = static_cast<int>(b->slices.size());
+          // Reads of 44-46 bases see what earlier reads left in the reference's reused buffers:
+          // the mapper looks for that among the reads handed over in the same call, so a batch is led by the
+          // tail of the input before it -- from the last record whose reads are all longer than 46 bases on
+          // (nearly always just that one record) -- whose results are dropped.
+          b->carry[0] = carry[0];
+          b->carry[1] = carry[1];
+          {
+            std::vector<std::string> next[2];
+            bool closed = false;
+            for (size_t si = b->slices.size(); si-- > 0 && !closed;) {
+              const Slice &sl = *b->slices[si];
+              for (size_t k = sl.n(); k-- > 0 && !closed;) {
+                bool all_long = true;
+                for (int e = 0; e < (paired ? 2 : 1); ++e) {
+                  const size_t len = sl.off[e][k + 1] - sl.off[e][k];
+                  next[e].emplace_back(sl.blob[e].data() + sl.off[e][k], len);
+                  all_long &= len > 46;
+                }
+                closed = all_long || next[0].size() >= 256;
+              }
+            }
+            if (!closed && next[0].size() < 256)  // the whole batch had no such record: keep the older tail too
+              for (int e = 0; e < (paired ? 2 : 1); ++e)
+                for (size_t k = carry[e].size(); k-- > 0 && next[e].size() < 256;) next[e].push_back(carry[e][k]);
+            for (int e = 0; e < (paired ? 2 : 1); ++e) { std::reverse(next[e].begin(), next[e].end()); carry[e].swap(next[e]); }
+          }
+          live_batches.push_back(std::move(owned));
         }
-        b->gpu = g;
-        const size_t n = b->n();
+        const size_t lead = b->carry[0].size();
+        const size_t n = b->n + lead;
         const auto t0 = now();
+        trace("batch formed", b->seq, n);
+        // the slices' reads, concatenated as the C ABI takes them (a single slice with nothing to lead it is used in place)
+        const bool one = b->slices.size() == 1 && lead == 0;
+        for (int e = 0; e < (paired ? 2 : 1); ++e) {
+          if (one) continue;
+          size_t bytes = 0;
+          for (const std::string &c : b->carry[e]) bytes += c.size();
+          for (auto &sl : b->slices) bytes += sl->blob[e].size();
+          b->blob[e].resize(bytes);
+          b->off[e].resize(n + 1);
+          size_t at = 0, r = 0;
+          for (const std::string &c : b->carry[e]) {
+            std::memcpy(&b->blob[e][at], c.data(), c.size());
+            b->off[e][r++] = at;
+            at += c.size();
+          }
+          for (auto &sl : b->slices) {
+            std::memcpy(&b->blob[e][at], sl->blob[e].data(), sl->blob[e].size());
+            const size_t m = sl->n();
+            for (size_t i = 0; i < m; ++i) b->off[e][r + i] = sl->off[e][i] + at;
+            at += sl->blob[e].size();
+            r += m;
+          }
+          b->off[e][n] = at;
+        }
+        {
+          size_t base = lead;
+          for (auto &sl : b->slices) { sl->batch = b; sl->base = base; base += sl->n(); }
+        }
+        const char *blob_p[2];
+        const uint64_t *off_p[2];
+        size_t blob_n[2];
+        for (int e = 0; e < 2; ++e) {
+          blob_p[e] = one ? b->slices[0]->blob[e].data() : b->blob[e].data();
+          off_p[e] = one ? b->slices[0]->off[e].data() : b->off[e].data();
+          blob_n[e] = one ? b->slices[0]->blob[e].size() : b->blob[e].size();
+        }
+        trace("batch ready", b->seq, n);
         if (n) {
           // a few CIGAR ops per read are typical; the worst case (read length + 2 each) is only
           // allocated if the first size turns out too small
-          const uint64_t worst = std::max<uint64_t>(1, std::max(b->blob[0].size(), b->blob[1].size()) + 2 * n);
+          const uint64_t worst = std::max<uint64_t>(1, std::max(blob_n[0], blob_n[1]) + 2 * n);
           uint64_t cap = std::min<uint64_t>(worst, 4 * n + 1024);
           for (;;) {
             int rc;
             if (!paired) {
               b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
-              rc = abm_map_se_batch(ctx, se_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->se[0].data(),
+              rc = abm_map_se_batch(ctx, se_mode, &par, n, blob_p[0], off_p[0], b->se[0].data(),
                                     b->cig[0].data(), cap, b->cig_off[0].data());
             }
             else {
               b->pairs.resize(n); b->se[0].resize(n); b->se[1].resize(n);
               for (int e = 0; e < 2; ++e) { b->cig[e].resize(cap); b->cig_off[e].resize(n + 1); }
-              rc = abm_map_pe_batch(ctx, pe_mode, &par, n, b->blob[0].data(), b->off[0].data(), b->blob[1].data(),
-                                    b->off[1].data(), b->pairs.data(), b->se[0].data(), b->se[1].data(), b->cig[0].data(),
-                                    b->cig_off[0].data(), b->cig[1].data(), b->cig_off[1].data(), cap);
+              rc = abm_map_pe_batch(ctx, pe_mode, &par, n, blob_p[0], off_p[0], blob_p[1], off_p[1], b->pairs.data(),
+                                    b->se[0].data(), b->se[1].data(), b->cig[0].data(), b->cig_off[0].data(),
+                                    b->cig[1].data(), b->cig_off[1].data(), cap);
             }
             if (rc == 0) break;
             if (rc == ABM_ERR_CAPACITY && cap < worst) { cap = worst; continue; }
             die_abm("mapping");
           }
         }
+        else { b->cig_off[0].assign(1, 0); b->cig_off[1].assign(1, 0); }
+        trace("batch mapped", b->seq, n);
         {
-          const int n_parts = static_cast<int>(std::max<size_t>(1, (n + slice_reads - 1) / slice_reads));
-          b->parts.resize(n_parts);
-          b->part_stats.resize(n_parts);
-          b->parts_left = n_parts;
           std::lock_guard<std::mutex> lk(mu);
           busy_map += since(t0);
-          Batch *raw = b.get();
-          formatting[raw->seq] = std::move(b);
-          for (int k = 0; k < n_parts; ++k)
-            q_format.push_back(Slice{raw, k * slice_reads, std::min(n, (k + 1) * slice_reads), k});
+          for (auto &sl : b->slices) q_format.push_back(sl.get());
         }
         cv.notify_all();
       }
@@ -764,36 +1061,41 @@ int cmd_map(int argc, char **argv) {
     cv.notify_all();
   };
 
-  auto format_slice = [&](Batch &bt, size_t lo, size_t hi, std::string &sam, Stats3 &st) {
-    Batch *b = &bt;
+  auto format_slice = [&](Slice &sl) {
+    const Batch *b = sl.batch;
     t_bam = opt.bam;
-    sam.reserve((hi - lo) * (paired ? 2 : 1) * 320);
+    std::string &sam = sl.text;
+    Stats3 &st = sl.stats;
+    const size_t m = sl.n(), base = sl.base;
+    sam.reserve(m * (paired ? 2 : 1) * 320);
     if (!paired) {
-      for (size_t i = lo; i < hi; ++i) {
+      for (size_t k = 0; k < m; ++k) {
+        const size_t i = base + k;
         abm_hit h = b->se[0][i];
-        const size_t len = b->off[0][i + 1] - b->off[0][i];
+        const size_t len = sl.off[0][k + 1] - sl.off[0][k];
         const uint32_t *cg = b->cig[0].data() + b->cig_off[0][i];
         const size_t ncg = b->cig_off[0][i + 1] - b->cig_off[0][i];
-        if (len && emit_se(sam, opt.ambig, h, ch, b->names[0][i], b->blob[0].data() + b->off[0][i], len, cg, ncg) == UNMAPPED) h.pos = 0;
+        if (len && emit_se(sam, opt.ambig, h, ch, sl.names[0][k], sl.blob[0].data() + sl.off[0][k], len, cg, ncg) == UNMAPPED) h.pos = 0;
         st.s[0].tally(len == 0, h, opt.ambig, ref_len(cg, ncg));
       }
       return;
     }
-    for (size_t i = lo; i < hi; ++i) {
+    for (size_t k = 0; k < m; ++k) {
+      const size_t i = base + k;
       abm_pair p = b->pairs[i];
       abm_hit h1 = b->se[0][i], h2 = b->se[1][i];
-      const char *s1 = b->blob[0].data() + b->off[0][i], *s2 = b->blob[1].data() + b->off[1][i];
-      const size_t l1 = b->off[0][i + 1] - b->off[0][i], l2 = b->off[1][i + 1] - b->off[1][i];
+      const char *s1 = sl.blob[0].data() + sl.off[0][k], *s2 = sl.blob[1].data() + sl.off[1][k];
+      const size_t l1 = sl.off[0][k + 1] - sl.off[0][k], l2 = sl.off[1][k + 1] - sl.off[1][k];
       const uint32_t *c1 = b->cig[0].data() + b->cig_off[0][i], *c2 = b->cig[1].data() + b->cig_off[1][i];
       const size_t nc1 = b->cig_off[0][i + 1] - b->cig_off[0][i], nc2 = b->cig_off[1][i + 1] - b->cig_off[1][i];
       // select_output, src/abismal.cpp:1073-1088
-      const Outcome po = emit_pe(sam, opt.ambig, p, ch, b->names[0][i], b->names[1][i], s1, l1, s2, l2, c1, nc1, c2, nc2);
+      const Outcome po = emit_pe(sam, opt.ambig, p, ch, sl.names[0][k], sl.names[1][k], s1, l1, s2, l2, c1, nc1, c2, nc2);
       const bool report = p.r1.pos != 0 && (opt.ambig || !(p.r1.flags & 0x100));
       bool pair_ok = report;
       if (!report || po == UNMAPPED) {
         if (po == UNMAPPED) { p.r1.pos = 0; p.r2.pos = 0; pair_ok = false; }
-        if (emit_se(sam, opt.ambig, h1, ch, b->names[0][i], s1, l1, c1, nc1) == UNMAPPED) h1.pos = 0;
-        if (emit_se(sam, opt.ambig, h2, ch, b->names[1][i], s2, l2, c2, nc2) == UNMAPPED) h2.pos = 0;
+        if (emit_se(sam, opt.ambig, h1, ch, sl.names[0][k], s1, l1, c1, nc1) == UNMAPPED) h1.pos = 0;
+        if (emit_se(sam, opt.ambig, h2, ch, sl.names[1][k], s2, l2, c2, nc2) == UNMAPPED) h2.pos = 0;
       }
       // paired_end_mapping_statistics::update, :1039-1057
       Stats &ps = st.s[0];
@@ -808,89 +1110,98 @@ int cmd_map(int argc, char **argv) {
     }
   };
 
-  auto formatter = [&]() {
+  // formats slices and writes the ones whose place in the file is known (any worker does either)
+  auto worker = [&]() {
     try {
       for (;;) {
-        Slice sl;
+        Slice *to_format = nullptr, *to_write = nullptr;
+        uint64_t at = 0;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || !q_format.empty() || mappers_live == 0; });
-          if (failure || q_format.empty()) break;
-          sl = q_format.front();
-          q_format.pop_front();
+          cv.wait(lk, [&] { return failure || !q_write.empty() || !q_format.empty() || (mappers_live == 0 && slices_written == n_slices && cut_done); });
+          if (failure) break;
+          if (!q_write.empty()) { to_write = q_write.front(); q_write.pop_front(); at = place[to_write->g]; place.erase(to_write->g); }
+          else if (!q_format.empty()) { to_format = q_format.front(); q_format.pop_front(); }
+          else break;
         }
-        const auto t0 = now();
-        std::string &text = sl.b->parts[sl.part];
-        format_slice(*sl.b, sl.lo, sl.hi, text, sl.b->part_stats[sl.part]);
-        if (opt.bam) { std::string z; bgzf_compress(text, z); text.swap(z); }
-        {
+        if (to_format) {
+          const auto t0 = now();
+          format_slice(*to_format);
+          if (opt.bam) { std::string z; bgzf_compress(to_format->text, z); to_format->text.swap(z); }
           std::lock_guard<std::mutex> lk(mu);
           busy_format += since(t0);
-          if (--sl.b->parts_left == 0) {
-            auto it = formatting.find(sl.b->seq);
-            done[sl.b->seq] = std::move(it->second);
-            formatting.erase(it);
+          trace("formatted", to_format->g, static_cast<uint64_t>(since(t0) * 1e6));
+          formatted[to_format->g] = to_format;
+          // fix the place of every slice whose predecessors are all formatted
+          for (auto it = formatted.find(next_to_place); it != formatted.end(); it = formatted.find(next_to_place)) {
+            place[next_to_place] = file_offset;
+            file_offset += it->second->text.size();
+            q_write.push_back(it->second);
+            formatted.erase(it);
+            ++next_to_place;
           }
+          cv.notify_all();
         }
-        cv.notify_all();
+        else {
+          const auto t0 = now();
+          if (!seekable) {  // a pipe: slices leave one at a time, in order (they were queued in order)
+            static std::mutex pipe_mu;
+            static uint64_t pipe_next = 0;
+            static std::condition_variable pipe_cv;
+            std::unique_lock<std::mutex> pk(pipe_mu);
+            pipe_cv.wait(pk, [&] { return pipe_next == to_write->g; });
+            write_all(to_write->text.data(), to_write->text.size(), at);
+            ++pipe_next;
+            pipe_cv.notify_all();
+          }
+          else write_all(to_write->text.data(), to_write->text.size(), at);
+          std::lock_guard<std::mutex> lk(mu);
+          busy_write += since(t0);
+          trace("written", to_write->g, static_cast<uint64_t>(since(t0) * 1e6));
+          Batch *b = to_write->batch;
+          total_records += to_write->n();
+          for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += to_write->stats.s[k].v[j];
+          reads_in_flight -= std::min<size_t>(reads_in_flight, slice_reads);
+          ++slices_written;
+          // give the slice's memory back at once; the batch goes when its last slice has
+          for (int e = 0; e < 2; ++e) if (to_write->raw[e].p) raw_pool.put(std::move(to_write->raw[e]));
+          std::string().swap(to_write->text);
+          if (--b->slices_left == 0) {
+            for (auto it = live_batches.begin(); it != live_batches.end(); ++it)
+              if (it->get() == b) { live_batches.erase(it); break; }
+          }
+          cv.notify_all();
+        }
       }
     }
     catch (...) { fail(); }
     std::lock_guard<std::mutex> lk(mu);
-    --formatters_live;
     cv.notify_all();
   };
 
   std::vector<std::thread> threads;
   parsers_live = static_cast<int>(n_host);
   mappers_live = n_gpus * per_gpu;
-  formatters_live = static_cast<int>(n_host);
-  threads.emplace_back(splitter);
+  if (plain_input) {
+    const unsigned n_count = std::max(1u, std::min(n_host, 16u));
+    for (unsigned t = 0; t < n_count; ++t) threads.emplace_back(counter);
+    threads.emplace_back(cutter_plain);
+  }
+  else threads.emplace_back(cutter_stream);
   for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(parser);
   for (int slot = 0; slot < n_gpus * per_gpu; ++slot) threads.emplace_back(mapper, slot);
-  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(formatter);
-  uint64_t total_records = 0;
-  {  // writer: batches leave in input order
-    std::unique_lock<std::mutex> lk(mu);
-    for (;;) {
-      cv.wait(lk, [&] { return failure || done.count(next_to_write) || (formatters_live == 0 && done.empty()); });
-      if (failure) break;
-      auto it = done.find(next_to_write);
-      if (it == done.end()) {
-        if (formatters_live == 0 && done.empty()) break;
-        continue;
-      }
-      std::unique_ptr<Batch> b = std::move(it->second);
-      done.erase(it);
-      ++next_to_write;
-      --in_flight;
-      lk.unlock();
-      const auto t0 = now();
-      for (const std::string &part : b->parts) out.write(part.data(), static_cast<std::streamsize>(part.size()));
-      if (!out) {  // a full disk must not end in a truncated file and exit code 0
-        lk.lock();
-        if (!failure) failure = std::make_exception_ptr(std::runtime_error("failed writing output file: " + opt.out));
-        break;
-      }
-      total_records += b->n();
-      for (const Stats3 &ps : b->part_stats)
-        for (int k = 0; k < 3; ++k)
-          for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += ps.s[k].v[j];
-      b.reset();
-      busy_write += since(t0);
-      cv.notify_all();
-      lk.lock();
-    }
-  }
-  cv.notify_all();
+  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(worker);
   for (auto &t : threads) t.join();
+  for (LineFile &F : lf) if (F.fd >= 0) ::close(F.fd);
   if (failure) std::rethrow_exception(failure);
   if (opt.bam) {  // BGZF end-of-file marker
     static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    out.write(reinterpret_cast<const char *>(eof_block), 28);
+    write_all(reinterpret_cast<const char *>(eof_block), 28, file_offset);
+    file_offset += 28;
   }
-  out.close();
-  if (!out) throw std::runtime_error("failed writing output file: " + opt.out);
+  out_closer.fd = -1;
+  if (::close(out_fd) != 0) throw std::runtime_error("failed writing output file: " + opt.out);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
   // statistics (6 counters x 3 structs, src/abismal.cpp:865-895, :1034-1037).  Every GPU's counters

@@ -154,6 +154,8 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
           if (lane == 0) lds.qbits[e * a.WB + wb] = word;
         }
       __syncthreads();
+      if (L < max(kWindow, L >> 1) + kKeyWeight - 1)  // 44-46 bases: seeds reach past the end of the read
+        ghost_bits(a.packed, a.lens, r, L, a.max_len, a.W, a.WB, lds.qbits);
 
       SeSet S;
       S.begin_read(L);

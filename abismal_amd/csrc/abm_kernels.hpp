@@ -29,6 +29,7 @@ struct SeArgs {
   u8 *need_big;       // [n] reads the main kernel gave up
   u64 n_reads;
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
+  u32 max_len;        // longest read of the batch
   u32 tb_extra;       // tb_extra_bytes()
   u32 G;              // lanes sharing one candidate window (WaveLds::G)
   int mode;           // ABM_SE_*
@@ -55,7 +56,7 @@ struct PeArgs {
   const u32 *subset;             // tier 2: ids of the pairs to redo
   const u32 *subset_count;       // tier 2: how many
   u64 n_pairs;
-  u32 W, WB, GW, tb_extra, G;
+  u32 W, WB, GW, tb_extra, G, max_len;
   int mode;
   double valid_frac;
   u32 min_frag, max_frag;

@@ -180,17 +180,23 @@ __device__ __forceinline__ u32 first_not(u32 lo, u32 hi, u32 &probes, Below belo
   return lo;
 }
 
-// find_candidates, src/abismal.cpp:1163-1194 (range as indices into tbl[])
+// find_candidates, src/abismal.cpp:1163-1194 (range as indices into tbl[]).  The read's letters come
+// from its 2-letter bit string qb (n_bits of it; 1 beyond): the loop ends at p == limit, and for reads
+// of 44-46 bases limit = L - i is BELOW the starting length for the last offsets, so the reference
+// keeps extending past the end of the read, through whatever its reused buffer holds there (the
+// ghost bits the kernel puts into qb: ghost_bits).
 __device__ __forceinline__ u32 narrow2(const u64 *__restrict__ genome, const u32 *__restrict__ tbl,
-                                       const u64 *qpk, u32 qbase, u32 limit, u32 maxc, u32 &lo,
+                                       const u64 *qb, u32 n_bits, u32 qbase, u32 limit, u32 maxc, u32 &lo,
                                        u32 &hi, u32 &probes) {
   u32 p = kKeyWeight, plo = lo, phi = hi;
-  for (; p != limit && (hi - lo) > maxc; ++p) {
+  for (; p != limit && (hi - lo) > maxc && qbase + p < n_bits + 4096u; ++p) {
     plo = lo; phi = hi;
     const u32 ones = first_not(lo, hi, probes, [&](u32 k) {
       return bit2(gnib(genome, static_cast<u64>(tbl[k]) + p)) < 1u;
     });
-    if (bit2(q_nibble(qpk, qbase + p))) lo = ones; else hi = ones;
+    const u32 at = qbase + p;
+    const bool one = at < n_bits ? ((qb[at >> 6] >> (at & 63u)) & 1ull) != 0 : true;
+    if (one) lo = ones; else hi = ones;
   }
   if (lo == hi) { --p; lo = plo; hi = phi; }
   return p;
@@ -532,6 +538,42 @@ struct HelpWave {  // one wave's view of the help workspace (see HelpArgs)
   }
 };
 
+// Ghost bits.  The reference hashes a read's first max(20, L/2) seed offsets and extends the last
+// ones while their buckets are too big; for reads of 44-46 bases that reaches PAST the end of the read,
+// into whatever the reused per-thread buffer of that encoding still holds: position k carries the
+// nibble the nearest earlier read longer than k left there (prep_read only resizes;
+// src/abismal.cpp:1163-1194, :1302-1308, :1377-1386; zero where nothing was written).
+// This rebuilds those 2-letter bits for positions L .. L+63 of the four encodings of read r from the
+// reads handed over before it (lens / packed of the same batch, input order = the reference at -t 1)
+// and writes them into the bit strings qbits (>= 2 words per encoding).  Lane j <-> position L + j.
+__device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const u32 *__restrict__ lens, u64 r, u32 L,
+                                           u32 max_len, u32 W, u32 WB, u64 *qbits) {
+  const int lane = lane_id();
+  const u32 k = L + static_cast<u32>(lane);
+  bool found = k >= max_len;  // no read of this batch ever wrote that far: still the zero fill
+  u64 src = 0;
+  for (u64 base = r; base > 0 && __ballot(!found) != 0; base = base > 64 ? base - 64 : 0) {
+    const u32 len_q = base > static_cast<u64>(lane) ? lens[base - 1 - lane] : 0u;
+    for (int t = 0; t < 64; ++t) {
+      const u32 lt = rdlane(len_q, t);
+      if (!found && lt >= kMinReadLen && lt > k) { found = true; src = base - 1 - t; }
+    }
+  }
+  const bool have = found && k < max_len && src < r && lens[src] > k;
+#pragma unroll
+  for (u32 e = 0; e < 4; ++e) {
+    u32 nib = 0;
+    if (have) nib = static_cast<u32>(packed[(src * 4 + e) * W + (k >> 4)] >> ((k & 15u) << 2)) & 15u;
+    const u64 m = __ballot(bit2(nib) != 0);  // bit j = 2-letter bit at position L + j (1 for the zero fill)
+    if (lane == 0) {
+      const u64 real = qbits[e * WB] & ((1ull << L) - 1);
+      qbits[e * WB] = real | (m << L);
+      qbits[e * WB + 1] = (m >> (64 - L)) | (~0ull << L);
+    }
+  }
+  __syncthreads();
+}
+
 // distances and positions of candidates [c0, c0 + 128) of a flattened block (two per lane: c0 + lane
 // and c0 + 64 + lane), reached out of sequence -- what a claimed chunk of a job computes
 __device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qpk, const u32 *idx3,
@@ -662,7 +704,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
       if (SPECIFIC) {
         u32 probes = 0;
-        const u32 len2 = narrow2(ix.genome, ix.index, qpk, i, L - i, maxc, lo2, hi2, probes);
+        const u32 len2 = narrow2(ix.genome, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
         const u32 len3 = narrow3(ix.genome, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
         chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;

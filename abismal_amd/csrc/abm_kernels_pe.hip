@@ -843,6 +843,10 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
         if (lane == 0) lds.qbits[e8 * a.WB + wb] = word;
       }
     __syncthreads();
+    #pragma unroll
+    for (int e = 0; e < 2; ++e)  // 44-46 bases: seeds reach past the end of the read (see ghost_bits)
+      if (w.L[e] >= kMinReadLen && w.L[e] < max(kWindow, w.L[e] >> 1) + kKeyWeight - 1)
+        ghost_bits(e ? a.packed2 : a.packed1, e ? a.lens2 : a.lens1, r, w.L[e], a.max_len, a.W, a.WB, lds.qbits + e * 4 * a.WB);
 
     PairBest best;
     best.f1 = best.f2 = 0;

@@ -586,7 +586,7 @@ def main():
         os.replace(idx + ".tmp", idx)  # atomic: a waiting rank never sees a partial file
         t_build = time.time() - t0
         log(f"index built in {t_build:.1f}s ({os.path.getsize(idx) / 1e9:.2f} GB)")
-        if args.no_e2e or args.pe:
+        if (args.no_e2e or args.pe) and not os.environ.get("ABM_BENCH_KEEP_FASTA"):
             os.remove(fasta)  # (the end-to-end leg simulates its FASTQ from this file)
     t_wait = time.time()
     while not os.path.exists(idx):

@@ -104,6 +104,11 @@ int abo_map_se(void *mapper, int mode, uint64_t n, const char *blob, const uint6
     try {
       Mapper mp(*b->ix, b->par);
       Cigar c;
+      {  // the reads before this shard, back to one longer than 46 bases, leave their trace in the buffers
+        uint64_t from = lo;
+        while (from > 0 && lo - from < 4096) { --from; if (off[from + 1] - off[from] > 46) break; }
+        for (uint64_t i = from; i < lo; ++i) mp.touch_se(std::string(blob + off[i], blob + off[i + 1]), static_cast<SeMode>(mode));
+      }
       for (uint64_t i = lo; i < hi; ++i) {
         Hit h;
         c.clear();
@@ -144,6 +149,16 @@ int abo_map_pe(void *mapper, int mode, uint64_t n, const char *blob1, const uint
     try {
       Mapper mp(*b->ix, b->par);
       Cigar c1, c2;
+      {  // (see abo_map_se)
+        uint64_t from = lo;
+        while (from > 0 && lo - from < 4096) {
+          --from;
+          if (off1[from + 1] - off1[from] > 46 && off2[from + 1] - off2[from] > 46) break;
+        }
+        for (uint64_t i = from; i < lo; ++i)
+          mp.touch_pe(std::string(blob1 + off1[i], blob1 + off1[i + 1]), std::string(blob2 + off2[i], blob2 + off2[i + 1]),
+                      static_cast<PeMode>(mode));
+      }
       for (uint64_t i = lo; i < hi; ++i) {
         PairHit p;
         Hit h1, h2;

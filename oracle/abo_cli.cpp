@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -315,23 +317,65 @@ int cmd_map(int argc, char **argv) {
   const bool paired = a.pos.size() == 2;
   constexpr std::size_t kBatch = 1000;  // src/abismal.cpp:207
 
+  // -t n (single-end): the batch is cut into n contiguous shares mapped by n mappers; a share's mapper
+  // first replays, for their side effect on its reused buffers only, the reads before the share
+  // (Mapper::touch_se), so the output equals the reference at -t 1 whatever n is.
+  const unsigned n_threads = std::max(1u, static_cast<unsigned>(std::stoul(a.get("t", a.get("threads", "1")))));
   if (!paired) {
     const SeMode mode = rpbat ? SE_RANDOM : ((arich || pbat) ? SE_A_RICH : SE_T_RICH);
     FastqReader rd(a.pos[0]);
-    Cigar cig;
+    const std::size_t batch = n_threads > 1 ? 4096u * n_threads : kBatch;
+    std::vector<std::unique_ptr<Mapper>> mappers;
+    for (unsigned t = 0; t < n_threads; ++t) mappers.emplace_back(new Mapper(ix, par));
+    std::vector<std::string> tail;  // the reads just before the batch, back to one longer than 46 bases
+    std::vector<Hit> bests;
+    std::vector<Cigar> cigs;
     while (rd.alive) {
-      rd.load(kBatch, n1, s1);
+      rd.load(batch, n1, s1);
+      const std::size_t n = s1.size();
+      bests.assign(n, Hit());
+      cigs.assign(n, Cigar());
+      auto share = [&](unsigned t) {
+        const std::size_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
+        Mapper &mp = *mappers[t];
+        if (n_threads > 1) {
+          std::size_t from = lo;
+          bool closed = false;
+          while (from > 0 && !closed) { --from; closed = s1[from].size() > 46; }
+          if (!closed) for (const std::string &r : tail) mp.touch_se(r, mode);
+          for (std::size_t i = from; i < lo; ++i) mp.touch_se(s1[i], mode);
+        }
+        for (std::size_t i = lo; i < hi; ++i) mp.map_se(s1[i], mode, bests[i], cigs[i]);
+      };
+      if (n_threads == 1) share(0);
+      else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_threads; ++t) th.emplace_back(share, t);
+        for (auto &x : th) x.join();
+      }
       buf.clear();
-      for (std::size_t i = 0; i < s1.size(); ++i) {
-        Hit best;
-        cig.clear();
-        mapper.map_se(s1[i], mode, best, cig);
+      for (std::size_t i = 0; i < n; ++i) {
+        Hit &best = bests[i];
         if (!s1[i].empty() &&
-            emit_se(buf, allow_ambig, best, ix.chroms, n1[i], s1[i], cig) == UNMAPPED)
+            emit_se(buf, allow_ambig, best, ix.chroms, n1[i], s1[i], cigs[i]) == UNMAPPED)
           best.clear();
-        se_stats.tally(s1[i].empty(), best, allow_ambig, cig);
+        se_stats.tally(s1[i].empty(), best, allow_ambig, cigs[i]);
       }
       out << buf;
+      if (n_threads > 1) {  // what the next batch's first share has to replay
+        std::vector<std::string> next;
+        bool closed = false;
+        for (std::size_t i = n; i-- > 0 && !closed;) { next.push_back(s1[i]); closed = s1[i].size() > 46; }
+        if (!closed) for (std::size_t i = tail.size(); i-- > 0;) next.push_back(tail[i]);
+        std::reverse(next.begin(), next.end());
+        tail.swap(next);
+      }
+    }
+    for (auto &mp : mappers) {
+      const Work &w = mp->work;
+      mapper.work.reads += w.reads; mapper.work.seed_iters += w.seed_iters; mapper.work.search_probes += w.search_probes;
+      mapper.work.candidates += w.candidates; mapper.work.words += w.words; mapper.work.set_updates += w.set_updates;
+      mapper.work.aligns += w.aligns; mapper.work.aligns_tb += w.aligns_tb; mapper.work.dp_cells += w.dp_cells;
     }
   }
   else {

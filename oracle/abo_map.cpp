@@ -611,6 +611,38 @@ void Mapper::map_se(const std::string &read, SeMode mode, Hit &best, Cigar &cig)
   m->choose_se(0, static_cast<u32>(read.size()), m->par.valid_frac, S, best, cig);
 }
 
+void Mapper::touch_se(const std::string &read, SeMode mode) {
+  if (read.empty())
+    return;
+  const std::string rc = revcomp_read(read);
+  for (int r = 0; r < 2; ++r)
+    for (int alpha = 0; alpha < 2; ++alpha) {
+      const bool ar = (r != 0) != (alpha != 0);  // alphabet = rc xor a_rich
+      const bool used = mode == SE_RANDOM || (mode == SE_A_RICH) == ar;
+      if (used) m->enc[0][r][alpha].encode(r ? rc : read, alpha != 0);
+    }
+}
+
+void Mapper::touch_pe(const std::string &r1, const std::string &r2, PeMode mode) {
+  if (r1.empty() && r2.empty())
+    return;
+  const std::string *rd[2] = {&r1, &r2};
+  for (int end = 0; end < 2; ++end) {
+    if (rd[end]->empty())
+      continue;
+    const std::string rc = revcomp_read(*rd[end]);
+    for (int r = 0; r < 2; ++r)
+      for (int alpha = 0; alpha < 2; ++alpha) {
+        // orientation(endA, ar): endA forward and endB reverse-complemented, both in alphabet ar;
+        // normal = {(0, T), (1, A)}, PBAT = {(0, A), (1, T)}, random = all four
+        const bool as_a = r == 0;  // this end is endA in the call that uses [end][r][alpha]
+        const int end_a = as_a ? end : 1 - end;
+        const bool used = mode == PE_RANDOM || ((mode == PE_PBAT) != (end_a == 1)) == (alpha != 0);
+        if (used) m->enc[end][r][alpha].encode(r ? rc : *rd[end], alpha != 0);
+      }
+  }
+}
+
 void Mapper::map_pe(const std::string &r1, const std::string &r2, PeMode mode, PairHit &best,
                     Hit &se1, Hit &se2, Cigar &cig1, Cigar &cig2) {
   const u32 l1 = static_cast<u32>(r1.size()), l2 = static_cast<u32>(r2.size());

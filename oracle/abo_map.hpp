@@ -75,6 +75,12 @@ public:
   // body of src/abismal.cpp:1950-1999 / :2094-2155, up to select_output.
   void map_pe(const std::string &r1, const std::string &r2, PeMode mode, PairHit &best,
               Hit &se1, Hit &se2, Cigar &cig1, Cigar &cig2);
+  // Only the side effect mapping a read has on LATER reads: its encodings overwrite the reused
+  // buffers (src/abismal.cpp:1377-1386), which reads of 44-46 bases hash past their end
+  // (SURVEY A.11).  A worker that starts in the middle of the input replays this for the reads
+  // before its share, so that sharded runs equal the reference at -t 1.
+  void touch_se(const std::string &read, SeMode mode);
+  void touch_pe(const std::string &r1, const std::string &r2, PeMode mode);
   Work work;
 
 private:

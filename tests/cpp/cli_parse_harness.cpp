@@ -15,13 +15,13 @@ int main(int argc, char **argv) {
       uint64_t first = 0;
       const uint64_t lines = s.next(want, raw, first);
       if (lines == 0) break;
-      std::vector<std::string> names;
+      std::vector<NameRef> names;
       std::string blob;
       std::vector<uint64_t> off;
       parse_raw(raw, first, argv[1], names, blob, off);
       std::printf("#batch first_line=%llu records=%zu\n", static_cast<unsigned long long>(first), names.size());
       for (size_t i = 0; i < names.size(); ++i)
-        std::printf("%s\t%.*s\n", names[i].c_str(), static_cast<int>(off[i + 1] - off[i]), blob.data() + off[i]);
+        std::printf("%.*s\t%.*s\n", static_cast<int>(names[i].n), names[i].p, static_cast<int>(off[i + 1] - off[i]), blob.data() + off[i]);
       if (s.exhausted()) break;
     }
   }

@@ -54,8 +54,6 @@ def mutated_reads(fasta, n, L, seed, mut=0.02, bis=0.95, pbat_frac=0.0, n_frac=0
     for _ in range(n):
         ch = chroms[int(rng.integers(0, len(chroms)))]
         ln = L if rng.random() > 0.05 else int(rng.integers(30, L))
-        if 44 <= ln <= 46:
-            ln = 47  # 44-46 bp reads depend on the previous read's leftovers in the reference
         at = int(rng.integers(0, len(ch) - ln - 20))
         frag = ch[at:at + ln + 20].copy()
         if rng.random() < 0.5:

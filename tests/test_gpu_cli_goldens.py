@@ -69,8 +69,13 @@ def test_gzip_input_gives_the_same_sam(chain):
     (["-P", "-s", "tests/reads_rpbat_pe.mstats", "-o", "tests/reads_rpbat_pe.sam", "-i", "tests/tRex1.idx",
       "tests/reads_rpbat_pe_1.fq", "tests/reads_rpbat_pe_2.fq"], ["tests/reads_rpbat_pe.sam", "tests/reads_rpbat_pe.mstats"]),
 ])
-def test_map_goldens(chain, args, outs):
-    r = subprocess.run([CLI, "map"] + args, cwd=chain, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+@pytest.mark.parametrize("units", [None, ("997", "4096", "7"), ("64", "1000", "1")])
+def test_map_goldens(chain, args, outs, units):
+    env = dict(os.environ)
+    if units:  # shrink slices / chunks / line marks so that the 10 k-read fixtures cross many of each
+        env.update(ABM_CLI_SLICE_READS=units[0], ABM_CLI_CHUNK_BYTES=units[1], ABM_CLI_MARK_LINES=units[2],
+                   ABM_CLI_BATCH_READS="3000")  # (not -batch: the SAM's @PG line carries the command line)
+    r = subprocess.run([CLI, "map"] + args, cwd=chain, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     g = golden()
     for o in outs:

@@ -52,7 +52,7 @@ def test_unseedable_and_ragged_inputs(ctx, oracle, trex_index, reads):
     rng = np.random.default_rng(0)
     weird = ["N" * 60, "A" * 44, "ACGT" * 11, "T" * 300, "", "NNNNACGTNNNN" * 8, "GATTACA" * 40]
     ragged = [r[: int(rng.integers(44, len(r) + 1))] if r and len(r) >= 47 else r for r in reads[:3000]]
-    ragged = [r if not (44 <= len(r) <= 46) else r[:43] for r in ragged]   # 44-46 bp: see DESIGN.md
+    # (reads of 44-46 bases included: what they see past their end comes from the reads before them, in order)
     batch = weird + ragged
     res, cig, off = ctx.map_se(batch)
     oix = oracle.index_load(trex_index)
@@ -67,6 +67,8 @@ def test_unseedable_and_ragged_inputs(ctx, oracle, trex_index, reads):
 def test_batch_order_and_size_do_not_matter(ctx, reads):
     """Results are per read: permuting the batch, splitting it, or running it twice changes nothing
     (the only cross-read state in the reference is buffer sizing, src/abismal.cpp:1549)."""
+    # reads of 44-46 bases are the exception: they see what EARLIER reads left in the reference's reused
+    # buffers (SURVEY A.11), so their results depend on the order by design (test_ghost_reads)
     base = [r for r in reads if not (44 <= len(r) <= 46)]
     res, cig, off = ctx.map_se(base)
     res2, cig2, off2 = ctx.map_se(base)
@@ -166,3 +168,48 @@ def test_small_cigar_capacity_is_reported_not_overrun(ctx, reads):
     assert rc == 0, lib.abm_last_error()
     mapped = int((res["pos"] != 0).sum())
     assert mapped > 0.8 * n and int(co[-1]) >= mapped
+
+
+@pytest.mark.parametrize("mode,maxc", [(0, 0), (0, 5), (1, 5), (2, 5), (2, 100)])
+def test_ghost_reads(oracle, tmp_path_factory, mode, maxc):
+    """Reads of 44-46 bases hash and extend seeds PAST their end, into what the reads before them left
+    in the reference's reused buffers (src/abismal.cpp:1163-1194, :1302-1308, :1377-1386): the result
+    depends on the preceding reads, in input order, exactly as at -t 1.  Half the batch is such reads,
+    between reads of many other lengths; a small -c forces the over-long extension to happen often."""
+    import abismal_amd as A
+    from tests import synth
+    from tests.test_gpu_se_parity import compare_se
+    wd = tmp_path_factory.mktemp("ghost")
+    fa, idx = str(wd / "rep.fa"), str(wd / "rep.idx")
+    synth.repeat_rich_genome(fa, seed=12, n_chroms=2, chrom_len=800_000)
+    A.index_build(fa, idx, 8)
+    rng = np.random.default_rng(40 + mode + maxc)
+    long_reads = synth.trim_like_readloader(synth.mutated_reads(fa, 4000, 120, seed=3, mut=0.02, pbat_frac=0.5 if mode else 0.0))
+    reads = []
+    for r in long_reads:
+        u = rng.random()
+        if u < 0.5 and len(r) >= 47:
+            r = r[: int(rng.integers(44, 47))]
+        elif u < 0.7 and len(r) >= 60:
+            r = r[: int(rng.integers(47, len(r) + 1))]
+        elif u < 0.75:
+            r = ""
+        reads.append(r)
+    assert sum(1 for r in reads if 44 <= len(r) <= 46) > 1000
+    ix = A.Index(idx)
+    ctx = A.Context(ix, 0)
+    oix = oracle.index_load(idx)
+    try:
+        o_res, o_cig, o_n, work = oracle.map_se(oix, reads, mode=mode, max_candidates=maxc, threads=1)
+        res, cig, off = ctx.map_se(reads, mode=mode, params=A.Params(max_candidates=maxc))
+        compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"ghost reads mode {mode} -c {maxc}")
+        # paired-end: the same for both ends' buffers
+        from tests.test_gpu_pe_parity import compare_pe
+        r1, r2 = reads[:1500], reads[1500:3000]
+        orc = oracle.map_pe(oix, r1, r2, mode=mode, max_candidates=maxc, threads=1)
+        gpu = ctx.map_pe(r1, r2, mode=mode, params=A.Params(max_candidates=maxc))
+        compare_pe(gpu, orc, f"ghost pairs mode {mode} -c {maxc}")
+    finally:
+        oracle.index_free(oix)
+        ctx.close()
+        ix.close()

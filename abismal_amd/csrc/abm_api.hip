@@ -457,12 +457,17 @@ const uint32_t *abm_index_chrom_starts(const abm_index *ix) { return ix->h.chrom
 uint64_t abm_index_bytes(const abm_index *ix) { return ix->h.device_bytes(); }
 
 int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_threads) {
+  return abm_index_build_targets(fasta_path, nullptr, out_path, n_threads);
+}
+
+int abm_index_build_targets(const char *fasta_path, const char *targets_path, const char *out_path, uint32_t n_threads) {
   return guarded([&] {
     if (!fasta_path || !out_path) throw std::invalid_argument("null argument");
     std::string text;
     std::vector<std::string> names;
     std::vector<uint32_t> starts;
     abm::load_fasta(fasta_path, text, names, starts);
+    if (targets_path && targets_path[0]) abm::mask_outside_targets(targets_path, text, names, starts);
     abm::HostIndex h;
     abm::build_index(text, names, starts, n_threads ? n_threads : 1u, h);
     abm::write_index(h, out_path);

@@ -11,6 +11,8 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <malloc.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -64,13 +66,41 @@ struct RawBuf {
   RawBuf(RawBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
   RawBuf &operator=(RawBuf &&o) noexcept { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); return *this; }
   ~RawBuf() { std::free(p); }
+  // Big blocks are 2 MB-aligned and advised to use huge pages: a run touches gigabytes of fresh memory
+  // from a hundred threads at once, and with 4 KB pages that is a million page faults on one address space.
   void reserve(size_t want) {
     if (want <= cap) return;
-    char *q = static_cast<char *>(std::realloc(p, want));
-    if (!q) throw std::bad_alloc();
+    want = std::max(want, cap + cap / 2);
+    char *q;
+    if (want >= (4u << 20)) {
+      want = (want + (2u << 20) - 1) & ~static_cast<size_t>((2u << 20) - 1);
+      q = static_cast<char *>(std::aligned_alloc(2u << 20, want));
+      if (!q) throw std::bad_alloc();
+      ::madvise(q, want, MADV_HUGEPAGE);
+      if (n) std::memcpy(q, p, n);
+      std::free(p);
+    }
+    else {
+      q = static_cast<char *>(std::realloc(p, want));
+      if (!q) throw std::bad_alloc();
+    }
     p = q; cap = want;
   }
   void append(const char *src, size_t len) { reserve(n + len); std::memcpy(p + n, src, len); n += len; }
+  // the part of std::string's interface the formatting code uses (contents are never zero-filled)
+  void append(size_t count, char c) { reserve(n + count); std::memset(p + n, c, count); n += count; }
+  void append(const std::string &t) { append(t.data(), t.size()); }
+  RawBuf &operator+=(char c) { if (n == cap) reserve(n + 1); p[n++] = c; return *this; }
+  RawBuf &operator+=(const std::string &t) { append(t.data(), t.size()); return *this; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  void resize(size_t m) { reserve(m); n = m; }
+  void clear() { n = 0; }
+  char &operator[](size_t i) { return p[i]; }
+  const char &operator[](size_t i) const { return p[i]; }
+  char *data() { return p; }
+  const char *data() const { return p; }
+  void swap(RawBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
 };
 struct RawPool {
   std::mutex mu;
@@ -85,7 +115,7 @@ struct RawPool {
   }
   void put(RawBuf &&b) {
     std::lock_guard<std::mutex> lk(mu);
-    if (free_list.size() < 24) free_list.push_back(std::move(b));
+    if (free_list.size() < 1024) free_list.push_back(std::move(b));
   }
 };
 
@@ -103,13 +133,39 @@ struct Slice {
   uint64_t byte_lo[2] = {0, 0}, byte_hi[2] = {0, 0};  // plain files: the slice's text in each file
   RawBuf raw[2];                     // the FASTQ text (names point into it)
   std::vector<NameRef> names[2];
-  std::string blob[2];               // reads as ReadLoader hands them over, concatenated
+  RawBuf blob[2];                    // reads as ReadLoader hands them over, concatenated
   std::vector<uint64_t> off[2];
   size_t n() const { return names[0].size(); }
   Batch *batch = nullptr;            // once mapped: the batch whose arrays hold this slice's results ...
   size_t base = 0;                   // ... from this index on
-  std::string text;                  // formatted output
+  RawBuf text;                       // formatted output
   Stats3 stats;
+};
+
+// written slices are recycled with their buffers (names, reads, output text keep their capacity): a
+// process with a hundred threads that keeps allocating and freeing multi-megabyte blocks spends its
+// time on the address-space lock
+struct SlicePool {
+  std::mutex mu;
+  std::vector<std::unique_ptr<Slice>> free_list;
+  std::unique_ptr<Slice> get() {
+    std::unique_ptr<Slice> s;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!free_list.empty()) { s = std::move(free_list.back()); free_list.pop_back(); }
+    }
+    if (!s) s.reset(new Slice);
+    return s;
+  }
+  void put(std::unique_ptr<Slice> s) {
+    for (int e = 0; e < 2; ++e) { s->names[e].clear(); s->blob[e].clear(); s->off[e].clear(); s->raw[e].n = 0; }
+    s->text.clear();
+    s->stats = Stats3();
+    s->batch = nullptr;
+    s->base = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_list.size() < 1024) free_list.push_back(std::move(s));
+  }
 };
 
 struct Batch {
@@ -118,8 +174,9 @@ struct Batch {
   std::vector<std::unique_ptr<Slice>> slices;
   size_t n = 0;
   std::vector<std::string> carry[2]; // reads of the input just before this batch, mapped along for their side effects only
-  std::string blob[2];               // carry + the slices' reads concatenated, as the C ABI takes them
-  std::vector<uint64_t> off[2];
+  RawBuf blob[2];                    // carry + the slices' reads concatenated, as the C ABI takes them
+  RawBuf off_bytes[2];               // ... and their n + 1 offsets (uint64_t)
+  uint64_t *off_of(int e) { return reinterpret_cast<uint64_t *>(off_bytes[e].p); }
   std::vector<abm_hit> se[2];
   std::vector<abm_pair> pairs;
   std::vector<uint32_t> cig[2];
@@ -212,7 +269,7 @@ struct RawSplitter {
 };
 
 void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, std::vector<NameRef> &names,
-               std::string &blob, std::vector<uint64_t> &off) {
+               RawBuf &blob, std::vector<uint64_t> &off) {
   names.clear(); blob.clear(); off.assign(1, 0);
   blob.reserve(raw.n / 2);
   names.reserve(raw.n / 200 + 16);
@@ -242,7 +299,7 @@ void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, 
         const char *b = p;
         while (b < e && *b != 'A' && *b != 'C' && *b != 'G' && *b != 'T') ++b;  // ... and everything before the first base
         if (b == e) throw std::runtime_error("read without A/C/G/T at line " + std::to_string(first_line + k));
-        blob.append(b, e);
+        blob.append(b, static_cast<size_t>(e - b));
       }
       off.push_back(blob.size());
     }
@@ -290,13 +347,13 @@ struct SeqTables {
 };
 const SeqTables kSeq;
 
-inline void put_uint(std::string &o, uint64_t v) {
+template <class S> inline void put_uint(S &o, uint64_t v) {
   char buf[24];
   int k = 24;
   do { buf[--k] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
   o.append(buf + k, static_cast<size_t>(24 - k));
 }
-inline void put_int(std::string &o, int64_t v) {
+template <class S> inline void put_int(S &o, int64_t v) {
   if (v < 0) { o += '-'; put_uint(o, static_cast<uint64_t>(-v)); }
   else put_uint(o, static_cast<uint64_t>(v));
 }
@@ -316,9 +373,9 @@ struct Record {
   char cv;
 };
 
-void put_bam_record(std::string &o, const Record &r);
+template <class S> void put_bam_record(S &o, const Record &r);
 thread_local bool t_bam = false;  // formatter threads switch put_record to BAM encoding
-void put_record(std::string &o, const Chroms &ch, const Record &r) {
+template <class S> void put_record(S &o, const Chroms &ch, const Record &r) {
   if (t_bam) { put_bam_record(o, r); return; }
   o.append(r.name->p, r.name->n); o += '\t'; put_uint(o, r.flag); o += '\t';
   o += ch.names[r.tid + 1]; o += '\t'; put_uint(o, static_cast<uint64_t>(r.pos) + 1); o.append("\t255\t", 5);
@@ -341,8 +398,8 @@ void put_record(std::string &o, const Chroms &ch, const Record &r) {
 // ---- BAM (-B): the same records as binary BAM in BGZF blocks (SAM spec 4.2 / 4.1) ------------------
 // htslib's bam_set1 + bam_aux_update_int("NM") + bam_aux_append("CV",'A') in the reference
 // (src/abismal.cpp:513-543); quality is absent (0xFF), MAPQ 255.
-inline void put_le32(std::string &o, uint32_t v) { char b[4] = {static_cast<char>(v), static_cast<char>(v >> 8), static_cast<char>(v >> 16), static_cast<char>(v >> 24)}; o.append(b, 4); }
-inline void put_le16(std::string &o, uint16_t v) { char b[2] = {static_cast<char>(v), static_cast<char>(v >> 8)}; o.append(b, 2); }
+template <class S> inline void put_le32(S &o, uint32_t v) { char b[4] = {static_cast<char>(v), static_cast<char>(v >> 8), static_cast<char>(v >> 16), static_cast<char>(v >> 24)}; o.append(b, 4); }
+template <class S> inline void put_le16(S &o, uint16_t v) { char b[2] = {static_cast<char>(v), static_cast<char>(v >> 8)}; o.append(b, 2); }
 inline int reg2bin(int64_t beg, int64_t end) {
   --end;
   if (beg >> 14 == end >> 14) return static_cast<int>(((1 << 15) - 1) / 7 + (beg >> 14));
@@ -352,7 +409,7 @@ inline int reg2bin(int64_t beg, int64_t end) {
   if (beg >> 26 == end >> 26) return static_cast<int>(((1 << 3) - 1) / 7 + (beg >> 26));
   return 0;
 }
-void put_bam_record(std::string &o, const Record &r) {
+template <class S> void put_bam_record(S &o, const Record &r) {
   static const char nt16[] = "=ACMGRSVTWYHKDBN";
   const size_t start = o.size();
   put_le32(o, 0);  // block_size, patched below
@@ -389,7 +446,7 @@ void put_bam_record(std::string &o, const Record &r) {
 }
 // raw bytes -> BGZF blocks (each an independent gzip member with the BC extra field)
 int g_bgzf_level = 1;  // deflate level of BAM output (-z): decoded content is the same at every level
-void bgzf_compress(const std::string &raw, std::string &out) {
+template <class A, class B> void bgzf_compress(const A &raw, B &out) {
   constexpr size_t kBlock = 0xff00;
   std::vector<unsigned char> buf(compressBound(kBlock) + 64);
   for (size_t at = 0; at < raw.size(); at += kBlock) {
@@ -428,7 +485,7 @@ std::string bam_header_bytes(const std::string &text, const Chroms &ch) {
 
 enum Outcome { UNMAPPED, UNIQUE, AMBIG };
 
-Outcome emit_se(std::string &o, bool allow_ambig, const abm_hit &h, const Chroms &ch, const NameRef &name,
+template <class S> Outcome emit_se(S &o, bool allow_ambig, const abm_hit &h, const Chroms &ch, const NameRef &name,
                 const char *seq, size_t n_seq, const uint32_t *cig, size_t n_cig) {
   const bool ambig = h.flags & 0x100;
   if (!allow_ambig && ambig) return AMBIG;
@@ -442,7 +499,7 @@ Outcome emit_se(std::string &o, bool allow_ambig, const abm_hit &h, const Chroms
   return ambig ? AMBIG : UNIQUE;
 }
 
-Outcome emit_pe(std::string &o, bool allow_ambig, const abm_pair &p, const Chroms &ch, const NameRef &n1,
+template <class S> Outcome emit_pe(S &o, bool allow_ambig, const abm_pair &p, const Chroms &ch, const NameRef &n1,
                 const NameRef &n2, const char *s1, size_t l1, const char *s2, size_t l2, const uint32_t *c1,
                 size_t nc1, const uint32_t *c2, size_t nc2) {
   if (p.r1.pos == 0) return UNMAPPED;
@@ -543,14 +600,16 @@ Options parse_map(int argc, char **argv) {
 int cmd_idx(int argc, char **argv) {
   unsigned threads = std::max(1u, std::thread::hardware_concurrency());
   std::vector<std::string> pos;
+  std::string targets;  // -A: index only these regions (src/abismalidx.cpp:51-52, :91-92)
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if ((a == "-t" || a == "-threads" || a == "--threads") && i + 1 < argc) threads = static_cast<unsigned>(std::stoul(argv[++i]));
+    else if ((a == "-A" || a == "-targets" || a == "--targets") && i + 1 < argc) targets = argv[++i];
     else if (a == "-v" || a == "-verbose") {}
     else pos.push_back(a);
   }
-  if (pos.size() != 2) { std::cerr << "usage: abismal-amd idx [-t n] <genome.fa> <out.idx>\n"; return EXIT_SUCCESS; }
-  if (abm_index_build(pos[0].c_str(), pos[1].c_str(), threads) != 0) die_abm("idx");
+  if (pos.size() != 2) { std::cerr << "usage: abismal-amd idx [-t n] [-A targets] <genome.fa> <out.idx>\n"; return EXIT_SUCCESS; }
+  if (abm_index_build_targets(pos[0].c_str(), targets.c_str(), pos[1].c_str(), threads) != 0) die_abm("idx");
   return EXIT_SUCCESS;
 }
 
@@ -592,7 +651,12 @@ int cmd_map(int argc, char **argv) {
   n_gpus = static_cast<int>(ctxs.size()) / per_gpu;
   const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();  // file -> host -> HBM
 
-  // ---- output file: written with pwrite at offsets fixed in slice order, so that many threads write ----
+  // ---- output file.  A slice's place is fixed in slice order; then whichever thread is free pwrite()s it.
+  // (Writes to one file take its inode lock, so they run one at a time at ~4 GB/s on tmpfs; copying into a
+  // shared mapping of the file from all threads instead was measured 3x SLOWER -- page faults on the
+  // mapping contend far worse than the lock.)
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);  // (the largest value the library takes: blocks below it come from its arenas ...)
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);   // (... and stay there)
   const int out_fd = ::open(opt.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
   if (out_fd < 0) throw std::runtime_error("failed to open output file: " + opt.out);
   struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) ::close(fd); } } out_closer{out_fd};
@@ -659,9 +723,12 @@ int cmd_map(int argc, char **argv) {
     }
     return true;
   }();
-  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
+  // Batches are FULL (-batch reads) except at the end of the input: the mapping kernel's time has a floor set
+  // by its costliest reads (a quarter of a second, whatever the batch), so small batches waste the GPU;
+  // cutting and parsing run far ahead of it, so a full batch is ready within a fraction of a kernel's time.
+  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 24)));
   const unsigned n_host = std::max(1u, opt.threads);
-  const size_t max_reads_in_flight = 3 * batch_reads + 4 * slice_reads * n_host;
+  const size_t max_reads_in_flight = (static_cast<size_t>(n_gpus) * per_gpu + 2) * batch_reads + 4 * slice_reads * n_host;
   std::deque<std::unique_ptr<Slice>> q_parse;               // cut, waiting for a parser
   std::map<uint64_t, std::unique_ptr<Slice>> parsed;        // parsed, waiting for a mapper (by slice number)
   std::deque<Slice *> q_format;                             // mapped, waiting for a formatter
@@ -671,6 +738,9 @@ int cmd_map(int argc, char **argv) {
   std::vector<std::unique_ptr<Batch>> live_batches;
   std::vector<std::string> carry[2];                        // tail of the input already handed to a batch (see the mapper)
   uint64_t n_slices = 0, next_to_map = 0, next_to_place = 0, slices_written = 0, n_batches = 0;
+  uint64_t run_end = 0, n_parsed = 0;  // parsed[next_to_map .. run_end) are all there; slices parsed so far
+  size_t run_reads = 0;                // reads in that run
+  SlicePool slice_pool;
   size_t reads_in_flight = 0;
   bool cut_done = false;
   int parsers_live = 0, mappers_live = 0;
@@ -715,7 +785,7 @@ int cmd_map(int argc, char **argv) {
       std::unique_ptr<RawSplitter> s2;
       if (paired) s2.reset(new RawSplitter(opt.reads[1]));
       for (;;) {
-        std::unique_ptr<Slice> sl(new Slice);
+        std::unique_ptr<Slice> sl = slice_pool.get();
         const auto t0 = now();
         sl->raw[0] = raw_pool.get();
         if (paired) sl->raw[1] = raw_pool.get();
@@ -859,7 +929,7 @@ int cmd_map(int argc, char **argv) {
       bool done[2] = {false, false};
       const size_t nf = lf.size();
       for (;;) {
-        std::unique_ptr<Slice> sl(new Slice);
+        std::unique_ptr<Slice> sl = slice_pool.get();
         const uint64_t target = line + 4 * slice_reads;  // newlines before the next slice
         uint64_t recs = 0;
         bool any = false;
@@ -900,7 +970,7 @@ int cmd_map(int argc, char **argv) {
         const auto t0 = now();
         for (int e = 0; e < (paired ? 2 : 1); ++e) {
           if (plain_input) {
-            sl->raw[e] = raw_pool.get();
+            if (!sl->raw[e].p) sl->raw[e] = raw_pool.get();
             const uint64_t len = sl->byte_hi[e] - sl->byte_lo[e];
             sl->raw[e].reserve(len + 1);
             read_range(lf[e].fd, opt.reads[e], sl->raw[e].p, sl->byte_lo[e], sl->byte_hi[e]);
@@ -918,6 +988,8 @@ int cmd_map(int argc, char **argv) {
           const uint64_t g = sl->g;
           trace("parsed", g, static_cast<uint64_t>(since(t0) * 1e6));
           parsed[g] = std::move(sl);
+          ++n_parsed;
+          for (auto it = parsed.find(run_end); it != parsed.end(); it = parsed.find(run_end)) { run_reads += it->second->n(); ++run_end; }
         }
         cv.notify_all();
       }
@@ -937,14 +1009,16 @@ int cmd_map(int argc, char **argv) {
         Batch *b = owned.get();
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || parsed.count(next_to_map) || (parsers_live == 0 && parsed.empty()); });
-          if (failure || !parsed.count(next_to_map)) break;
-          // every consecutive slice that is ready, up to the batch size
-          while (b->n < batch_reads) {
+          auto all_parsed = [&] { return cut_done && n_parsed == n_slices; };
+          cv.wait(lk, [&] { return failure || run_reads >= batch_reads || (all_parsed() && (run_end > next_to_map || parsed.empty())); });
+          if (failure || run_end == next_to_map) break;
+          // a full batch; at the end of the input whatever is left, if that is at most a batch and a half
+          const size_t want = (all_parsed() && run_reads <= batch_reads + batch_reads / 2) ? run_reads : batch_reads;
+          while (next_to_map < run_end) {
             auto it = parsed.find(next_to_map);
-            if (it == parsed.end()) break;
-            if (!b->slices.empty() && b->n + it->second->n() > batch_reads) break;
+            if (!b->slices.empty() && b->n + it->second->n() > want) break;
             b->n += it->second->n();
+            run_reads -= it->second->n();
             b->slices.push_back(std::move(it->second));
             parsed.erase(it);
             ++next_to_map;
@@ -992,21 +1066,36 @@ int cmd_map(int argc, char **argv) {
           for (const std::string &c : b->carry[e]) bytes += c.size();
           for (auto &sl : b->slices) bytes += sl->blob[e].size();
           b->blob[e].resize(bytes);
-          b->off[e].resize(n + 1);
+          b->off_bytes[e].resize((n + 1) * sizeof(uint64_t));
+          uint64_t *boff = b->off_of(e);
           size_t at = 0, r = 0;
           for (const std::string &c : b->carry[e]) {
             std::memcpy(&b->blob[e][at], c.data(), c.size());
-            b->off[e][r++] = at;
+            boff[r++] = at;
             at += c.size();
           }
-          for (auto &sl : b->slices) {
-            std::memcpy(&b->blob[e][at], sl->blob[e].data(), sl->blob[e].size());
-            const size_t m = sl->n();
-            for (size_t i = 0; i < m; ++i) b->off[e][r + i] = sl->off[e][i] + at;
-            at += sl->blob[e].size();
-            r += m;
+          // where each slice goes, then the copies on a few threads
+          std::vector<size_t> s_at(b->slices.size()), s_r(b->slices.size());
+          for (size_t k = 0; k < b->slices.size(); ++k) {
+            s_at[k] = at; s_r[k] = r;
+            at += b->slices[k]->blob[e].size();
+            r += b->slices[k]->n();
           }
-          b->off[e][n] = at;
+          boff[n] = at;
+          auto copy_range = [&, e](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; ++k) {
+              const Slice &sl = *b->slices[k];
+              std::memcpy(&b->blob[e][s_at[k]], sl.blob[e].data(), sl.blob[e].size());
+              const size_t m = sl.n();
+              uint64_t *dst = boff + s_r[k];
+              for (size_t i = 0; i < m; ++i) dst[i] = sl.off[e][i] + s_at[k];
+            }
+          };
+          const size_t n_copy = std::min<size_t>(std::max<size_t>(1, n_host / 4), std::max<size_t>(1, b->slices.size() / 4));
+          std::vector<std::thread> copiers;
+          for (size_t t = 1; t < n_copy; ++t) copiers.emplace_back(copy_range, b->slices.size() * t / n_copy, b->slices.size() * (t + 1) / n_copy);
+          copy_range(0, b->slices.size() / n_copy);
+          for (auto &t : copiers) t.join();
         }
         {
           size_t base = lead;
@@ -1017,7 +1106,7 @@ int cmd_map(int argc, char **argv) {
         size_t blob_n[2];
         for (int e = 0; e < 2; ++e) {
           blob_p[e] = one ? b->slices[0]->blob[e].data() : b->blob[e].data();
-          off_p[e] = one ? b->slices[0]->off[e].data() : b->off[e].data();
+          off_p[e] = one ? b->slices[0]->off[e].data() : b->off_of(e);
           blob_n[e] = one ? b->slices[0]->blob[e].size() : b->blob[e].size();
         }
         trace("batch ready", b->seq, n);
@@ -1064,7 +1153,7 @@ int cmd_map(int argc, char **argv) {
   auto format_slice = [&](Slice &sl) {
     const Batch *b = sl.batch;
     t_bam = opt.bam;
-    std::string &sam = sl.text;
+    RawBuf &sam = sl.text;
     Stats3 &st = sl.stats;
     const size_t m = sl.n(), base = sl.base;
     sam.reserve(m * (paired ? 2 : 1) * 320);
@@ -1127,7 +1216,7 @@ int cmd_map(int argc, char **argv) {
         if (to_format) {
           const auto t0 = now();
           format_slice(*to_format);
-          if (opt.bam) { std::string z; bgzf_compress(to_format->text, z); to_format->text.swap(z); }
+          if (opt.bam) { RawBuf z; bgzf_compress(to_format->text, z); to_format->text.swap(z); }
           std::lock_guard<std::mutex> lk(mu);
           busy_format += since(t0);
           trace("formatted", to_format->g, static_cast<uint64_t>(since(t0) * 1e6));
@@ -1164,12 +1253,14 @@ int cmd_map(int argc, char **argv) {
             for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += to_write->stats.s[k].v[j];
           reads_in_flight -= std::min<size_t>(reads_in_flight, slice_reads);
           ++slices_written;
-          // give the slice's memory back at once; the batch goes when its last slice has
-          for (int e = 0; e < 2; ++e) if (to_write->raw[e].p) raw_pool.put(std::move(to_write->raw[e]));
-          std::string().swap(to_write->text);
+          // the batch goes when its last slice is written; its slices are recycled with their buffers
           if (--b->slices_left == 0) {
             for (auto it = live_batches.begin(); it != live_batches.end(); ++it)
-              if (it->get() == b) { live_batches.erase(it); break; }
+              if (it->get() == b) {
+                for (auto &sl : (*it)->slices) slice_pool.put(std::move(sl));
+                live_batches.erase(it);
+                break;
+              }
           }
           cv.notify_all();
         }

@@ -104,6 +104,57 @@ void load_fasta(const std::string &path, std::string &text, std::vector<std::str
   starts.push_back(static_cast<uint32_t>(text.size()));
 }
 
+// `abismal idx -A targets` (src/AbismalIndex.cpp:83-123, :188-205, :206-241): only the listed regions are
+// indexed -- everything outside them is turned into N before the usual N handling, so it lands in the
+// long excluded runs.  The file has one "chrom start end" per line (0-based, end exclusive); regions
+// must be sorted within a chromosome and are taken in the genome's chromosome order; names the genome
+// does not have are dropped.
+void mask_outside_targets(const std::string &targets_path, std::string &text, const std::vector<std::string> &names,
+                          const std::vector<uint32_t> &starts) {
+  std::ifstream in(targets_path);
+  if (!in)
+    throw std::runtime_error("failed reading target file");
+  struct Region { std::string chrom; uint64_t a, b; };
+  std::vector<Region> listed;
+  for (std::string line; std::getline(in, line);) {
+    std::istringstream f(line);
+    Region r;
+    if (!(f >> r.chrom) || !(f >> r.a) || !(f >> r.b))
+      throw std::runtime_error("failed parsing target region");
+    listed.push_back(r);
+  }
+  // per chromosome of the genome, in its order: the FIRST run of consecutive lines naming it
+  std::vector<std::pair<uint32_t, uint32_t>> spans;
+  for (size_t c = 0; c < names.size(); ++c) {
+    size_t u = 0;
+    while (u < listed.size() && listed[u].chrom != names[c]) ++u;
+    size_t v = u;
+    while (v < listed.size() && listed[v].chrom == names[c]) ++v;
+    for (size_t k = u; k + 1 < v; ++k)
+      if (listed[k + 1].a < listed[k].a || (listed[k + 1].a == listed[k].a && listed[k + 1].b < listed[k].b))
+        throw std::runtime_error("target regions not sorted");
+    for (size_t k = u; k < v; ++k)  // ChromLookup::get_pos: 32-bit arithmetic (:1296-1303)
+      spans.emplace_back(starts[c] + static_cast<uint32_t>(listed[k].a), starts[c] + static_cast<uint32_t>(listed[k].b));
+  }
+  // mask_non_target (:108-123): a position is blanked while it lies before the current region's start; once
+  // inside or past it, it is kept and the regions ending at or before it are retired -- so the base just
+  // past a region's end survives too
+  const uint64_t G = text.size();
+  uint64_t i = 0;
+  size_t t = 0;
+  while (i < G) {
+    if (t == spans.size()) { std::fill(text.begin() + static_cast<std::ptrdiff_t>(i), text.end(), 'N'); break; }
+    if (i < spans[t].first) {
+      const uint64_t to = std::min<uint64_t>(spans[t].first, G);
+      std::fill(text.begin() + static_cast<std::ptrdiff_t>(i), text.begin() + static_cast<std::ptrdiff_t>(to), 'N');
+      i = to;
+      continue;
+    }
+    while (t < spans.size() && spans[t].second <= i) ++t;
+    ++i;
+  }
+}
+
 void build_index(std::string &text, const std::vector<std::string> &names,
                  const std::vector<uint32_t> &starts, unsigned nt, HostIndex &out) {
   nt = std::max(1u, nt);

@@ -288,6 +288,9 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     for _ in range(max(0, args.warmup - len(slots))):
         step()
     torch.cuda.synchronize()
+    for z in slots:
+        z.ctx.take_work_tiers()
+        z.ctx.set_timing(True)
     barrier()
     issued[0] = 0
     t0 = time.perf_counter()
@@ -296,6 +299,17 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # exact work tallies and per-launch durations (HIP events on the launch streams) of the timed steps
+    tier_work = [dict(), dict()]
+    tier_ms = [[], []]
+    for z in slots:
+        times = z.ctx.take_kernel_times()
+        z.ctx.set_timing(False)
+        tier_ms[0] += times[0::2]
+        tier_ms[1] += times[1::2]
+        for t, w in enumerate(z.ctx.take_work_tiers()):
+            for k, v in w.items():
+                tier_work[t][k] = tier_work[t].get(k, 0) + v
     diag = None
     if args.phase_stamps and rank == 0:
         # one more step through the diagnostic kernels: per-tier durations and phase shares
@@ -344,14 +358,58 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         oix = o.index_load(os.path.join(args.workdir, f"g{int(args.genome_mbp)}.idx"))
         cores = os.cpu_count() or 1
         t0 = time.perf_counter()
-        op, os1, os2, _, _, _ = o.map_pe(oix, h1, h2, mode=0, threads=cores)
+        orc = o.map_pe(oix, h1, h2, mode=0, threads=cores)
         t_cpu = time.perf_counter() - t0
         o.index_free(oix)
+        op, o_work = orc[0], orc[5]
         gp = pairs[:ns].cpu().numpy().view(np.uint32)
         same = int(((gp[:, 2] == op["r1"]["pos"]) & (gp[:, 4] == op["r2"]["pos"])).sum())
+        # everything the boundary hands over -- pair score, both hits, both fallback hits, CIGARs -- for the
+        # sample, through the host entry point (long CIGARs patched in), against the oracle
+        from tests.test_gpu_pe_parity import compare_pe
+        full = "identical"
+        try:
+            compare_pe(slots[0].ctx.map_pe(h1, h2, mode=A.PE_NORMAL), orc, "bench sample")
+        except AssertionError as e:
+            full = str(e)[:300]
         cpu = {"value": round(2 * ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": f"first {ns} pairs, oracle restatement, {cores} threads, {t_cpu:.1f}s",
-               "pair_positions_identical_to_gpu": f"{same}/{ns}"}
+               "sample": f"first {ns} pairs, oracle restatement (-O3 -DNDEBUG), {cores} threads, {t_cpu:.1f}s",
+               "pair_positions_identical_to_gpu": f"{same}/{ns}",
+               "pairs_hits_fallbacks_cigars_vs_oracle": full}
+        nr = max(1, o_work["reads"] // 2)
+        strict = {k: o_work[k] / nr for k in ("seed_iters", "search_probes", "candidates", "words", "aligns", "aligns_tb")}
+    # roofline (HBM-bound, like the single-end kernel): algorithmic bytes per PAIR by SURVEY 8(d)'s formula from the
+    # kernels' own tallies (tier 1 + tier 2: a pair redone by tier 2 counts twice, as the work was done twice) and,
+    # strictly, from the oracle's counters on the sample.  The tiers of the (context, stream) slots overlap in time,
+    # so the rate is bytes of all timed steps / wall time of the timed region; per-launch durations are listed beside.
+    bw_band = 2 * int(0.1 * L) + 1
+    nw = (L + 15) // 16
+
+    def pair_bytes(S, P, C, W, Aln, Cw=None):
+        return 2 * L + S * 16 + P * 4.5 + C * 4 + (W + (C if Cw is None else Cw)) * 8 + Aln * (L + bw_band) / 2 + 36 + 16
+
+    done_pairs = n * args.steps
+    tw = {k: tier_work[0].get(k, 0) + tier_work[1].get(k, 0) for k in tier_work[0]}
+    fetched = tw["candidates"] - tw["window_cache_hits"]
+    k_bytes = pair_bytes(tw["seed_offsets"] / done_pairs, tw["search_probes"] / done_pairs, tw["candidates"] / done_pairs,
+                         fetched * nw / done_pairs, tw["alignments"] / done_pairs, fetched / done_pairs)
+    s_bytes = None
+    if cpu is not None:
+        s_bytes = pair_bytes(strict["seed_iters"], strict["search_probes"], strict["candidates"], strict["words"],
+                             strict["aligns"] + strict["aligns_tb"])
+    use = s_bytes if s_bytes is not None else k_bytes
+    achieved = use * done_pairs / elapsed / 1e9
+    roofline = {"bound": "hbm", "kernel": "map_pe_kernel (tier 1 + tier 2)", "achieved": round(achieved, 2), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "basis": "strict" if s_bytes is not None else "kernel_tally",
+                "alg_bytes_per_pair_strict": round(s_bytes, 1) if s_bytes is not None else None,
+                "alg_bytes_per_pair_kernel_tally": round(k_bytes, 1),
+                "frac_kernel_tally": round(k_bytes * done_pairs / elapsed / 1e9 / 8000.0, 5),
+                "denominator": "wall time of the timed region (kernels of %d slots overlap)" % len(slots),
+                "tier1_ms_per_launch": round(sum(tier_ms[0]) / max(1, len(tier_ms[0])), 2),
+                "tier2_ms_per_launch": round(sum(tier_ms[1]) / max(1, len(tier_ms[1])), 2),
+                "traffic": None,
+                "work_per_pair": {k: round(v / done_pairs, 2) for k, v in tw.items() if not k.startswith("cyc_")},
+                "tier2_share_of_candidates": round(tier_work[1].get("candidates", 0) / max(1, tw["candidates"]), 3)}
     print(json.dumps({
         "metric": "mapped reads/sec (whole node), paired-end", "value": round(2 * n * args.steps * world / elapsed, 1),
         "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen, "per_rank_reads_per_s": rank_rates,
@@ -360,7 +418,7 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step",
                    "streams": len(slots)},
-        "cpu_baseline": cpu, "kernel_status": int(status.item()), "phase_stamps": diag,
+        "roofline": roofline, "cpu_baseline": cpu, "kernel_status": int(status.item()), "phase_stamps": diag,
         "mapping": {"pairs": int(stats[0]), "concordant": int(stats[1]), "ends_mapped_single": int(stats[2])}}), flush=True)
 
 

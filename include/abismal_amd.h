@@ -60,6 +60,9 @@ uint64_t abm_index_bytes(const abm_index *ix);                  /* bytes residen
  * AbismalIndex::create_index + write, src/AbismalIndex.cpp:281-331, :1037-1072).
  * Host-side, multi-threaded; the file is byte-identical to the reference's. */
 int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_threads);
+/* `abismal idx -A <targets> ...` (AbismalIndex::create_index(targets, genome), src/AbismalIndex.cpp:206-279):
+ * only the regions listed in targets_path ("chrom start end" per line) are indexed; NULL or "" = whole genome. */
+int abm_index_build_targets(const char *fasta_path, const char *targets_path, const char *out_path, uint32_t n_threads);
 
 /* A context = one host thread's workspaces and stream on `device` (hipSetDevice
  * ordinal).  The first context on a device replicates the index into its HBM;

@@ -31,6 +31,9 @@ struct abo_pair { int16_t aln_score; int16_t pad; abo_hit r1, r2; };
 
 const char *abo_last_error() { return g_err.c_str(); }
 
+int abo_index_build_targets(const char *fasta, const char *targets, const char *out, unsigned threads) {
+  return guarded([&] { Index ix; ix.build_from_fasta(fasta, threads, targets ? targets : ""); ix.write(out); });
+}
 int abo_index_build(const char *fasta, const char *out, unsigned threads) {
   return guarded([&] { Index ix; ix.build_from_fasta(fasta, threads); ix.write(out); });
 }

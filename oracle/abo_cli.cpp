@@ -251,10 +251,10 @@ Args parse(int argc, char **argv, const std::string &with_value) {
 }
 
 int cmd_idx(int argc, char **argv) {
-  Args a = parse(argc, argv, ",t,threads,");
+  Args a = parse(argc, argv, ",t,threads,A,targets,");
   if (a.pos.size() != 2) { std::cerr << "usage: idx [-t n] <genome.fa> <out.idx>\n"; return 1; }
   Index ix;
-  ix.build_from_fasta(a.pos[0], static_cast<unsigned>(std::stoul(a.get("t", a.get("threads", "1")))));
+  ix.build_from_fasta(a.pos[0], static_cast<unsigned>(std::stoul(a.get("t", a.get("threads", "1")))), a.get("A", a.get("targets")));
   ix.write(a.pos[1]);
   return 0;
 }

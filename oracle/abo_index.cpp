@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <sstream>
 #include <stdexcept>
 #include <thread>
 
@@ -243,9 +244,50 @@ struct Hasher {  // rolling 2-letter / 3-letter keys over the packed genome
 
 }  // namespace
 
-void Index::build_from_fasta(const std::string &fasta, unsigned n_threads) {
+// create_index(targets_file, genome_file), src/AbismalIndex.cpp:206-241: load_target_regions (:83-106),
+// sort_by_chrom (:188-205), ChromLookup::get_pos (:1296-1303), mask_non_target (:108-123)
+static void keep_only_targets(const std::string &path, const ChromTable &ct, std::string &genome) {
+  std::ifstream in(path);
+  if (!in)
+    throw std::runtime_error("failed reading target file");
+  struct Iv { std::string chrom; std::size_t s = 0, e = 0; };
+  std::vector<Iv> u;
+  std::string line;
+  while (std::getline(in, line)) {
+    std::istringstream iss(line);
+    Iv iv;
+    if (!(iss >> iv.chrom) || !(iss >> iv.s) || !(iss >> iv.e))
+      throw std::runtime_error("failed parsing target region");
+    u.push_back(iv);
+  }
+  auto less = [](const Iv &a, const Iv &b) {
+    const int x = a.chrom.compare(b.chrom);
+    return x < 0 || (x == 0 && (a.s < b.s || (a.s == b.s && a.e < b.e)));
+  };
+  std::vector<std::pair<u32, u32>> targets;
+  for (std::size_t i = 0; i < ct.names.size(); ++i) {
+    const auto first = std::find_if(u.begin(), u.end(), [&](const Iv &x) { return x.chrom == ct.names[i]; });
+    const auto last = std::find_if(first, u.end(), [&](const Iv &x) { return x.chrom != ct.names[i]; });
+    if (!std::is_sorted(first, last, less))
+      throw std::runtime_error("target regions not sorted");
+    for (auto it = first; it != last; ++it)
+      targets.emplace_back(ct.starts[i] + static_cast<u32>(it->s), ct.starts[i] + static_cast<u32>(it->e));
+  }
+  auto t = targets.begin();
+  for (std::size_t i = 0; i < genome.size(); ++i) {
+    if (t == targets.end() || i < t->first)
+      genome[i] = 'N';
+    else
+      while (t != targets.end() && t->second <= i)
+        ++t;
+  }
+}
+
+void Index::build_from_fasta(const std::string &fasta, unsigned n_threads, const std::string &targets) {
   std::string text;
   load_fasta_padded(fasta, text, chroms);
+  if (!targets.empty())
+    keep_only_targets(targets, chroms, text);
   const u64 G = text.size();
   const std::vector<Span> runs = long_n_runs(text);
 

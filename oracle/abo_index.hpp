@@ -19,7 +19,8 @@ struct Index {
   void read(const std::string &path);         // src/AbismalIndex.cpp:1082-1146
   void write(const std::string &path) const;  // src/AbismalIndex.cpp:1037-1072
   // src/AbismalIndex.cpp:281-331 (+ everything it calls)
-  void build_from_fasta(const std::string &fasta, unsigned n_threads = 1);
+  // targets: `abismal idx -A` file (src/AbismalIndex.cpp:206-279); empty = whole genome
+  void build_from_fasta(const std::string &fasta, unsigned n_threads = 1, const std::string &targets = "");
 };
 
 }  // namespace abo

@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
       const uint64_t lines = s.next(want, raw, first);
       if (lines == 0) break;
       std::vector<NameRef> names;
-      std::string blob;
+      RawBuf blob;
       std::vector<uint64_t> off;
       parse_raw(raw, first, argv[1], names, blob, off);
       std::printf("#batch first_line=%llu records=%zu\n", static_cast<unsigned long long>(first), names.size());

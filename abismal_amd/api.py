@@ -15,9 +15,9 @@ PAIR_DTYPE = np.dtype([("aln_score", "<i2"), ("reserved", "<i2"), ("r1", HIT_DTY
 EXPORTED_SYMBOLS = [
     "abm_last_error", "abm_default_params", "abm_index_open", "abm_index_close",
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
-    "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_ctx_create", "abm_ctx_destroy",
+    "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
-    "abm_max_read_length", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
+    "abm_max_read_length", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
 ]
 
 
@@ -70,10 +70,14 @@ def load_library():
     lib.abm_index_bytes.restype = C.c_uint64
     lib.abm_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
     lib.abm_index_build_targets.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]
+    lib.abm_index_build_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    lib.abm_index_window.argtypes = [C.c_void_p]
+    lib.abm_index_window.restype = C.c_uint32
     lib.abm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.abm_ctx_destroy.argtypes = [C.c_void_p]
     lib.abm_max_read_length.restype = C.c_uint32
     lib.abm_ctx_take_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.abm_ctx_long_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.abm_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.abm_ctx_set_phase_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.abm_ctx_set_read_cycles.argtypes = [C.c_void_p, C.c_void_p]
@@ -107,11 +111,11 @@ def blob_and_offsets(reads):
     return blob, off
 
 
-def index_build(fasta, out, threads=0, targets=None):
-    """abm_index_build / abm_index_build_targets (`abismal idx [-A targets]`)."""
+def index_build(fasta, out, threads=0, targets=None, window=20):
+    """abm_index_build / abm_index_build_opts (`abismal idx [-A targets]`; window 12 = the reference's --enable-short)."""
     threads = threads or (os.cpu_count() or 1)
-    if targets:
-        _check(load_library().abm_index_build_targets(os.fsencode(fasta), os.fsencode(targets), os.fsencode(out), threads))
+    if targets or window != 20:
+        _check(load_library().abm_index_build_opts(os.fsencode(fasta), os.fsencode(targets or ""), window, os.fsencode(out), threads))
     else:
         _check(load_library().abm_index_build(os.fsencode(fasta), os.fsencode(out), threads))
 
@@ -129,6 +133,7 @@ class Index:
         st = self._lib.abm_index_chrom_starts(h)
         self.chrom_starts = np.array([st[i] for i in range(n + 1)], dtype=np.uint32)
         self.max_candidates = self._lib.abm_index_max_candidates(h)
+        self.window = self._lib.abm_index_window(h)
         self.device_bytes = self._lib.abm_index_bytes(h)
 
     def close(self):
@@ -195,6 +200,14 @@ class Context:
                                           se2.ctypes.data, c1.ctypes.data, co1.ctypes.data, c2.ctypes.data,
                                           co2.ctypes.data, cap))
         return pairs, se1, se2, (c1[: int(co1[-1])], co1), (c2[: int(co2[-1])], co2)
+
+    def long_cigars(self):
+        """abm_ctx_long_cigars: the arena (u32 ops) of CIGARs longer than their slot from the last device call."""
+        n = C.c_uint64()
+        _check(self._lib.abm_ctx_long_cigars(self.handle, None, 1 << 40, C.byref(n)))
+        out = np.zeros(max(1, int(n.value)), dtype=np.uint32)
+        _check(self._lib.abm_ctx_long_cigars(self.handle, out.ctypes.data, len(out), C.byref(n)))
+        return out[: int(n.value)]
 
     def set_timing(self, on=True):
         _check(self._lib.abm_ctx_set_timing(self.handle, int(on)))

@@ -68,6 +68,20 @@ template <class T> struct DevBuf {  // grow-only device allocation
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// pinned host staging (grow-only): device -> host copies into pinned memory run at the link's rate
+template <class T> struct HostBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) HIPCHK(hipHostFree(p));
+    p = nullptr; cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault));
+    cap = n;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 }  // namespace
 
 // the index arrays resident on one device, shared by every context created on it
@@ -111,6 +125,9 @@ struct abm_ctx {
   DevBuf<abm::u8> cls;
   DevBuf<unsigned long long> work;
   DevBuf<unsigned long long> next_read;
+  DevBuf<abm::u32> cig_arena, cig_arena_count;  // CIGARs longer than a slot (CigarSink)
+  size_t arena_want = 0;                        // arena size the host entry points ask for (0 = default)
+  HostBuf<abm::u32> h_cn, h_slots, h_arena, h_cn2, h_slots2;
   DevBuf<char> help_ws;  // tail-help workspace of the single-end kernel (see HelpArgs)
   unsigned launch_seq = 0;
   // every device entry point reuses this context's workspaces: a call first makes its stream wait for
@@ -206,6 +223,16 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.res = reinterpret_cast<abm::Hit *>(d_res);
   a.cig = d_cig;
   a.cig_stride = cig_stride;
+  a.ctmp_cap = eff_len + 2;
+  {  // arena for the CIGARs that outgrow their slot: few reads do, one op per read is ample
+    const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, n));
+    ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+    ctx->cig_arena_count.reserve(1);
+    HIPCHK(hipMemsetAsync(ctx->cig_arena_count.p, 0, 4, st));
+    a.cig_arena = ctx->cig_arena.p;
+    a.cig_arena_count = ctx->cig_arena_count.p;
+    a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->cig_arena.cap, 0xFFFFFF00u));
+  }
   a.cig_n = d_cig_n;
   a.status = d_status;
   a.work = ctx->work.p;
@@ -218,12 +245,11 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   };
   a.read_cycles = ctx->phase_stamps ? ctx->read_cycles : nullptr;
   // the occupancy query costs milliseconds: remember it per launch shape
-  const uint64_t shape = (static_cast<uint64_t>(W) << 48) ^ (static_cast<uint64_t>(cig_stride) << 24) ^ (static_cast<uint64_t>(eff_len) << 8) ^
-                         static_cast<uint64_t>(size_frac * 255.0);
+  const uint64_t shape = (static_cast<uint64_t>(W) << 48) ^ (static_cast<uint64_t>(eff_len) << 8) ^ static_cast<uint64_t>(size_frac * 255.0);
   int waves;
   auto it = ctx->se_waves.find(shape);
   if (it != ctx->se_waves.end()) waves = it->second;
-  else { waves = abm::se_resident_waves(W, WB, cig_stride, eff_len, size_frac); ctx->se_waves[shape] = waves; }
+  else { waves = abm::se_resident_waves(W, WB, a.ctmp_cap, eff_len, size_frac); ctx->se_waves[shape] = waves; }
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
   abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
@@ -292,38 +318,39 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(hipEventRecord(ctx->last_done, st));
 }
 
-// fixed CIGAR slots on the device -> compact blob + offsets in the caller's host buffers.  Offsets
-// reserve every read's full op count; a read whose CIGAR outgrew its slot gets only the ops the slot
-// held and is patched by the caller (patch_long_cigars).
-void fetch_cigars(abm_ctx *ctx, const abm::Hit *d_res, const abm::u32 *d_cig, const abm::u32 *d_cig_n, uint64_t n,
-                  uint32_t stride, uint32_t *out_blob, uint64_t cap, uint64_t *out_off) {
-  const hipStream_t st = ctx->stream;
-  ctx->coff.reserve(n + 1);
-  size_t tmp_bytes = 0;
-  HIPCHK(abm::launch_compact_cigars(nullptr, nullptr, nullptr, n, stride, ctx->coff.p, nullptr, nullptr, &tmp_bytes, st));
-  ctx->scan_tmp.reserve(tmp_bytes + 16);
-  HIPCHK(abm::launch_compact_cigars(d_res, d_cig, d_cig_n, n, stride, ctx->coff.p, nullptr, ctx->scan_tmp.p, &tmp_bytes, st));
-  unsigned long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, ctx->coff.p + n, sizeof(total), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (total > cap) throw std::length_error("cig_capacity too small");
-  ctx->cblob.reserve(std::max<unsigned long long>(total, 1));
-  if (total) {
-    // offsets are already scanned: only the gather is left
-    HIPCHK(abm::launch_gather_cigars(d_cig, stride, ctx->coff.p, n, ctx->cblob.p, st));
-    HIPCHK(hipMemcpyAsync(out_blob, ctx->cblob.p, total * 4ull, hipMemcpyDeviceToHost, st));
-  }
-  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "offset width");
-  HIPCHK(hipMemcpyAsync(out_off, ctx->coff.p, (n + 1) * 8ull, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-}
-
-// reads whose compact CIGAR is longer than the slot it came from
-std::vector<uint64_t> long_cigars(const uint64_t *off, uint64_t n, uint32_t stride) {
-  std::vector<uint64_t> v;
-  for (uint64_t r = 0; r < n; ++r)
-    if (off[r + 1] - off[r] > stride) v.push_back(r);
-  return v;
+// CIGARs as the kernels leave them -- `stride` ops per read in fixed slots, longer ones whole in the launch's
+// arena with slot[0] = where -- into the caller's compact blob + n + 1 offsets, in read order.  Host-side on
+// purpose: no kernel has to run after the mapping kernel, so a batch's results leave the GPU while the next
+// batch's (persistent, device-filling) mapping kernel is already running.
+void assemble_cigars(uint64_t n, uint32_t stride, const uint32_t *cn, const uint32_t *slots, const uint32_t *arena,
+                     uint64_t arena_n, uint32_t *out_blob, uint64_t cap, uint64_t *out_off) {
+  out_off[0] = 0;
+  for (uint64_t i = 0; i < n; ++i) out_off[i + 1] = out_off[i] + cn[i];
+  if (out_off[n] > cap) throw std::length_error("cig_capacity too small");
+  auto fill = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      const uint32_t k = cn[i];
+      if (k == 0) continue;
+      const uint32_t *src = slots + i * stride;
+      if (k > stride) {
+        if (static_cast<uint64_t>(src[0]) + k > arena_n) throw std::runtime_error("CIGAR arena reference out of range");
+        src = arena + src[0];
+      }
+      std::memcpy(out_blob + out_off[i], src, k * 4ull);
+    }
+  };
+  const unsigned nt = n > (1u << 18) ? 8u : 1u;
+  if (nt == 1) { fill(0, n); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err;
+  std::mutex emu;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try { fill(n * t / nt, n * (t + 1) / nt); }
+      catch (...) { std::lock_guard<std::mutex> lk(emu); err = std::current_exception(); }
+    });
+  for (auto &x : th) x.join();
+  if (err) std::rethrow_exception(err);
 }
 
 void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob1,
@@ -374,6 +401,16 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.pairs = reinterpret_cast<abm::Hit *>(d_pair);
   a.se1 = reinterpret_cast<abm::Hit *>(d_se1); a.se2 = reinterpret_cast<abm::Hit *>(d_se2);
   a.cig1 = d_cig1; a.cig2 = d_cig2; a.cig_stride = cig_stride; a.cig_n1 = d_cig_n1; a.cig_n2 = d_cig_n2;
+  a.ctmp_cap = eff_len + 2;
+  {
+    const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, 2 * n));
+    ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+    ctx->cig_arena_count.reserve(1);
+    HIPCHK(hipMemsetAsync(ctx->cig_arena_count.p, 0, 4, st));
+    a.cig_arena = ctx->cig_arena.p;
+    a.cig_arena_count = ctx->cig_arena_count.p;
+    a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->cig_arena.cap, 0xFFFFFF00u));
+  }
   a.status = d_status;
   a.work = ctx->work.p;
   a.need_big = ctx->need_big.p;
@@ -381,7 +418,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   // tier 1: every pair, small sets in LDS
   {
     a.cap = abm::kPeTier1Cap;
-    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, size_frac, a.cap, false);
+    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, false);
     const int waves = abm::pe_resident_waves(lds, false);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 1) does not fit on this device");
     ctx->payload1.reserve(static_cast<size_t>(waves) * a.cap);
@@ -399,7 +436,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(abm::launch_collect_big(ctx->need_big.p, ctx->cls.p, n, ctx->class33.p, ctx->subset.p, ctx->subset_count.p, st));
     a.cap = abm::kPeCapLarge;
     a.order = nullptr;
-    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, cig_stride, eff_len, size_frac, a.cap, true);
+    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, true);
     const int waves = abm::pe_resident_waves(lds, true);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
     ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);
@@ -461,6 +498,13 @@ int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_thr
 }
 
 int abm_index_build_targets(const char *fasta_path, const char *targets_path, const char *out_path, uint32_t n_threads) {
+  return abm_index_build_opts(fasta_path, targets_path, 20, out_path, n_threads);
+}
+
+uint32_t abm_index_window(const abm_index *ix) { return ix->h.window; }
+
+int abm_index_build_opts(const char *fasta_path, const char *targets_path, uint32_t window, const char *out_path,
+                         uint32_t n_threads) {
   return guarded([&] {
     if (!fasta_path || !out_path) throw std::invalid_argument("null argument");
     std::string text;
@@ -469,7 +513,7 @@ int abm_index_build_targets(const char *fasta_path, const char *targets_path, co
     abm::load_fasta(fasta_path, text, names, starts);
     if (targets_path && targets_path[0]) abm::mask_outside_targets(targets_path, text, names, starts);
     abm::HostIndex h;
-    abm::build_index(text, names, starts, n_threads ? n_threads : 1u, h);
+    abm::build_index(text, names, starts, n_threads ? n_threads : 1u, h, window);
     abm::write_index(h, out_path);
   });
 }
@@ -515,6 +559,8 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
             rep.dix.index_t = reinterpret_cast<const abm::u32 *>(base + offs[5]);
             rep.dix.index_a = reinterpret_cast<const abm::u32 *>(base + offs[6]);
             rep.dix.max_candidates = h.max_candidates;
+            rep.dix.window = h.window;
+            rep.dix.min_len = abm::kKeyWeight + h.window - 1;
           }
           catch (...) { (void)hipFree(arena); throw; }
           rep.arena = arena;
@@ -560,7 +606,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->ix->replicas.erase(it);
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->help_ws.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->help_ws.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -718,34 +764,33 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
         throw std::runtime_error("kernel reported status " + std::to_string(status));
       return status;
     };
-    const uint32_t stride = 16;
+    // four ops per slot cover nearly every read; longer CIGARs come back through the arena.  If the arena
+    // itself ran out (its default size is one op per read), the batch is mapped again with a larger one.
+    const uint32_t stride = 4;
     HostTrace tr;
-    const uint32_t status = run(n, seq_blob + base, bytes, rel.data(), stride, true);
-    tr.mark("upload+map");
-    HIPCHK(hipMemcpyAsync(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
-    fetch_cigars(ctx, ctx->res.p, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob, cig_capacity, out_cig_off);
-    tr.mark("hits+cigars back");
-    if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) return;
-    // The few reads whose CIGAR has more ops than the slot are mapped again (same hits, the
-    // mapping is deterministic) with full-size slots, and their ops written over the truncated ones.
-    const std::vector<uint64_t> again = long_cigars(out_cig_off, n, stride);
-    if (again.empty()) return;
-    std::string sub;
-    std::vector<uint64_t> sub_off(1, 0);
-    for (uint64_t r : again) { sub.append(seq_blob + seq_off[r], seq_off[r + 1] - seq_off[r]); sub_off.push_back(sub.size()); }
-    const uint32_t wide = max_len + 2;
-    const uint64_t m = again.size();
-    run(m, sub.data(), sub.size(), sub_off.data(), wide, false);
-    std::vector<uint32_t> slots(m * wide), counts(m);
-    HIPCHK(hipMemcpyAsync(slots.data(), ctx->cig.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(counts.data(), ctx->cig_n.p, m * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (uint64_t k = 0; k < m; ++k) {
-      const uint64_t r = again[k], have = out_cig_off[r + 1] - out_cig_off[r];
-      if (counts[k] != have || counts[k] > wide) throw std::runtime_error("CIGAR rerun disagrees with the first pass");
-      std::memcpy(out_cig_blob + out_cig_off[r], slots.data() + k * wide, have * 4ull);
+    for (;;) {
+      const uint32_t status = run(n, seq_blob + base, bytes, rel.data(), stride, true);
+      tr.mark("upload+map");
+      if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) break;
+      if (ctx->cig_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
+      ctx->arena_want = ctx->cig_arena.cap * 4;
     }
-    tr.mark("long-cigar rerun");
+    ctx->h_cn.reserve(n);
+    ctx->h_slots.reserve(n * stride);
+    uint32_t arena_n = 0;
+    HIPCHK(hipMemcpyAsync(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_cn.p, ctx->cig_n.p, n * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_slots.p, ctx->cig.p, n * stride * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&arena_n, ctx->cig_arena_count.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->h_arena.reserve(std::max<uint32_t>(arena_n, 1));
+    if (arena_n) {
+      HIPCHK(hipMemcpyAsync(ctx->h_arena.p, ctx->cig_arena.p, arena_n * 4ull, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    tr.mark("hits+cigars back");
+    assemble_cigars(n, stride, ctx->h_cn.p, ctx->h_slots.p, ctx->h_arena.p, arena_n, out_cig_blob, cig_capacity, out_cig_off);
+    tr.mark("cigars assembled");
   });
 }
 
@@ -823,46 +868,50 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
         throw std::runtime_error("kernel reported status " + std::to_string(status));
       return status;
     };
-    const uint32_t stride = 16;
-    const uint32_t status = run(n, seq_blob1 + seq_off1[0], rel1[n], rel1.data(), seq_blob2 + seq_off2[0], rel2[n],
-                                rel2.data(), stride);
+    const uint32_t stride = 4;
+    for (;;) {
+      const uint32_t status = run(n, seq_blob1 + seq_off1[0], rel1[n], rel1.data(), seq_blob2 + seq_off2[0], rel2[n],
+                                  rel2.data(), stride);
+      if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) break;
+      if (ctx->cig_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
+      ctx->arena_want = ctx->cig_arena.cap * 4;
+    }
+    ctx->h_cn.reserve(n); ctx->h_cn2.reserve(n);
+    ctx->h_slots.reserve(n * stride); ctx->h_slots2.reserve(n * stride);
+    uint32_t arena_n = 0;
     HIPCHK(hipMemcpyAsync(out_pair, d_pair, n * sizeof(abm_pair), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out_se1, d_se1, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out_se2, d_se2, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
-    fetch_cigars(ctx, nullptr, ctx->cig.p, ctx->cig_n.p, n, stride, out_cig_blob1, cig_capacity, out_cig_off1);
-    fetch_cigars(ctx, nullptr, ctx->cig2h.p, ctx->cig_n2h.p, n, stride, out_cig_blob2, cig_capacity, out_cig_off2);
-    if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) return;
-    // pairs with a CIGAR longer than its slot: mapped again with full-size slots, ops patched in
-    std::vector<uint64_t> again = long_cigars(out_cig_off1, n, stride);
-    {
-      const std::vector<uint64_t> b = long_cigars(out_cig_off2, n, stride);
-      std::vector<uint64_t> u;
-      std::set_union(again.begin(), again.end(), b.begin(), b.end(), std::back_inserter(u));
-      again.swap(u);
-    }
-    if (again.empty()) return;
-    std::string s1, s2;
-    std::vector<uint64_t> so1(1, 0), so2(1, 0);
-    for (uint64_t r : again) {
-      s1.append(seq_blob1 + seq_off1[r], seq_off1[r + 1] - seq_off1[r]); so1.push_back(s1.size());
-      s2.append(seq_blob2 + seq_off2[r], seq_off2[r + 1] - seq_off2[r]); so2.push_back(s2.size());
-    }
-    const uint32_t wide = max_len + 2;
-    const uint64_t m = again.size();
-    run(m, s1.data(), s1.size(), so1.data(), s2.data(), s2.size(), so2.data(), wide);
-    std::vector<uint32_t> slots1(m * wide), slots2(m * wide), c1(m), c2(m);
-    HIPCHK(hipMemcpyAsync(slots1.data(), ctx->cig.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(slots2.data(), ctx->cig2h.p, m * wide * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c1.data(), ctx->cig_n.p, m * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c2.data(), ctx->cig_n2h.p, m * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_cn.p, ctx->cig_n.p, n * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_cn2.p, ctx->cig_n2h.p, n * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_slots.p, ctx->cig.p, n * stride * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_slots2.p, ctx->cig2h.p, n * stride * 4ull, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&arena_n, ctx->cig_arena_count.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (uint64_t k = 0; k < m; ++k) {
-      const uint64_t r = again[k];
-      const uint64_t h1 = out_cig_off1[r + 1] - out_cig_off1[r], h2 = out_cig_off2[r + 1] - out_cig_off2[r];
-      if (c1[k] != h1 || c2[k] != h2 || h1 > wide || h2 > wide) throw std::runtime_error("CIGAR rerun disagrees with the first pass");
-      std::memcpy(out_cig_blob1 + out_cig_off1[r], slots1.data() + k * wide, h1 * 4ull);
-      std::memcpy(out_cig_blob2 + out_cig_off2[r], slots2.data() + k * wide, h2 * 4ull);
+    ctx->h_arena.reserve(std::max<uint32_t>(arena_n, 1));
+    if (arena_n) {
+      HIPCHK(hipMemcpyAsync(ctx->h_arena.p, ctx->cig_arena.p, arena_n * 4ull, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
     }
+    assemble_cigars(n, stride, ctx->h_cn.p, ctx->h_slots.p, ctx->h_arena.p, arena_n, out_cig_blob1, cig_capacity, out_cig_off1);
+    assemble_cigars(n, stride, ctx->h_cn2.p, ctx->h_slots2.p, ctx->h_arena.p, arena_n, out_cig_blob2, cig_capacity, out_cig_off2);
+  });
+}
+
+// CIGARs of the context's last device call that were longer than their slot (count > cig_stride): each lies
+// whole in the arena, beginning at the index its slot's first word holds.
+int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint64_t *n_ops) {
+  return guarded([&] {
+    if (!ctx || !n_ops) throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventSynchronize(ctx->last_done));
+    uint32_t cnt = 0;
+    if (ctx->cig_arena_count.p) HIPCHK(hipMemcpy(&cnt, ctx->cig_arena_count.p, 4, hipMemcpyDeviceToHost));
+    cnt = static_cast<uint32_t>(std::min<uint64_t>(cnt, ctx->cig_arena.cap));
+    *n_ops = cnt;
+    if (cnt > capacity) throw std::length_error("capacity too small for the long CIGARs");
+    if (cnt && out_ops) HIPCHK(hipMemcpy(out_ops, ctx->cig_arena.p, cnt * 4ull, hipMemcpyDeviceToHost));
   });
 }
 

@@ -40,7 +40,8 @@ namespace abm { int sim_main(int argc, char **argv); }
 namespace {
 
 constexpr const char *kVersion = "3.3.0";  // the SAM @PG line carries the reference's version
-constexpr uint32_t kMinReadLen = 44, kPadding = 32767;
+constexpr uint32_t kPadding = 32767;
+uint32_t g_min_read_len = 44;  // key weight + the index's window - 1 (src/abismal.cpp:212-213): 36 with a short-read index
 
 [[noreturn]] void die_abm(const char *what) { throw std::runtime_error(std::string(what) + ": " + abm_last_error()); }
 
@@ -293,7 +294,7 @@ void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, 
                                  ", which is too long. Maximum allowed read size = " + std::to_string(kPadding));
       size_t informative = 0;
       for (const char *c = p; c < le; ++c) informative += (*c != 'N');
-      if (informative >= kMinReadLen) {
+      if (informative >= g_min_read_len) {
         const char *e = le;
         while (e > p && e[-1] == 'N') --e;                       // remove Ns from 3'
         const char *b = p;
@@ -601,15 +602,18 @@ int cmd_idx(int argc, char **argv) {
   unsigned threads = std::max(1u, std::thread::hardware_concurrency());
   std::vector<std::string> pos;
   std::string targets;  // -A: index only these regions (src/abismalidx.cpp:51-52, :91-92)
+  uint32_t window = 20;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if ((a == "-t" || a == "-threads" || a == "--threads") && i + 1 < argc) threads = static_cast<unsigned>(std::stoul(argv[++i]));
     else if ((a == "-A" || a == "-targets" || a == "--targets") && i + 1 < argc) targets = argv[++i];
+    else if ((a == "-w" || a == "-window" || a == "--window") && i + 1 < argc) window = static_cast<uint32_t>(std::stoul(argv[++i]));
+    else if (a == "-short" || a == "--short") window = 12;  // what the reference's --enable-short build indexes with
     else if (a == "-v" || a == "-verbose") {}
     else pos.push_back(a);
   }
-  if (pos.size() != 2) { std::cerr << "usage: abismal-amd idx [-t n] [-A targets] <genome.fa> <out.idx>\n"; return EXIT_SUCCESS; }
-  if (abm_index_build_targets(pos[0].c_str(), targets.c_str(), pos[1].c_str(), threads) != 0) die_abm("idx");
+  if (pos.size() != 2) { std::cerr << "usage: abismal-amd idx [-t n] [-A targets] [-short | -w 12] <genome.fa> <out.idx>\n"; return EXIT_SUCCESS; }
+  if (abm_index_build_opts(pos[0].c_str(), targets.c_str(), window, pos[1].c_str(), threads) != 0) die_abm("idx");
   return EXIT_SUCCESS;
 }
 
@@ -629,6 +633,7 @@ int cmd_map(int argc, char **argv) {
   const auto t_index = std::chrono::steady_clock::now();
   if (abm_index_open(index_path.c_str(), &ix) != 0) die_abm("loading index");
   if (opt.index.empty()) std::remove(index_path.c_str());
+  g_min_read_len = 24 + abm_index_window(ix);
   Chroms ch;
   for (uint32_t i = 0; i < abm_index_n_chroms(ix); ++i) ch.names.push_back(abm_index_chrom_name(ix, i));
   ch.starts.assign(abm_index_chrom_starts(ix), abm_index_chrom_starts(ix) + ch.names.size() + 1);
@@ -726,7 +731,7 @@ int cmd_map(int argc, char **argv) {
   // Batches are FULL (-batch reads) except at the end of the input: the mapping kernel's time has a floor set
   // by its costliest reads (a quarter of a second, whatever the batch), so small batches waste the GPU;
   // cutting and parsing run far ahead of it, so a full batch is ready within a fraction of a kernel's time.
-  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 24)));
+  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
   const unsigned n_host = std::max(1u, opt.threads);
   const size_t max_reads_in_flight = (static_cast<size_t>(n_gpus) * per_gpu + 2) * batch_reads + 4 * slice_reads * n_host;
   std::deque<std::unique_ptr<Slice>> q_parse;               // cut, waiting for a parser
@@ -741,6 +746,8 @@ int cmd_map(int argc, char **argv) {
   uint64_t run_end = 0, n_parsed = 0;  // parsed[next_to_map .. run_end) are all there; slices parsed so far
   size_t run_reads = 0;                // reads in that run
   SlicePool slice_pool;
+  int writers_active = 0;  // writes to one file run one at a time in the kernel: a few writers keep it busy, the rest format
+  constexpr int kMaxWriters = 4;
   size_t reads_in_flight = 0;
   bool cut_done = false;
   int parsers_live = 0, mappers_live = 0;
@@ -1010,10 +1017,20 @@ int cmd_map(int argc, char **argv) {
         {
           std::unique_lock<std::mutex> lk(mu);
           auto all_parsed = [&] { return cut_done && n_parsed == n_slices; };
-          cv.wait(lk, [&] { return failure || run_reads >= batch_reads || (all_parsed() && (run_end > next_to_map || parsed.empty())); });
+          // How many reads this batch should hold.  While the input is still being cut: a full batch.  Once its
+          // extent is known (cutting runs far ahead of parsing): what is left, split evenly into batches of at
+          // most -batch reads -- and into two even when one would do, if each half still has a few million reads:
+          // a batch's output is formatted and written while the next one is being mapped.
+          auto target = [&]() -> size_t {
+            if (!cut_done) return batch_reads;
+            const size_t left = static_cast<size_t>(n_slices - next_to_map) * slice_reads;
+            size_t k = (left + batch_reads - 1) / batch_reads;
+            if (k <= 1) k = left >= (1u << 22) ? 2 : 1;
+            return std::max<size_t>(slice_reads, (left + k - 1) / k);
+          };
+          cv.wait(lk, [&] { return failure || run_reads >= target() || (all_parsed() && (run_end > next_to_map || parsed.empty())); });
           if (failure || run_end == next_to_map) break;
-          // a full batch; at the end of the input whatever is left, if that is at most a batch and a half
-          const size_t want = (all_parsed() && run_reads <= batch_reads + batch_reads / 2) ? run_reads : batch_reads;
+          const size_t want = std::min(target(), std::max<size_t>(run_reads, 1));
           while (next_to_map < run_end) {
             auto it = parsed.find(next_to_map);
             if (!b->slices.empty() && b->n + it->second->n() > want) break;
@@ -1207,9 +1224,13 @@ int cmd_map(int argc, char **argv) {
         uint64_t at = 0;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return failure || !q_write.empty() || !q_format.empty() || (mappers_live == 0 && slices_written == n_slices && cut_done); });
+          cv.wait(lk, [&] { return failure || (!q_write.empty() && writers_active < kMaxWriters) || !q_format.empty() ||
+                                   (mappers_live == 0 && slices_written == n_slices && cut_done); });
           if (failure) break;
-          if (!q_write.empty()) { to_write = q_write.front(); q_write.pop_front(); at = place[to_write->g]; place.erase(to_write->g); }
+          if (!q_write.empty() && writers_active < kMaxWriters) {
+            to_write = q_write.front(); q_write.pop_front(); at = place[to_write->g]; place.erase(to_write->g);
+            ++writers_active;
+          }
           else if (!q_format.empty()) { to_format = q_format.front(); q_format.pop_front(); }
           else break;
         }
@@ -1245,6 +1266,7 @@ int cmd_map(int argc, char **argv) {
           }
           else write_all(to_write->text.data(), to_write->text.size(), at);
           std::lock_guard<std::mutex> lk(mu);
+          --writers_active;
           busy_write += since(t0);
           trace("written", to_write->g, static_cast<uint64_t>(since(t0) * 1e6));
           Batch *b = to_write->batch;

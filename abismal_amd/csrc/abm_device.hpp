@@ -19,7 +19,7 @@ using i32 = int32_t;
 
 constexpr u32 kKeyWeight = 25;   // src/AbismalIndex.hpp:68
 constexpr u32 kKeyWeight3 = 16;  // src/AbismalIndex.hpp:69
-constexpr u32 kWindow = 20;      // src/AbismalIndex.hpp:76
+constexpr u32 kWindow = 20;      // src/AbismalIndex.hpp:76 (12 in a short-read index: DevIndex::window)
 constexpr u32 kHashMod3 = 43046721u;
 constexpr u32 kMinReadLen = 44;  // src/abismal.cpp:212-213
 constexpr u32 kMaxReadLen = 512; // kernel cap (LDS-resident traceback)
@@ -34,6 +34,8 @@ struct DevIndex {
   const u32 *counter, *counter_t, *counter_a;
   const u32 *index, *index_t, *index_a;
   u32 max_candidates;
+  u32 window;   // seed window of this index: 20, or 12 (--enable-short, src/AbismalIndex.hpp:73-77)
+  u32 min_len;  // shortest read that is mapped: key_weight + window - 1 (src/abismal.cpp:212-213)
 };
 
 struct Hit {  // == abm_hit

@@ -20,7 +20,7 @@ namespace abm {
 
 namespace {
 
-constexpr uint32_t K2 = 25, K3 = 16, WIN = 20, DEPTH = 256, PAD = 32767, MAXN = 256;
+constexpr uint32_t K2 = 25, K3 = 16, DEPTH = 256, PAD = 32767, MAXN = 256;
 constexpr uint32_t MASK2 = (1u << K2) - 1, MOD3 = 43046721u;
 constexpr uint64_t BLOCK = 1000000;
 
@@ -156,7 +156,11 @@ void mask_outside_targets(const std::string &targets_path, std::string &text, co
 }
 
 void build_index(std::string &text, const std::vector<std::string> &names,
-                 const std::vector<uint32_t> &starts, unsigned nt, HostIndex &out) {
+                 const std::vector<uint32_t> &starts, unsigned nt, HostIndex &out, uint32_t window) {
+  if (window != 20 && window != 12)
+    throw std::runtime_error("window size must be 20 or 12 (short reads)");
+  const uint32_t WIN = window;
+  out.window = window;
   nt = std::max(1u, nt);
   const uint64_t G = text.size();
   if (G >= (1ull << 32))
@@ -378,7 +382,7 @@ void write_index(const HostIndex &h, const std::string &path) {
       throw std::runtime_error("failed writing index");
   };
   put("AbismalIndex", 12);
-  const uint32_t seed[3] = {K2, WIN, DEPTH};
+  const uint32_t seed[3] = {K2, h.window, DEPTH};
   put(seed, sizeof(seed));
   const uint32_t n_chroms = static_cast<uint32_t>(h.chrom_names.size());
   put(&n_chroms, 4);

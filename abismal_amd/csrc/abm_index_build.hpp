@@ -11,7 +11,7 @@ void mask_outside_targets(const std::string &targets_path, std::string &text, co
                           const std::vector<uint32_t> &starts);
 // consumes `text` (freed early to bound peak memory)
 void build_index(std::string &text, const std::vector<std::string> &names,
-                 const std::vector<uint32_t> &starts, unsigned n_threads, HostIndex &out);
+                 const std::vector<uint32_t> &starts, unsigned n_threads, HostIndex &out, uint32_t window = 20);
 // AbismalIndex::write, src/AbismalIndex.cpp:1037-1072
 void write_index(const HostIndex &h, const std::string &path);
 }  // namespace abm

@@ -29,8 +29,9 @@ void HostIndex::load(const std::string &path) {
   need(f, seed, 3, "failed to read seed data");
   if (seed[0] != 25u)
     throw std::runtime_error("inconsistent k-mer size. Expected: 25, got: " + std::to_string(seed[0]));
-  if (seed[1] != 20u)
+  if (seed[1] != 20u && seed[1] != 12u)  // (a reference binary takes only the one it was compiled for; this one follows the file)
     throw std::runtime_error("inconsistent window size size. Expected: 20, got: " + std::to_string(seed[1]));
+  window = seed[1];
   if (seed[2] != 256u)
     throw std::runtime_error("inconsistent sorting size size. Expected: 256, got: " + std::to_string(seed[2]));
   // ChromLookup::read, :1225-1258

@@ -11,6 +11,9 @@ struct HostIndex {
   std::vector<std::string> chrom_names;  // incl. pad_start / pad_end
   std::vector<uint32_t> chrom_starts;    // n_chroms + 1
   uint32_t max_candidates = 100;
+  // seed window: 20, or 12 for an index made for short reads (the reference's --enable-short build:
+  // configure.ac:70-73, src/AbismalIndex.hpp:73-77).  Stored in the file; the mapper follows it.
+  uint32_t window = 20;
   bool multibit_genome = false;  // some genome nibble has 2+ bits (IUPAC code): Hamming sums can go negative
   uint64_t counter_size = 0, counter_size3 = 0, index_size = 0, index_size3 = 0;
   // one contiguous arena so the upload is a handful of large copies

@@ -80,7 +80,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
   lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
   lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
-  lds.jpos = lds.ctmp + a.cig_stride;
+  lds.jpos = lds.ctmp + a.ctmp_cap;
   lds.jdf = lds.jpos + kSeCap;
   lds.lbest = reinterpret_cast<int *>(lds.jdf + kSeCap);
   lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
@@ -103,6 +103,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   hw.r = 0;
   hw.epoch = 0;
   hw.registered = hw.on = hw.failed = hw.mismatch = false;
+  const CigarSink sink = {a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap};
   PassCtl pc;
   pc.hw = &hw;
   pc.gave_up = false;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     u32 n_ops = 0;
     u32 *cig_out = a.cig + r * a.cig_stride;
     if (L > kMaxReadLen) too_long = true;
-    if (L >= kMinReadLen && L <= kMaxReadLen) {
+    if (L >= a.ix.min_len && L <= kMaxReadLen) {
       // stage the four encodings and derive their 2-letter bit strings
       const u64 *src = a.packed + r * 4 * a.W;
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[k] = src[k];
@@ -154,8 +155,8 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
           if (lane == 0) lds.qbits[e * a.WB + wb] = word;
         }
       __syncthreads();
-      if (L < max(kWindow, L >> 1) + kKeyWeight - 1)  // 44-46 bases: seeds reach past the end of the read
-        ghost_bits(a.packed, a.lens, r, L, a.max_len, a.W, a.WB, lds.qbits);
+      if (L < max(a.ix.window, L >> 1) + kKeyWeight - 1)  // 44-46 bases: seeds reach past the end of the read
+        ghost_bits(a.packed, a.lens, r, L, a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits);
 
       SeSet S;
       S.begin_read(L);
@@ -181,7 +182,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         continue;
       }
       ABM_STAMP(t_a);
-      choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, a.cig_stride, n_ops, overflow, n_aln);
+      choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln);
       ABM_STAMP(t_b);
       if (TIMED) wt.t_align += t_b - t_a;
     }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void weigh_reads_kernel(DevIndex ix, const u64
   if (r < n) {
     const u32 L = lens[r];
     u32 c = 0;
-    if (L >= kMinReadLen) {
+    if (L >= ix.min_len) {
       const u64 *pk = packed + r * 4 * W;
       // forward call of the mode and its reverse-strand partner
       const bool ar = mode == 1;
@@ -420,7 +421,7 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
 
 hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st, bool heavy) {
   if (a.n_reads == 0) return hipSuccess;
-  const size_t lds = se_lds_bytes(a.W, a.WB, a.cig_stride, max_len, a.size_frac);
+  const size_t lds = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
   if (heavy) {
     if (a.G != 0) {

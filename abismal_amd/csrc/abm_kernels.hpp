@@ -38,6 +38,10 @@ struct SeArgs {
   Hit *res;           // [n]
   u32 *cig;           // [n][cig_stride]
   u32 cig_stride;
+  u32 ctmp_cap;       // LDS scratch for a CIGAR's ops: longest read + 2
+  u32 *cig_arena;     // CIGARs longer than a slot (see CigarSink); null = none
+  u32 *cig_arena_count;
+  u32 cig_arena_cap;
   u32 *cig_n;         // [n]
   u32 *status;        // ABM_STATUS_* bits
   unsigned long long *next_read;  // work counter, zero at launch
@@ -65,6 +69,10 @@ struct PeArgs {
   Hit *se1, *se2;
   u32 *cig1, *cig2;
   u32 cig_stride;
+  u32 ctmp_cap;                  // LDS scratch for a CIGAR's ops: longest read + 2
+  u32 *cig_arena;                // CIGARs longer than a slot (see CigarSink; both ends share it); null = none
+  u32 *cig_arena_count;
+  u32 cig_arena_cap;
   u32 *cig_n1, *cig_n2;
   u32 *status;
   unsigned long long *next_read;

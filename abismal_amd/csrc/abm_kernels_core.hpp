@@ -139,7 +139,7 @@ struct WaveLds {
   u64 *qpk;    // [4][W] packed encodings
   u64 *qbits;  // [4][WB] 2-letter bit strings, bit j = bit2(nibble j), 1 past the end
   u16 *mark;   // [64]
-  u32 *ctmp;   // [cig_stride] reversed CIGAR scratch
+  u32 *ctmp;   // [ctmp_cap] reversed CIGAR scratch
   u8 *tb;      // traceback bytes
   u64 *gwin;   // [kMaxJobs][GW] genome windows of the alignments in flight
   u32 *jpos;   // [kSeCap] alignment job list: position
@@ -547,7 +547,7 @@ struct HelpWave {  // one wave's view of the help workspace (see HelpArgs)
 // reads handed over before it (lens / packed of the same batch, input order = the reference at -t 1)
 // and writes them into the bit strings qbits (>= 2 words per encoding).  Lane j <-> position L + j.
 __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const u32 *__restrict__ lens, u64 r, u32 L,
-                                           u32 max_len, u32 W, u32 WB, u64 *qbits) {
+                                           u32 max_len, u32 min_len, u32 W, u32 WB, u64 *qbits) {
   const int lane = lane_id();
   const u32 k = L + static_cast<u32>(lane);
   bool found = k >= max_len;  // no read of this batch ever wrote that far: still the zero fill
@@ -556,7 +556,7 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
     const u32 len_q = base > static_cast<u64>(lane) ? lens[base - 1 - lane] : 0u;
     for (int t = 0; t < 64; ++t) {
       const u32 lt = rdlane(len_q, t);
-      if (!found && lt >= kMinReadLen && lt > k) { found = true; src = base - 1 - t; }
+      if (!found && lt >= min_len && lt > k) { found = true; src = base - 1 - t; }
     }
   }
   const bool have = found && k < max_len && src < r && lens[src] > k;
@@ -674,8 +674,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   const u32 *idx3 = g_to_a ? ix.index_a : ix.index_t;
   const u32 maxc = ix.max_candidates;
   const u32 nwords = (L + 15) >> 4;
-  const u32 spec_len = min(L - kWindow, L >> 1);
-  const u32 n_off = SPECIFIC ? max(kWindow, L >> 1) : L - kKeyWeight + 1;
+  const u32 spec_len = min(L - ix.window, L >> 1);
+  const u32 n_off = SPECIFIC ? max(ix.window, L >> 1) : L - kKeyWeight + 1;
 
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
   if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
@@ -1058,11 +1058,21 @@ __device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job,
   }
 }
 
+// where CIGARs go: fixed slots of `stride` ops per read; one with more ops goes whole into the launch's
+// overflow arena (bump-allocated), its slot's first word = where, and its count (> stride) says so
+struct CigarSink {
+  u32 stride;
+  u32 ctmp_cap;        // entries of the reversed-ops scratch in LDS (longest read + 2: no CIGAR has more ops)
+  u32 *arena;          // [arena_cap] or null
+  u32 *arena_count;    // ops handed out so far
+  u32 arena_cap;
+};
+
 // build_cigar_len_and_pos + get_traceback (src/AbismalAlign.hpp:166-193, :388-440).
 // Runs uniformly on the wave; ops are collected reversed in LDS then emitted.
 __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int diffs, int max_diffs,
                                            int score, int best_r, int best_c, u32 *cig_out,
-                                           u32 cig_stride, u32 &n_ops, int &ins, int &del, u32 &aln_len,
+                                           const CigarSink &sink, u32 &n_ops, int &ins, int &del, u32 &aln_len,
                                            u32 &t_pos, bool &overflow) {
   const int lane = lane_id();
   ins = del = 0;  // count_total_ops<I>/<D> with oplen() narrowed to uint8_t (abismal_cigar_utils.hpp:50-53)
@@ -1077,8 +1087,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   const int clip_tail = (L + (bw - 1)) - (r + c);
   u32 n = 0;
   auto emit = [&](u32 run, int op) {
-    if (n < cig_stride) { if (lane == 0) ctmp[n] = (run << 4) | static_cast<u32>(op); }
-    else overflow = true;
+    if (n < sink.ctmp_cap) { if (lane == 0) ctmp[n] = (run << 4) | static_cast<u32>(op); }
     if (op == 1) ins = static_cast<i16>(ins + static_cast<int>(static_cast<u8>(run)));
     if (op == 2) del = static_cast<i16>(del + static_cast<int>(static_cast<u8>(run)));
     ++n;
@@ -1104,19 +1113,35 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   const int clip_head = (r + c) - (bw - 1);
   __syncthreads();
   // final order: [head clip] reversed(ops) [tail clip]
-  const u32 body = min(n, cig_stride);
-  const u32 full = n + (clip_head > 0) + (clip_tail > 0);  // the CIGAR's true op count
-  u32 total = body + (clip_head > 0) + (clip_tail > 0);
-  if (n > cig_stride || total > cig_stride) { overflow = true; total = min(total, cig_stride); }
+  const u32 full = n + (clip_head > 0) + (clip_tail > 0);  // the CIGAR's op count
+  u32 *dst = cig_out;
+  u32 body = n, total = full;
+  if (full > sink.stride) {  // too long for the slot: the whole CIGAR goes to the arena
+    u32 at = 0xFFFFFFFFu;
+    if (sink.arena != nullptr && n <= sink.ctmp_cap) {
+      if (lane == 0) at = atomicAdd(sink.arena_count, full);
+      at = static_cast<u32>(uni(static_cast<int>(at)));
+      if (at > sink.arena_cap || full > sink.arena_cap - at) at = 0xFFFFFFFFu;
+    }
+    if (at != 0xFFFFFFFFu) {
+      dst = sink.arena + at;
+      if (lane == 0) cig_out[0] = at;
+    }
+    else {  // no room: the slot gets what fits and the launch is flagged
+      overflow = true;
+      body = min(min(n, sink.ctmp_cap), sink.stride);
+      total = min(body + (clip_head > 0) + (clip_tail > 0), sink.stride);
+    }
+  }
   for (u32 k = lane; k < total; k += 64) {
     u32 v;
     const u32 kk = k - (clip_head > 0 ? 1u : 0u);
     if (clip_head > 0 && k == 0) v = (static_cast<u32>(clip_head) << 4) | 4u;
     else if (kk < body) v = ctmp[body - 1 - kk];
     else v = (static_cast<u32>(clip_tail) << 4) | 4u;
-    cig_out[k] = v;
+    dst[k] = v;
   }
-  n_ops = full;  // > cig_stride: the slot is incomplete and the caller maps this read again with a wider slot
+  n_ops = full;  // > stride: the ops are in the arena at slot[0] (or, with ABM_STATUS_CIGAR_OVERFLOW set, nowhere complete)
   aln_len = static_cast<u32>(L - clip_tail - clip_head);
   t_pos = t_pos - static_cast<u32>((bw - 1) / 2) + static_cast<u32>(r);
 }
@@ -1132,7 +1157,7 @@ __device__ __forceinline__ int edit_distance(int scr, u32 len, int ins, int del)
   return static_cast<i16>(mism + ins + del);
 }
 
-__device__ __forceinline__ bool long_enough(u32 aln_len, u32 readlen) {
+__device__ __forceinline__ bool long_enough(u32 aln_len, u32 readlen, u32 kMinReadLen) {
   const double min_frac = 1.0 - 0.4;  // src/abismal.cpp:307-314
   return aln_len >= max(kMinReadLen, static_cast<u32>(min_frac * readlen));
 }
@@ -1290,7 +1315,7 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
 
 // align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
 __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
-                                          SeSet &S, Hit &best, u32 *cig_out, u32 cig_stride,
+                                          SeSet &S, Hit &best, u32 *cig_out, const CigarSink &sink,
                                           u32 &n_ops, bool &overflow, u32 &n_aln) {
   const int lane = lane_id();
   const int Ls = static_cast<i16>(L);
@@ -1382,12 +1407,12 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   __syncthreads();
   u32 alen = 0, pos = b_pos;
   int n_ins = 0, n_del = 0;
-  wave_cigar(lds.tb, lds.ctmp, static_cast<int>(L), b_diffs, md, sc, br, bc, cig_out, cig_stride, n_ops,
+  wave_cigar(lds.tb, lds.ctmp, static_cast<int>(L), b_diffs, md, sc, br, bc, cig_out, sink, n_ops,
              n_ins, n_del, alen, pos, overflow);
   __syncthreads();
   // NM from the score found by the scoring pass (best_scr), as the reference does
   const int nm = edit_distance(top, alen, n_ins, n_del);
-  if (long_enough(alen, static_cast<u32>(Ls)) && nm <= md) {
+  if (long_enough(alen, static_cast<u32>(Ls), ix.min_len) && nm <= md) {
     best.diffs = static_cast<i16>(nm);
     best.pos = pos;
   }

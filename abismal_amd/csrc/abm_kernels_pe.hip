@@ -280,6 +280,7 @@ template <bool BIG> struct PeWave {
     return w;
   }
   __device__ __forceinline__ u32 *cig_of(int end, u64 r) const { return (end ? a.cig2 : a.cig1) + r * a.cig_stride; }
+  __device__ __forceinline__ CigarSink sink() const { return CigarSink{a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap}; }
 
   // ---- one end of one orientation call: both seed passes, then freeze the set ----
   template <bool TIMED> __device__ __forceinline__ void seed_end(int which, int end, bool rc, bool ar) {
@@ -291,7 +292,7 @@ template <bool BIG> struct PeWave {
     P.lpos = pl.lpos[which];
     P.ld = pl.ld[which];
     P.begin_read(L[end]);
-    if (L[end] >= kMinReadLen) {
+    if (L[end] >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
       seed_pass<true, TIMED, ABM_PE_COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       if (!P.overflow && P.wants_sensitive()) {
@@ -529,7 +530,7 @@ template <bool BIG> struct PeWave {
       const int bc = static_cast<int>(0xFFu - static_cast<u32>(topk & 0xFFu));
       const int sc = static_cast<i16>(static_cast<int>(topk >> 32));
       __syncthreads();
-      wave_cigar(lds.tb, lds.ctmp, Ln, d, md, sc, br, bc, cig_out, a.cig_stride, nops, n_ins, n_del, alen, pos,
+      wave_cigar(lds.tb, lds.ctmp, Ln, d, md, sc, br, bc, cig_out, sink(), nops, n_ins, n_del, alen, pos,
                  overflow);
       __syncthreads();
     }
@@ -703,7 +704,7 @@ template <bool BIG> struct PeWave {
   // map_fragments + select_maps + best_single (:1715-1720, :1833-1885)
   template <bool TIMED, int O> __device__ __forceinline__ bool orientation(int endA, bool ar, u64 r, PairBest &best) {
     const int endB = 1 - endA;
-    const bool emptyA = L[endA] < kMinReadLen, emptyB = L[endB] < kMinReadLen;
+    const bool emptyA = L[endA] < a.ix.min_len, emptyB = L[endB] < a.ix.min_len;
     if (emptyA && emptyB) {
       // res1/res2 are reset and nothing else happens (:1863-1866)
       return false;
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
   lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
   lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
-  lds.jpos = lds.ctmp + a.cig_stride;
+  lds.jpos = lds.ctmp + a.ctmp_cap;
   lds.jdf = lds.jpos + kSeCap;
   w.pl.jidx = lds.jdf + kSeCap;
   lds.lbest = reinterpret_cast<int *>(w.pl.jidx + kSeCap);
@@ -845,14 +846,14 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     __syncthreads();
     #pragma unroll
     for (int e = 0; e < 2; ++e)  // 44-46 bases: seeds reach past the end of the read (see ghost_bits)
-      if (w.L[e] >= kMinReadLen && w.L[e] < max(kWindow, w.L[e] >> 1) + kKeyWeight - 1)
-        ghost_bits(e ? a.packed2 : a.packed1, e ? a.lens2 : a.lens1, r, w.L[e], a.max_len, a.W, a.WB, lds.qbits + e * 4 * a.WB);
+      if (w.L[e] >= a.ix.min_len && w.L[e] < max(a.ix.window, w.L[e] >> 1) + kKeyWeight - 1)
+        ghost_bits(e ? a.packed2 : a.packed1, e ? a.lens2 : a.lens1, r, w.L[e], a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits + e * 4 * a.WB);
 
     PairBest best;
     best.f1 = best.f2 = 0;
-    best.clear(w.L[0] >= kMinReadLen ? w.L[0] : 0u, w.L[1] >= kMinReadLen ? w.L[1] : 0u);
-    w.se[0].begin_read(w.L[0] >= kMinReadLen ? w.L[0] : 0u);
-    w.se[1].begin_read(w.L[1] >= kMinReadLen ? w.L[1] : 0u);
+    best.clear(w.L[0] >= a.ix.min_len ? w.L[0] : 0u, w.L[1] >= a.ix.min_len ? w.L[1] : 0u);
+    w.se[0].begin_read(w.L[0] >= a.ix.min_len ? w.L[0] : 0u);
+    w.se[1].begin_read(w.L[1] >= a.ix.min_len ? w.L[1] : 0u);
     w.need_big = false;
     if (BIG && lane < 8) w.log_head(lane)[0] = 0;  // no list logged yet for this pair
     w.max_set = 0;
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     }
     {  // valid_pair, :624-631, on whatever CIGARs the mating left behind
       const u32 a1 = w.ref_len[0], a2 = w.ref_len[1];
-      const bool ok = long_enough(a1, w.L[0]) && long_enough(a2, w.L[1]) &&
+      const bool ok = long_enough(a1, w.L[0], a.ix.min_len) && long_enough(a2, w.L[1], a.ix.min_len) &&
                       static_cast<i16>(best.d1 + best.d2) <= static_cast<i16>(a.valid_frac * (a1 + a2));
       if (!ok) best.clear();
     }
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
         const WaveLds we = w.lds_of(e);
         u32 nops = 0;
         Hit &h = e ? h2 : h1;
-        choose_se(a.ix, we, w.L[e], a.valid_frac / 2, w.se[e], h, w.cig_of(e, r), a.cig_stride, nops,
+        choose_se(a.ix, we, w.L[e], a.valid_frac / 2, w.se[e], h, w.cig_of(e, r), w.sink(), nops,
                   w.overflow, w.n_aln);
         if (h.pos != 0 || w.se[e].best_p != 0) w.n_ops[e] = nops;
       }

@@ -63,6 +63,12 @@ int abm_index_build(const char *fasta_path, const char *out_path, uint32_t n_thr
 /* `abismal idx -A <targets> ...` (AbismalIndex::create_index(targets, genome), src/AbismalIndex.cpp:206-279):
  * only the regions listed in targets_path ("chrom start end" per line) are indexed; NULL or "" = whole genome. */
 int abm_index_build_targets(const char *fasta_path, const char *targets_path, const char *out_path, uint32_t n_threads);
+/* The same with the seed window chosen: 20 (default) or 12, the reference's --enable-short build for short reads
+ * (configure.ac:70-73, src/AbismalIndex.hpp:73-77: shortest mappable read 36 instead of 44 bases).  The window is
+ * stored in the index file; abm_index_open takes either and the mapping entry points follow it. */
+int abm_index_build_opts(const char *fasta_path, const char *targets_path, uint32_t window, const char *out_path,
+                         uint32_t n_threads);
+uint32_t abm_index_window(const abm_index *ix);
 
 /* A context = one host thread's workspaces and stream on `device` (hipSetDevice
  * ordinal).  The first context on a device replicates the index into its HBM;
@@ -91,11 +97,12 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
 /* Same computation with every buffer already resident in HBM (d_* are device
  * pointers), enqueued on `stream` (a hipStream_t; NULL = default stream) and
  * not synchronised.  CIGARs land in fixed slots of cig_stride ops per read,
- * their op counts in d_cig_n.  A count above cig_stride (ABM_STATUS_CIGAR_OVERFLOW
- * is then set) means the slot is incomplete: the hit itself is exact, and mapping
- * that read again with cig_stride >= max_len + 2 yields its CIGAR, which is what
- * the host-buffer entry points do.  d_status (one uint32) is OR-ed with
- * ABM_STATUS_* bits. max_len = longest read in the batch.
+ * their op counts in d_cig_n.  A CIGAR with more ops than cig_stride (its count
+ * says so) lies whole in the context's arena instead, beginning at the index its
+ * slot's first word holds; abm_ctx_long_cigars() returns the arena of the last
+ * call.  ABM_STATUS_CIGAR_OVERFLOW is only set if the arena itself ran out (one op
+ * per read by default), in which case such slots hold what fitted.  d_status (one
+ * uint32) is OR-ed with ABM_STATUS_* bits. max_len = longest read in the batch.
  * A context owns ONE set of workspaces: a device call first makes `stream` wait
  * for the context's previous device call (on whatever stream that ran), so calls
  * on one context execute one after the other; use one context per stream to
@@ -123,8 +130,11 @@ int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t
                       uint32_t cig_stride, uint32_t *d_cig_n1, uint32_t *d_cig_n2,
                       uint32_t *d_status, void *stream);
 
+/* the arena of CIGARs longer than their slot left by the context's last device call (waits for it) */
+int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint64_t *n_ops);
+
 enum {
-  ABM_STATUS_CIGAR_OVERFLOW = 1u, /* a CIGAR needed more than cig_stride ops */
+  ABM_STATUS_CIGAR_OVERFLOW = 1u, /* the arena for CIGARs longer than a slot ran out */
   ABM_STATUS_READ_TOO_LONG = 2u,  /* a read exceeded the kernel's length cap */
   ABM_STATUS_SET_OVERFLOW = 4u,   /* PE candidate set outgrew its workspace */
   ABM_STATUS_HELP_TIMEOUT = 8u,   /* a wave waited too long for chunks handed to idle waves (results invalid) */

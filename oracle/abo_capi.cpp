@@ -34,6 +34,9 @@ const char *abo_last_error() { return g_err.c_str(); }
 int abo_index_build_targets(const char *fasta, const char *targets, const char *out, unsigned threads) {
   return guarded([&] { Index ix; ix.build_from_fasta(fasta, threads, targets ? targets : ""); ix.write(out); });
 }
+int abo_index_build_opts(const char *fasta, const char *targets, unsigned window, const char *out, unsigned threads) {
+  return guarded([&] { Index ix; ix.build_from_fasta(fasta, threads, targets ? targets : "", window); ix.write(out); });
+}
 int abo_index_build(const char *fasta, const char *out, unsigned threads) {
   return guarded([&] { Index ix; ix.build_from_fasta(fasta, threads); ix.write(out); });
 }

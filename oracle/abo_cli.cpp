@@ -27,7 +27,8 @@ struct FastqReader {
   std::string path;
   u64 line_no = 0;
   bool alive = true;
-  explicit FastqReader(const std::string &p) : in(p), path(p) {
+  u32 min_len = kMinReadLen;  // fewer informative bases: the read is skipped (src/abismal.cpp:187-195, :212-213)
+  explicit FastqReader(const std::string &p, u32 min_read_len = kMinReadLen) : in(p), path(p), min_len(min_read_len) {
     if (!in)
       throw std::runtime_error("cannot open reads file: " + p);
   }
@@ -52,7 +53,7 @@ struct FastqReader {
                                    std::to_string(kPadding));
         const auto informative =
           std::count_if(line.begin(), line.end(), [](char c) { return c != 'N'; });
-        if (informative < static_cast<std::ptrdiff_t>(kMinReadLen))
+        if (informative < static_cast<std::ptrdiff_t>(min_len))
           line.clear();
         else {
           while (line.back() == 'N') line.pop_back();
@@ -251,10 +252,11 @@ Args parse(int argc, char **argv, const std::string &with_value) {
 }
 
 int cmd_idx(int argc, char **argv) {
-  Args a = parse(argc, argv, ",t,threads,A,targets,");
+  Args a = parse(argc, argv, ",t,threads,A,targets,w,window,");
   if (a.pos.size() != 2) { std::cerr << "usage: idx [-t n] <genome.fa> <out.idx>\n"; return 1; }
   Index ix;
-  ix.build_from_fasta(a.pos[0], static_cast<unsigned>(std::stoul(a.get("t", a.get("threads", "1")))), a.get("A", a.get("targets")));
+  ix.build_from_fasta(a.pos[0], static_cast<unsigned>(std::stoul(a.get("t", a.get("threads", "1")))), a.get("A", a.get("targets")),
+                      static_cast<u32>(std::stoul(a.get("w", a.get("window", "20")))));
   ix.write(a.pos[1]);
   return 0;
 }
@@ -323,7 +325,7 @@ int cmd_map(int argc, char **argv) {
   const unsigned n_threads = std::max(1u, static_cast<unsigned>(std::stoul(a.get("t", a.get("threads", "1")))));
   if (!paired) {
     const SeMode mode = rpbat ? SE_RANDOM : ((arich || pbat) ? SE_A_RICH : SE_T_RICH);
-    FastqReader rd(a.pos[0]);
+    FastqReader rd(a.pos[0], ix.min_read_len());
     const std::size_t batch = n_threads > 1 ? 4096u * n_threads : kBatch;
     std::vector<std::unique_ptr<Mapper>> mappers;
     for (unsigned t = 0; t < n_threads; ++t) mappers.emplace_back(new Mapper(ix, par));
@@ -380,7 +382,7 @@ int cmd_map(int argc, char **argv) {
   }
   else {
     const PeMode mode = rpbat ? PE_RANDOM : (pbat ? PE_PBAT : PE_NORMAL);
-    FastqReader rd1(a.pos[0]), rd2(a.pos[1]);
+    FastqReader rd1(a.pos[0], ix.min_read_len()), rd2(a.pos[1], ix.min_read_len());
     Cigar c1, c2;
     while (rd1.alive && rd2.alive) {
       rd1.load(kBatch, n1, s1);

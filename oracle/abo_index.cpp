@@ -91,7 +91,7 @@ void Index::write(const std::string &path) const {
   File o(path, "wb");
   o.put(kMagic, 12);
   o.put(kKeyWeight);
-  o.put(kWindow);
+  o.put(window);
   o.put(kSortDepth);
   const u32 n_chroms = static_cast<u32>(chroms.names.size());
   o.put(n_chroms);
@@ -126,8 +126,9 @@ void Index::read(const std::string &path) {
   if (kw != kKeyWeight)
     throw std::runtime_error("inconsistent k-mer size. Expected: 25, got: " + std::to_string(kw));
   in.get(ws);
-  if (ws != kWindow)
+  if (ws != 20 && ws != 12)  // (a reference binary accepts only the value it was compiled with)
     throw std::runtime_error("inconsistent window size size. Expected: 20, got: " + std::to_string(ws));
+  window = ws;
   in.get(sd);
   if (sd != kSortDepth)
     throw std::runtime_error("inconsistent sorting size size. Expected: 256, got: " + std::to_string(sd));
@@ -283,7 +284,11 @@ static void keep_only_targets(const std::string &path, const ChromTable &ct, std
   }
 }
 
-void Index::build_from_fasta(const std::string &fasta, unsigned n_threads, const std::string &targets) {
+void Index::build_from_fasta(const std::string &fasta, unsigned n_threads, const std::string &targets, u32 window_size) {
+  if (window_size != 20 && window_size != 12)
+    throw std::runtime_error("window size must be 20 or 12 (--enable-short)");
+  window = window_size;
+  const u64 kWindow = window;  // (shadows the default: everything below follows this index's window)
   std::string text;
   load_fasta_padded(fasta, text, chroms);
   if (!targets.empty())

@@ -283,7 +283,7 @@ i16 edit_distance(i16 scr, u32 len, const Cigar &cig) {
 }
 
 inline i16 max_diffs_for(u32 readlen, double frac) { return static_cast<i16>(frac * readlen); }
-inline bool long_enough(u32 aln_len, u32 readlen) {
+inline bool long_enough(u32 aln_len, u32 readlen, u32 kMinReadLen) {
   static const double min_frac = 1.0 - 0.4;
   return aln_len >= std::max(kMinReadLen, static_cast<u32>(min_frac * readlen));
 }
@@ -413,8 +413,8 @@ struct Mapper::Impl {
     u32 k2, k3;
     keys_at_0(k2, k3);
 
-    const u32 spec_len = std::min(L - kWindow, L >> 1);
-    const u32 spec_lim = std::max(kWindow, L >> 1);
+    const u32 spec_len = std::min(L - ix.window, L >> 1);
+    const u32 spec_lim = std::max(ix.window, L >> 1);
     S.enter_specific();
     for (u32 i = 0; i < spec_lim && !S.sure_ambig; ++i) {
       ++work.seed_iters;
@@ -488,7 +488,7 @@ struct Mapper::Impl {
     u32 alen = 0;
     aln.cigar_from_last(best.diffs, md, cig, alen, best.pos);
     best.diffs = edit_distance(top, alen, cig);
-    if (!(long_enough(alen, static_cast<u32>(L)) && best.diffs <= max_diffs_for(static_cast<u32>(L), frac)))
+    if (!(long_enough(alen, static_cast<u32>(L), ix.min_read_len()) && best.diffs <= max_diffs_for(static_cast<u32>(L), frac)))
       best.clear();
   }
 
@@ -676,7 +676,7 @@ void Mapper::map_pe(const std::string &r1, const std::string &r2, PeMode mode, P
   // valid_pair: src/abismal.cpp:624-631
   {
     const u32 a1 = cigar_ref_len(cig1), a2 = cigar_ref_len(cig2);
-    const bool ok = long_enough(a1, l1) && long_enough(a2, l2) &&
+    const bool ok = long_enough(a1, l1, m->ix.min_read_len()) && long_enough(a2, l2, m->ix.min_read_len()) &&
                     best.diffs() <= static_cast<i16>(m->par.valid_frac * (a1 + a2));
     if (!ok)
       best.clear();

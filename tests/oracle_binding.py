@@ -55,10 +55,10 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle: " + self.lib.abo_last_error().decode())
 
-    def index_build(self, fasta, out, threads=1, targets=None):
-        if targets:
-            self.lib.abo_index_build_targets.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint]
-            self._chk(self.lib.abo_index_build_targets(os.fsencode(fasta), os.fsencode(targets), os.fsencode(out), threads))
+    def index_build(self, fasta, out, threads=1, targets=None, window=20):
+        if targets or window != 20:
+            self.lib.abo_index_build_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
+            self._chk(self.lib.abo_index_build_opts(os.fsencode(fasta), os.fsencode(targets or ""), window, os.fsencode(out), threads))
         else:
             self._chk(self.lib.abo_index_build(os.fsencode(fasta), os.fsencode(out), threads))
 

@@ -144,6 +144,38 @@ def test_device_entry_point_matches_host_entry_point(ctx, reads):
     assert [tuple(dc[i, :cn[i]].tolist()) for i in range(n)] == cigars(cig, off)
 
 
+def test_long_cigars_come_back_through_the_arena(ctx, reads):
+    """Device entry point with 2-op slots: every CIGAR with more ops lies whole in the context's arena, at the
+    index its slot's first word holds (abm_ctx_long_cigars) -- nothing is truncated, nothing is mapped twice."""
+    import torch
+    import abismal_amd as A
+    base = [r for r in reads[:6000] if len(r) == 100]
+    res, cig, off = ctx.map_se(base)
+    want = cigars(cig, off)
+    dev = torch.device("cuda", 0)
+    n, L, stride = len(base), 100, 2
+    blob = torch.tensor(np.frombuffer("".join(base).encode(), dtype=np.uint8), device=dev)
+    offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    d_res = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    d_cig = torch.zeros((n, stride), dtype=torch.int32, device=dev)
+    d_n = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.map_se_device(A.SE_T_RICH, A.Params(), n, blob.data_ptr(), offs.data_ptr(), L, d_res.data_ptr(),
+                      d_cig.data_ptr(), stride, d_n.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(d_st.item()) == 0
+    arena = ctx.long_cigars()
+    cn = d_n.cpu().numpy()
+    dc = d_cig.cpu().numpy().view(np.uint32)
+    got = []
+    for i in range(n):
+        k = int(cn[i])
+        got.append(tuple(dc[i, :k].tolist()) if k <= stride else tuple(arena[int(dc[i, 0]):int(dc[i, 0]) + k].tolist()))
+    assert got == want
+    # (the arena may also hold CIGARs of reads whose alignment was discarded afterwards)
+    assert sum(1 for c in want if len(c) > stride) > 100 and len(arena) >= sum(len(c) for c in want if len(c) > stride)
+
+
 def test_small_cigar_capacity_is_reported_not_overrun(ctx, reads):
     """abm_map_se_batch with too little room for the CIGARs returns ABM_ERR_CAPACITY (-2) and the
     same call with enough room succeeds (the CLI relies on this to start with a small buffer)."""

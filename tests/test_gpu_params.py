@@ -109,3 +109,40 @@ def test_cli_pe_flags_vs_oracle_cli(oracle, rep, flags):
         outs[who] = ([ln for ln in open(sam) if not ln.startswith("@PG")], open(st).read())
     assert outs["gpu"][0] == outs["oracle"][0], f"SAM differs with {flags}"
     assert outs["gpu"][1] == outs["oracle"][1], f"statistics differ with {flags}"
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_short_read_index(oracle, rep, mode):
+    """An index built with window 12 (the reference's --enable-short): reads from 36 bases on are mapped,
+    the specific-pass limits follow the window (src/abismal.cpp:212-213, :1302-1305), results == oracle --
+    including the reads short enough to hash past their end (36-38 bases here)."""
+    import numpy as np
+    import abismal_amd as A
+    from tests import synth
+    from tests.test_gpu_se_parity import compare_se
+    from tests.test_gpu_pe_parity import compare_pe
+    idx = str(rep["wd"] / "rep12.idx")
+    if not os.path.exists(idx):
+        A.index_build(rep["fa"], idx, 8, window=12)
+    rng = np.random.default_rng(5 + mode)
+    long_reads = synth.trim_like_readloader(synth.mutated_reads(rep["fa"], 5000, 100, seed=21, mut=0.02, pbat_frac=0.5 if mode else 0.0))
+    reads = []
+    for r in long_reads:
+        if len(r) >= 60 and rng.random() < 0.8:
+            r = r[: int(rng.integers(30, 61))]
+        reads.append(r if len(r) >= 36 else "")
+    ix = A.Index(idx)
+    ctx = A.Context(ix, 0)
+    oix = oracle.index_load(idx)
+    try:
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, mode=mode, threads=1)
+        res, cig, off = ctx.map_se(reads, mode=mode)
+        compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"window-12 index, mode {mode}")
+        short = [i for i, r in enumerate(reads) if 36 <= len(r) < 44]
+        assert len(short) > 300 and sum(1 for i in short if res[i]["pos"] != 0) > 100, "reads below 44 bases must map with this index"
+        r1, r2 = reads[:2000], reads[2000:4000]
+        compare_pe(ctx.map_pe(r1, r2, mode=mode), oracle.map_pe(oix, r1, r2, mode=mode, threads=1), "window-12 pairs")
+    finally:
+        oracle.index_free(oix)
+        ctx.close()
+        ix.close()

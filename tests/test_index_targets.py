@@ -51,3 +51,23 @@ def test_unsorted_targets_are_rejected(oracle, tmp_path):
     tf.write_text(f"{c1}\t5000\n")
     with pytest.raises(A.AbismalAmdError, match="failed parsing target region"):
         A.index_build(FA, str(tmp_path / "p.idx"), 2, targets=str(tf))
+
+
+def test_short_read_index_equals_oracle(oracle, tmp_path):
+    """Window 12 (the reference's --enable-short build, src/AbismalIndex.hpp:73-77): product builder == oracle
+    builder, the file says 12, and both loaders take it."""
+    import struct
+    import abismal_amd as A
+    A.index_build(FA, str(tmp_path / "p12.idx"), 5, window=12)
+    oracle.index_build(FA, str(tmp_path / "o12.idx"), threads=1, window=12)
+    assert md5(tmp_path / "p12.idx") == md5(tmp_path / "o12.idx")
+    with open(tmp_path / "p12.idx", "rb") as f:
+        assert f.read(12) == b"AbismalIndex" and struct.unpack("<3I", f.read(12)) == (25, 12, 256)
+    ix = A.Index(str(tmp_path / "p12.idx"))
+    assert ix.window == 12
+    ix.close()
+    oix = oracle.index_load(str(tmp_path / "o12.idx"))
+    oracle.index_free(oix)
+    # more positions are kept than with window 20 (a denser selection)
+    A.index_build(FA, str(tmp_path / "p20.idx"), 5)
+    assert os.path.getsize(tmp_path / "p12.idx") > os.path.getsize(tmp_path / "p20.idx")

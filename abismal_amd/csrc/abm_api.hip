@@ -127,6 +127,7 @@ struct abm_ctx {
   DevBuf<unsigned long long> next_read;
   DevBuf<abm::u32> cig_arena, cig_arena_count;  // CIGARs longer than a slot (CigarSink)
   size_t arena_want = 0;                        // arena size the host entry points ask for (0 = default)
+  uint64_t too_long = 0;                        // reads (pairs) beyond kMaxReadLen seen by the host entry points
   HostBuf<abm::u32> h_cn, h_slots, h_arena, h_cn2, h_slots2;
   DevBuf<char> help_ws;  // tail-help workspace of the single-end kernel (see HelpArgs)
   unsigned launch_seq = 0;
@@ -474,6 +475,7 @@ void abm_default_params(abm_params *p) {
 }
 
 uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
+uint64_t abm_ctx_reads_too_long(abm_ctx *ctx) { return ctx ? ctx->too_long : 0; }
 
 int abm_index_open(const char *path, abm_index **out) {
   return guarded([&] {
@@ -724,9 +726,9 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       if (seq_off[i + 1] < seq_off[i]) throw std::invalid_argument("seq_off not monotone");
       max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off[i + 1] - seq_off[i]));
     }
-    if (max_len > abm::kMaxReadLen)
-      throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
-                                  std::to_string(abm::kMaxReadLen));
+    // reads beyond the kernels' length cap are not mapped (the reference takes reads below 32767 bases); they come
+    // back without a hit and are counted (abm_ctx_reads_too_long), the rest of the batch is unaffected
+    for (uint64_t i = 0; i < n; ++i) ctx->too_long += (seq_off[i + 1] - seq_off[i]) > abm::kMaxReadLen;
     // one pass: upload, map, hits + compact CIGARs back
     auto run = [&](uint64_t m, const char *blob, uint64_t nbytes, const uint64_t *offs, uint32_t stride, bool take_turn) {
       ctx->blob.reserve(std::max<uint64_t>(nbytes, 1));
@@ -760,7 +762,7 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
         HIPCHK(hipStreamSynchronize(st));
         t2.mark("  map: tail");
       }
-      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW))
+      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW | ABM_STATUS_READ_TOO_LONG))
         throw std::runtime_error("kernel reported status " + std::to_string(status));
       return status;
     };
@@ -829,9 +831,8 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off1[i + 1] - seq_off1[i]));
       max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off2[i + 1] - seq_off2[i]));
     }
-    if (max_len > abm::kMaxReadLen)
-      throw std::invalid_argument("read of " + std::to_string(max_len) + " bases exceeds the kernel cap of " +
-                                  std::to_string(abm::kMaxReadLen));
+    for (uint64_t i = 0; i < n; ++i)
+      ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kMaxReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kMaxReadLen;
     abm_pair *d_pair = nullptr;
     abm_hit *d_se1 = nullptr, *d_se2 = nullptr;
     auto run = [&](uint64_t m, const char *b1, uint64_t nb1, const uint64_t *o1, const char *b2, uint64_t nb2,
@@ -864,7 +865,7 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       uint32_t status = 0;
       HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW))
+      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW | ABM_STATUS_READ_TOO_LONG))
         throw std::runtime_error("kernel reported status " + std::to_string(status));
       return status;
     };

@@ -1368,6 +1368,13 @@ int cmd_map(int argc, char **argv) {
               << "[abismal-amd] busy seconds: split " << busy_split << ", parse " << busy_parse << " (" << n_host
               << " threads), map " << busy_map << " (" << n_gpus * per_gpu << " threads), format " << busy_format << " ("
               << n_host << " threads), write " << busy_write << "\n";
+  {
+    uint64_t too_long = 0;
+    for (abm_ctx *c : ctxs) too_long += abm_ctx_reads_too_long(c);
+    if (too_long)
+      std::cerr << "[abismal-amd] warning: " << too_long << (paired ? " pairs" : " reads") << " longer than " << abm_max_read_length()
+                << " bases were not mapped (reported as unmapped)\n";
+  }
   for (abm_ctx *c : ctxs) abm_ctx_destroy(c);
   abm_index_close(ix);
   return EXIT_SUCCESS;

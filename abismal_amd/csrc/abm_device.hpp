@@ -22,7 +22,7 @@ constexpr u32 kKeyWeight3 = 16;  // src/AbismalIndex.hpp:69
 constexpr u32 kWindow = 20;      // src/AbismalIndex.hpp:76 (12 in a short-read index: DevIndex::window)
 constexpr u32 kHashMod3 = 43046721u;
 constexpr u32 kMinReadLen = 44;  // src/abismal.cpp:212-213
-constexpr u32 kMaxReadLen = 512; // kernel cap (LDS-resident traceback)
+constexpr u32 kMaxReadLen = 1024; // kernel cap (LDS-resident traceback: (L + 61) x 61 bytes per wave)
 constexpr u32 kMaxBand = 61;     // src/AbismalAlign.hpp:108,133
 constexpr u32 kSeCap = 50;       // src/abismal.cpp:448
 constexpr u32 kPeCapSmall = 32, kPeCapLarge = 32u << 10;  // src/abismal.cpp:861-862

@@ -1416,8 +1416,8 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
     best.diffs = static_cast<i16>(nm);
     best.pos = pos;
   }
-  else
-    n_ops = 0;
+  // (a hit that fails here leaves best.pos == 0; n_ops still counts the CIGAR the traceback wrote into the slot,
+  // like the reference's r.cig, so that count and slot -- or arena reference -- always belong together)
 }
 
 

@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
         Hit &h = e ? h2 : h1;
         choose_se(a.ix, we, w.L[e], a.valid_frac / 2, w.se[e], h, w.cig_of(e, r), w.sink(), nops,
                   w.overflow, w.n_aln);
-        if (h.pos != 0 || w.se[e].best_p != 0) w.n_ops[e] = nops;
+        if (nops != 0) w.n_ops[e] = nops;  // whatever traceback ran last owns the slot (A.10)
       }
       ABM_STAMP(tf1);
       if (TIMED) t_fb += tf1 - tf0;

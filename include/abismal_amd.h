@@ -140,7 +140,10 @@ enum {
   ABM_STATUS_HELP_TIMEOUT = 8u,   /* a wave waited too long for chunks handed to idle waves (results invalid) */
   ABM_STATUS_HELP_MISMATCH = 16u  /* self-check build only: a handed-off result differed from the owner's own */
 };
-uint32_t abm_max_read_length(void); /* longest read the kernels accept */
+uint32_t abm_max_read_length(void); /* longest read the kernels map (the reference: below 32767 bases) */
+/* Reads (pairs) longer than that handed to this context's host entry points so far: they come back without a hit,
+ * everything else in their batch is mapped as usual. */
+uint64_t abm_ctx_reads_too_long(abm_ctx *ctx);
 
 /* Measurement hook (no reference counterpart): exact work tallies accumulated
  * by every launch on this context since the previous call, then reset:

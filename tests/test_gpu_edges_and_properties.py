@@ -40,10 +40,35 @@ def test_empty_batch_and_all_skipped(ctx):
     assert (pairs["r1"]["pos"] == 0).all() and (se1["pos"] == 0).all() and (se2["pos"] == 0).all()
 
 
-def test_too_long_read_is_rejected_loudly(ctx):
+def test_long_reads(ctx, oracle, trex_index):
+    """Reads up to the kernels' cap (1024 bases) map like any other; a longer one comes back unmapped and
+    counted, without disturbing its batch (the reference takes reads below 32767 bases)."""
     import abismal_amd as A
-    with pytest.raises(A.AbismalAmdError, match="exceeds the kernel cap"):
-        ctx.map_se(["ACGT" * 200])
+    import bench
+    from tests.test_gpu_se_parity import compare_se
+    names, starts, gw = bench.read_index_genome(trex_index)
+    dec = np.frombuffer(b"NACNGNNNTNNNNNNN", dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    reads = []
+    for L in (300, 513, 800, 1024, 1024, 700, 100, 1500, 1025, 64):
+        p = int(rng.integers(int(starts[1]) + 20000, int(starts[2]) - 3000))
+        idx = np.arange(p, p + L)
+        s = dec[(gw[idx >> 4] >> ((idx & 15).astype(np.uint64) << np.uint64(2))) & np.uint64(15)].copy()
+        s[s == ord("C")] = ord("T")
+        mut = rng.random(L) < 0.02
+        s[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+        reads.append(bytes(s).decode().replace("N", "A"))
+    before = ctx.reads_too_long()
+    res, cig, off = ctx.map_se(reads)
+    assert ctx.reads_too_long() - before == 2
+    oix = oracle.index_load(trex_index)
+    try:
+        keep = [r if len(r) <= A.load_library().abm_max_read_length() else "" for r in reads]
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, keep, threads=1)
+    finally:
+        oracle.index_free(oix)
+    compare_se(res, cig, off, o_res, o_cig, o_n, keep, "long reads")
+    assert res["pos"][7] == 0 and res["pos"][8] == 0 and (res["pos"][:7] != 0).sum() >= 5
     with pytest.raises(A.AbismalAmdError):
         ctx.map_se(["ACGT" * 30], mode=7)
 

@@ -25,11 +25,12 @@ nbytes = cnt["TCC_EA0_RDREQ_128B_sum"] * 128 + cnt["TCC_EA0_RDREQ_64B_sum"] * 64
 traffic = {"round": rnd, "kernel": "map_se_kernel",
            "workload": {"genome_mbp": 3100, "reads": wl["reads_per_step_per_gpu"], "read_len": wl["read_len"]},
            "counters": cnt, "hbm_read_bytes_per_launch": nbytes, "kernel_seconds_under_pmc": secs,
+           "build": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % root).read().strip() or "n/a",
            "note": "rocprofv3 --pmc TCC_EA0_RDREQ_{,32B,64B,128B}_sum in a pass of its own over `python3 bench.py --steps 1 "
                    "--warmup 0 --no-cpu-baseline` (scripts/profile_round.sh; rows in %s_pmc_rdreq_map_se.csv). Essentially every "
                    "L2->HBM read request of this kernel is a 128-B line; an earlier FETCH_SIZE pass reported requests x 64 B, "
                    "i.e. exactly half, as MI355X_MICROARCH.md says for gfx950. Write traffic is negligible (8 B + CIGAR slot "
-                   "per read)." % tag}
+                   "per read).  TCC_EA0_RDREQ counts Infinity-Cache hits as well: fabric-side requests, an upper bound on HBM bytes." % tag}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv"))))[:6]
 calls_note = ""
@@ -45,19 +46,43 @@ if os.path.exists(cpath):
                       f"launches average {sum(timed) / len(timed):.1f} ms in the rocprofv3 trace.")
 rf, cb = line["roofline"], line["cpu_baseline"]
 with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
-    f.write(f"# Round {rnd} profiles\n\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py` (default flags: 3100 Mbp "
-            "synthetic hg38-shaped genome, 10 M reads x 100 bp per step, a different batch every step, 3 steps + 1 warm-up) on one "
-            "MI355X; commands in `scripts/profile_round.sh`.\n\n| kernel | calls | avg ms | % |\n|---|---|---|---|\n")
+    f.write(f"# Round {rnd} profiles\n\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-e2e` (3100 Mbp "
+            "synthetic hg38-shaped genome, 10 M reads x 100 bp per step, a different batch every step, 3 steps + 1 warm-up; the "
+            "end-to-end leg runs the CLI as a child process and is kept out of the profiled run) on one MI355X; commands in "
+            "`scripts/profile_round.sh`, this file written by `scripts/install_profiles.py`.\n\n| kernel | calls | avg ms | % |\n|---|---|---|---|\n")
     for r in rows:
         f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {r['Percentage']} |\n")
     f.write(f"\nbench.py's own line from that run (`{tag}_bench_line_under_rocprof.json`): value {line['value']:.0f} reads/s, HIP-event "
-            f"average of map_se_kernel {rf['avg_kernel_ms']} ms (compare the rocprofv3 average above), algorithmic {rf['achieved']} GB/s = "
-            f"{rf['frac']} of 8 TB/s, cpu_baseline {cb['value']} reads/s on {cb['cores']} threads ({cb['positions_identical_to_gpu']} "
-            "positions identical)." + calls_note + "\n\n"
-            f"HBM traffic (`{tag}_traffic.json`, separate `--pmc` pass, `{tag}_pmc_rdreq_map_se.csv`): {nbytes / 1e12:.2f} TB of 128-byte "
-            f"line reads per launch = {nbytes / secs / 1e12:.2f} TB/s during the kernel ({secs * 1e3:.0f} ms under the counters).\n\n"
-            "Work per read in that run: " + ", ".join(f"{k} {v}" for k, v in line["work_per_read"].items()) + ".\n\n"
-            "Hardware probes used for the roofline discussion (`tests/hip/*.hip`, run by hand): random 8-byte gathers 56 G/s, random "
-            "72-byte windows 37.6 G/s over 1.5 GB; a flag stored by a running kernel to pinned host memory is seen by the host "
-            "within 0.03-0.4 ms (`flag_probe.hip`).\n")
+            f"average of map_se_kernel {rf['avg_kernel_ms']} ms (compare the rocprofv3 average above)." + calls_note + "\n\n")
+    f.write("## Recomputing the roofline line\n\n"
+            "`roofline.achieved = alg_bytes_per_read x reads per launch / avg_kernel_ms`, `frac = achieved / 8000 GB/s`, with\n"
+            "`alg_bytes_per_read = L + S*16 + P*4.5 + C*4 + (W + C)*8 + A*(L + bw)/2 + 8*(1 + ops/2)` (SURVEY.md 8d; L = 100, bw = 21).\n\n"
+            "| basis | S | P | C | W | A | ops | bytes/read | GB/s | frac |\n|---|---|---|---|---|---|---|---|---|---|\n")
+    sc = rf.get("strict_counts_per_read") or {}
+    n_reads = line["config"]["reads_per_step_per_gpu"]
+    if sc:
+        f.write(f"| strict (oracle counters on the cpu_baseline sample: reference algorithm, early-exit full_compare) | {sc['S']} | {sc['P']} | "
+                f"{sc['C']} | {sc['W']} | {sc['A']} | {sc['ops']} | {rf['alg_bytes_per_read_strict']} | "
+                f"{rf['alg_bytes_per_read_strict'] * n_reads / rf['avg_kernel_ms'] / 1e6:.1f} | {rf['frac_strict']} |\n")
+    wp = line["work_per_read"]
+    f.write(f"| kernel tally (what the kernel did: full windows, position-cache hits not fetched) | {wp['seed_offsets']} | {wp['search_probes']} | "
+            f"{wp['candidates']} | {wp['read_words']} (of which {wp['window_cache_hits']} candidates cached) | {wp['alignments']} | - | "
+            f"{rf['alg_bytes_per_read_kernel_tally']} | {rf['alg_bytes_per_read_kernel_tally'] * n_reads / rf['avg_kernel_ms'] / 1e6:.1f} | "
+            f"{rf['frac_kernel_tally']} |\n\n")
+    if rf.get("stages"):
+        f.write("Per stage (time shares from one extra step of the s_memtime-stamped diagnostic kernel, applied to the real kernel's "
+                "average duration; bytes = that stage's terms of the formula):\n\n| stage | share | ms | bytes/read | GB/s | frac of 8 TB/s |\n|---|---|---|---|---|---|\n")
+        for st in rf["stages"]:
+            f.write(f"| {st['stage']} | {st['time_share']} | {st['ms']} | {st['alg_bytes_per_read']} | {st['achieved_GBps']} | {st['frac']} |\n")
+        f.write("\n")
+    f.write(f"cpu_baseline: {cb['value']} reads/s on {cb['cores']} threads ({cb['sample']}); identical to the GPU on the sample: positions "
+            f"{cb['positions_identical_to_gpu']}, + diffs and flags {cb['pos_diffs_flags_identical_to_gpu']}, + CIGARs "
+            f"{cb['pos_diffs_flags_cigar_identical_to_gpu']} (long CIGARs through the arena: {cb['long_cigars_checked_through_the_arena']}).\n\n")
+    f.write(f"## Memory-side traffic\n\n`{tag}_traffic.json` (separate `--pmc` pass, rows in `{tag}_pmc_rdreq_map_se.csv`): "
+            f"{cnt['TCC_EA0_RDREQ_sum'] / 1e9:.2f} G read requests from the L2s to the fabric per launch, all of them 128-byte lines = "
+            f"{nbytes / 1e12:.2f} TB = {nbytes / secs / 1e12:.2f} TB/s during the kernel ({secs * 1e3:.0f} ms under the counters).  "
+            "`TCC_EA0_RDREQ` counts Infinity-Cache hits too, so this is fabric request traffic and an UPPER bound on HBM bytes "
+            "(MI355X_MICROARCH.md, HBM).  It is about 2.6x the kernel-tally bytes and 5x the strict bytes: every 8-72-byte "
+            "gather costs a whole 128-byte line.\n\n")
+    f.write("Work per read in that run: " + ", ".join(f"{k} {v}" for k, v in line["work_per_read"].items()) + ".\n")
 print(open(os.path.join(dst, f"{tag}_README.md")).read())

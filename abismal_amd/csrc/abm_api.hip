@@ -134,8 +134,6 @@ struct abm_ctx {
   // every device entry point reuses this context's workspaces: a call first makes its stream wait for
   // the previous call's work (whatever stream that ran on), so consecutive calls never overlap
   hipEvent_t last_done = nullptr;
-  hipStream_t stream2 = nullptr;  // the single-end heavy kernel runs beside the main kernel on this one
-  hipEvent_t fork = nullptr, join = nullptr;
   std::map<uint64_t, int> se_waves;
   // staging for the host-buffer entry points
   DevBuf<char> blob;
@@ -255,66 +253,31 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
 
-  // Two kernels share a batch.  Work per read spans four orders of magnitude: a satellite or homopolymer
-  // read puts one to two million candidates through the filter, 128 per dependent memory round trip, and
-  // keeps its wave busy for a quarter of a second -- the floor under any launch, however small the batch.
-  // Reads the ordering pass predicts to be that heavy (weight class >= heavy_class) go to the HEAVY kernel
-  // (same per-read code, more window loads in flight per lane, fewer registers-limited waves), started
-  // first on a second stream so that its few waves run beside the main kernel from the start; the main
-  // kernel gives up any read whose candidates exceed a budget (a misprediction), and those are mapped
-  // from scratch by a second, short heavy launch.  Results are indexed by read, so none of this shows.
-  int heavy_class = 16;
-  abm::u32 budget = 1u << 17, heavy_grid = 1024;
-  // Measured on MI355X at hg38 scale (scripts/r02_tier.sh, profiles/r02_README.md): OFF by default.  The reads
-  // above any useful budget are ~20 % of all work, so the heavy kernel's few waves become the long pole
-  // (10 M reads: 1480-1820 ms against 898 ms single-tier; 1 M: 305-413 ms against 221 ms).
-  bool two_tier = false;
-  if (const char *e = std::getenv("ABM_SE_TWO_TIER")) two_tier = e[0] == '1' && a.order != nullptr && a.G != 0 && !ctx->phase_stamps;
-  if (const char *e = std::getenv("ABM_SE_HEAVY_CLASS")) heavy_class = std::max(1, std::min(32, std::atoi(e)));
-  if (const char *e = std::getenv("ABM_SE_BUDGET")) budget = static_cast<abm::u32>(std::max(1024, std::atoi(e)));
-  if (const char *e = std::getenv("ABM_SE_HEAVY_GRID")) heavy_grid = static_cast<abm::u32>(std::max(64, std::atoi(e)));
+  // In-block help (HelpWave): the cooperative-filter kernel runs se_block_waves() waves per workgroup whose idle
+  // waves take filter chunks of their block-mates' heaviest reads; ABM_SE_HELP=0 selects one-wave workgroups.
+  abm::u32 block_waves = a.G != 0 ? abm::se_block_waves() : 1u;
+  if (const char *e = std::getenv("ABM_SE_HELP")) if (e[0] == '0') block_waves = 1;
+  if (ctx->phase_stamps) block_waves = 1;  // (the stamped diagnostic build measures the plain per-read phases)
+  if (block_waves > 1) {
+    const uint64_t shape2 = shape ^ (0xB10Cull << 32);
+    auto it2 = ctx->se_waves.find(shape2);
+    if (it2 != ctx->se_waves.end()) waves = it2->second;
+    else { waves = abm::se_resident_waves(W, WB, a.ctmp_cap, eff_len, size_frac, block_waves); ctx->se_waves[shape2] = waves; }
+    if (waves <= 0) block_waves = 1, waves = ctx->se_waves[shape];
+    else grid = static_cast<abm::u32>(waves);
+  }
+  if (block_waves > 1) {
+    const abm::u32 cap = 16384;
+    size_t zeroed = 0, total = 0;
+    abm::se_help_bytes(grid, cap, zeroed, total);
+    ctx->help_ws.reserve(total);
+    abm::se_help_carve(ctx->help_ws.p, grid, cap, a.help);
+    HIPCHK(hipMemsetAsync(ctx->help_ws.p, 0, zeroed, st));
+  }
   const hipEvent_t e1 = begin_timed(ctx, st);
-  if (!two_tier) {
-    a.next_read = fresh_counter(st);
-    a.drained = ctx->signal_drained ? ctx->drained : nullptr;
-    HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
-  }
-  else {
-    ctx->need_big.reserve(n);
-    ctx->subset.reserve(n);
-    ctx->subset_count.reserve(1);
-    HIPCHK(hipMemsetAsync(ctx->need_big.p, 0, n, st));
-    a.need_big = ctx->need_big.p;
-    // heavy kernel on the predicted-heavy reads, order[0 .. class33[heavy_class]) -- class33[c] is, after
-    // the ordering pass, the end of class c in the heaviest-first order
-    HIPCHK(hipEventRecord(ctx->fork, st));
-    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->fork, 0));
-    abm::SeArgs h = a;
-    h.list_begin = nullptr;
-    h.list_end = ctx->class33.p + heavy_class;
-    h.budget = 0;
-    h.next_read = fresh_counter(ctx->stream2);
-    HIPCHK(abm::launch_map_se(h, eff_len, heavy_grid, false, ctx->stream2, true));
-    HIPCHK(hipEventRecord(ctx->join, ctx->stream2));
-    // main kernel on the rest
-    a.list_begin = ctx->class33.p + heavy_class;
-    a.list_end = nullptr;
-    a.budget = budget;
-    a.next_read = fresh_counter(st);
-    a.drained = ctx->signal_drained ? ctx->drained : nullptr;
-    HIPCHK(abm::launch_map_se(a, eff_len, grid, false, st));
-    HIPCHK(hipStreamWaitEvent(st, ctx->join, 0));
-    // the reads the main kernel gave up
-    HIPCHK(abm::launch_collect_big(ctx->need_big.p, ctx->cls.p, n, ctx->class33.p, ctx->subset.p, ctx->subset_count.p, st));
-    abm::SeArgs l = a;
-    l.order = ctx->subset.p;
-    l.list_begin = nullptr;
-    l.list_end = ctx->subset_count.p;
-    l.budget = 0;
-    l.drained = nullptr;
-    l.next_read = fresh_counter(st);
-    HIPCHK(abm::launch_map_se(l, eff_len, heavy_grid, false, st, true));
-  }
+  a.next_read = fresh_counter(st);
+  a.drained = ctx->signal_drained ? ctx->drained : nullptr;
+  HIPCHK(abm::launch_map_se(a, eff_len, grid, block_waves, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipEventRecord(ctx->last_done, st));
 }
@@ -574,13 +537,6 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
       }
       HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming));
-      {
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));  // "hi" = greatest priority
-      }
-      HIPCHK(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
       HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->drained), sizeof(abm::u32), hipHostMallocMapped | hipHostMallocCoherent));
       *c->drained = 0;
       c->work.reserve(32);
@@ -596,9 +552,6 @@ void abm_ctx_destroy(abm_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->last_done) (void)hipEventDestroy(c->last_done);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->fork) (void)hipEventDestroy(c->fork);
-  if (c->join) (void)hipEventDestroy(c->join);
   if (c->drained) (void)hipHostFree(c->drained);
   if (c->holds_replica && c->ix) {
     std::lock_guard<std::mutex> lk(c->ix->mu);

@@ -45,7 +45,15 @@ struct Hit {  // == abm_hit
 };
 
 // ---- lane helpers -----------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x); }
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
+
+// Between phases a wave needs its own LDS / global writes ordered before its later reads -- what __syncthreads()
+// meant while every workgroup was one wave.  Waves of a multi-wave workgroup here never run in lock-step (each maps
+// its own reads), so a workgroup barrier is exactly what must NOT be used.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

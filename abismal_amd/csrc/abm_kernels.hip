@@ -9,9 +9,7 @@
 #ifndef ABM_SE_WAVES_PER_SIMD
 #define ABM_SE_WAVES_PER_SIMD 5  // 96 VGPRs per lane, 20 waves per CU
 #endif
-#ifndef ABM_SE_HEAVY_WAVES_PER_SIMD
-#define ABM_SE_HEAVY_WAVES_PER_SIMD 4  // heavy kernel: 128 VGPRs per lane (its waves are few and latency-bound)
-#endif
+
 
 namespace abm {
 
@@ -65,14 +63,25 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
-template <bool TIMED, bool COOP, bool HEAVY>
+template <bool TIMED, bool COOP, u32 NW>
 __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
+  // NW waves per workgroup, each with its own LDS region behind the workgroup's control block (NW > 1);
+  // after the start-up barrier the waves never meet at a barrier again
+  const u32 wave = NW > 1 ? static_cast<u32>(uni(static_cast<int>(threadIdx.x >> 6))) : 0u;
+  BlockCtl<NW> *bc = reinterpret_cast<BlockCtl<NW> *>(smem);
+  constexpr u32 kCtlBytes = NW > 1 ? static_cast<u32>((sizeof(BlockCtl<NW>) + 15) & ~15ul) : 0u;
+  unsigned char *wave_lds0 = smem + kCtlBytes;
+  unsigned char *mine = wave_lds0 + static_cast<size_t>(wave) * a.lds_per_wave;
+  if constexpr (NW > 1) {
+    for (u32 k = threadIdx.x; k < sizeof(BlockCtl<NW>) / 4; k += 64 * NW) reinterpret_cast<u32 *>(smem)[k] = 0;
+    __syncthreads();
+  }
   WaveLds lds;
   lds.W = a.W;
   lds.WB = a.WB;
-  lds.qpk = reinterpret_cast<u64 *>(smem);
+  lds.qpk = reinterpret_cast<u64 *>(mine);
   lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
   lds.gwin = lds.qbits + 4 * a.WB;
@@ -94,23 +103,19 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
   WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  constexpr bool HELP = HEAVY && COOP && ABM_HEAVY_HELP != 0;
-  constexpr int MODE = HEAVY ? kHeavy : kMain;
+  constexpr int MODE = kMain;
   HelpWave hw;
   hw.h = a.help;
-  hw.grid = gridDim.x;
-  hw.slot = blockIdx.x;
-  hw.r = 0;
+  if constexpr (NW == 1) hw.h.seg = nullptr;
+  hw.span = &bc->span[wave]; hw.epoch_w = &bc->epoch[wave]; hw.done_w = &bc->done[wave]; hw.info_w = &bc->info[wave][0];
+  hw.retired = &bc->retired;
+  hw.slot = blockIdx.x * NW + wave;
   hw.epoch = 0;
-  hw.registered = hw.on = hw.failed = hw.mismatch = false;
+  hw.failed = hw.mismatch = false;
   const CigarSink sink = {a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap};
   PassCtl pc;
-  pc.hw = &hw;
-  pc.gave_up = false;
-  const u32 budget = (!HEAVY && a.budget) ? a.budget : 0xFFFFFFFFu;
-  // the reads of this launch: order[first .. first + n_items)
-  const u64 first = a.list_begin ? static_cast<u64>(*a.list_begin) : 0ull;
-  const u64 n_items = (a.list_end ? static_cast<u64>(*a.list_end) : a.n_reads) - first;
+  pc.hw = NW > 1 ? &hw : nullptr;
+  const u64 first = 0, n_items = a.n_reads;
   long long t_begin = 0, t_a = 0, t_b = 0;
   ABM_STAMP(t_begin);
   u32 n_aln = 0;
@@ -146,7 +151,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       // stage the four encodings and derive their 2-letter bit strings
       const u64 *src = a.packed + r * 4 * a.W;
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[k] = src[k];
-      __syncthreads();
+      wave_sync();
       for (u32 e = 0; e < 4; ++e)
         for (u32 wb = 0; wb < a.WB; ++wb) {
           const u32 j = wb * 64 + lane;
@@ -154,32 +159,24 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
           const u64 word = __ballot(b);
           if (lane == 0) lds.qbits[e * a.WB + wb] = word;
         }
-      __syncthreads();
+      wave_sync();
       if (L < max(a.ix.window, L >> 1) + kKeyWeight - 1)  // 44-46 bases: seeds reach past the end of the read
         ghost_bits(a.packed, a.lens, r, L, a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits);
 
       SeSet S;
       S.begin_read(L);
-      pc.budget_left = budget;
-      pc.gave_up = false;
       for (u32 cidx = 0; cidx < n_calls; ++cidx) {
         const bool rc = (call_rc >> cidx) & 1u, ar = (call_ar >> cidx) & 1u;
         const bool g_to_a = rc != ar;  // get_conv_type, src/abismal.cpp:1261-1267
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        hw.r = r;
         seed_pass<true, TIMED, COOP, MODE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, &pc);
         // should_do_sensitive, :367-370
-        if (!pc.gave_up && (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff)) {
+        if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
           S.cutoff = S.top_d();  // set_sensitive
           seed_pass<false, TIMED, COOP, MODE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, &pc);
         }
-        if (pc.gave_up) break;
-      }
-      if (pc.gave_up) {  // too many candidates for this kernel: the heavy kernel maps the read from scratch
-        if (lane == 0) a.need_big[r] = 1;
-        continue;
       }
       ABM_STAMP(t_a);
       choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln);
@@ -193,10 +190,9 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     }
   }
   // no reads left: this wave's slot takes no more jobs, and it works for the waves still busy
-  if constexpr (HELP) {
-    hw.retire_owner();
-    help_others(a.ix, lds, a.packed, hw);
-  }
+  // no reads left: stay and work for the block-mates that are still busy
+  if constexpr (NW > 1 && COOP) help_block_mates<NW>(a.ix, lds, bc, wave_lds0, a.lds_per_wave, wave, hw, wt);
+  else if constexpr (NW > 1) { if (lane == 0) __hip_atomic_fetch_add(&bc->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   if (a.work) {  // exact per-launch work tallies for the roofline model
     auto wsum = [&](u32 v) { u32 t; (void)wave_excl_sum(v, t); return t; };
     const u32 s0 = wsum(wt.seed_iters), s1 = wsum(wt.probes), s2 = wsum(wt.cands), s3 = wsum(wt.words);
@@ -222,11 +218,13 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u) | (hw.failed ? 8u : 0u) | (hw.mismatch ? 16u : 0u));
 }
 
-template <bool TIMED, bool COOP>
-__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false>(a); }
-// the same per-read body for the reads with very many candidates (see PassMode)
-template <bool TIMED, bool COOP>
-__global__ __launch_bounds__(64, ABM_SE_HEAVY_WAVES_PER_SIMD) void map_se_heavy_kernel(SeArgs a) { map_se_body<TIMED, COOP, true>(a); }
+#ifndef ABM_SE_BLOCK_WAVES
+#define ABM_SE_BLOCK_WAVES 4  // waves per workgroup of the cooperative-filter kernel (see HelpWave); 20 waves per CU = 5 workgroups
+#endif
+constexpr u32 kBlockWaves = ABM_SE_BLOCK_WAVES;
+// (the launch bound's second argument is waves per SIMD: 5 x 4 SIMDs = 20 waves per CU whatever the workgroup shape)
+template <bool TIMED, bool COOP, u32 NW>
+__global__ __launch_bounds__(64 * NW, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, NW>(a); }
 
 // =============================================================================
 // Heaviest-first ordering.  Work per read spans four orders of magnitude and is
@@ -351,21 +349,18 @@ hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned lon
   return hipGetLastError();
 }
 
-// ---- tail-help workspace ------------------------------------------------------
+// ---- in-block help workspace -----------------------------------------------------
 void se_help_bytes(u32 n_waves, u32 cap, size_t &zeroed, size_t &total) {
-  const size_t ctl_words = 64 + ((static_cast<size_t>(n_waves) + 31) & ~static_cast<size_t>(31));
-  zeroed = (ctl_words + 32ull * n_waves) * 4;
-  total = zeroed + (static_cast<size_t>(kHelpDescWords) + cap / 2 + cap) * n_waves * 4;
+  zeroed = static_cast<size_t>(kHelpFlagWords) * n_waves * 4;
+  total = zeroed + (static_cast<size_t>(kHelpSegWords) + cap / 2 + cap) * n_waves * 4;
 }
 void se_help_carve(char *base, u32 n_waves, u32 cap, HelpArgs &h) {
-  const size_t ctl_words = 64 + ((static_cast<size_t>(n_waves) + 31) & ~static_cast<size_t>(31));
-  h.ctl = reinterpret_cast<u32 *>(base);
-  h.tick = h.ctl + ctl_words;
-  h.desc = h.tick + 32ull * n_waves;
-  h.res = h.desc + static_cast<size_t>(kHelpDescWords) * n_waves;
-  h.stats = nullptr;
+  h.flags = reinterpret_cast<u32 *>(base);
+  h.seg = h.flags + static_cast<size_t>(kHelpFlagWords) * n_waves;
+  h.res = h.seg + static_cast<size_t>(kHelpSegWords) * n_waves;
   h.cap = cap;
 }
+u32 se_block_waves() { return kBlockWaves; }
 
 // ---- launchers ----------------------------------------------------------------
 u32 se_window_words(u32 max_len, double valid_frac) {
@@ -394,20 +389,27 @@ size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_fra
   return (b + 15) & ~static_cast<size_t>(15);
 }
 
-int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac) {
+static size_t se_block_lds(size_t per_wave, u32 block_waves) {
+  return block_waves > 1 ? ((sizeof(BlockCtl<kBlockWaves>) + 15) & ~static_cast<size_t>(15)) + per_wave * block_waves : per_wave;
+}
+
+int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac, u32 block_waves) {
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true>, 64,
-                                                   se_lds_bytes(W, WB, cig_stride, max_len, valid_frac)) != hipSuccess)
-    return 0;
+  const size_t lds = se_block_lds(se_lds_bytes(W, WB, cig_stride, max_len, valid_frac), block_waves);
+  const hipError_t e = block_waves > 1
+      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true, kBlockWaves>, 64 * kBlockWaves, lds)
+      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true, 1>, 64, lds);
+  if (e != hipSuccess) return 0;
   // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): the kernel is bound by
   // the random line requests a CU can keep outstanding, and what matters is waves without register
   // spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
   // window loads with 8 rounds in flight, 16 waves at 128 registers 1029 ms (20 waves at 96 with spills:
   // 1386); with 2 rounds in flight 20 waves fit almost without spills: 923 ms (24 waves: 999).
   constexpr int kSeWavesPerCu = 20;
-  return min(per_cu, kSeWavesPerCu) * prop.multiProcessorCount;
+  return min(per_cu * static_cast<int>(block_waves), kSeWavesPerCu) / static_cast<int>(block_waves) * static_cast<int>(block_waves) *
+         prop.multiProcessorCount;
 }
 
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,
@@ -419,29 +421,26 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
   return hipGetLastError();
 }
 
-hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st, bool heavy) {
+hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, u32 block_waves, bool timed, hipStream_t st) {
   if (a.n_reads == 0) return hipSuccess;
-  const size_t lds = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
-  const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
-  if (heavy) {
-    if (a.G != 0) {
-      if (timed) hipLaunchKernelGGL((map_se_heavy_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
-      else hipLaunchKernelGGL((map_se_heavy_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
-    }
-    else {
-      if (timed) hipLaunchKernelGGL((map_se_heavy_kernel<true, false>), dim3(blocks), dim3(64), lds, st, a);
-      else hipLaunchKernelGGL((map_se_heavy_kernel<false, false>), dim3(blocks), dim3(64), lds, st, a);
-    }
-    return hipGetLastError();
-  }
+  const size_t per_wave = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
+  a.lds_per_wave = static_cast<u32>(per_wave);
+  if (a.G == 0 || block_waves != kBlockWaves) block_waves = 1;  // in-block help needs the cooperative filter
+  const size_t lds = se_block_lds(per_wave, block_waves);
+  const u32 waves = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
+  const u32 blocks = (waves + block_waves - 1) / block_waves;
   // COOP: G lanes share a candidate's window (a.G != 0); otherwise one lane per window
-  if (a.G != 0) {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
+  if (a.G != 0 && block_waves > 1) {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, kBlockWaves>), dim3(blocks), dim3(64 * kBlockWaves), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, true, kBlockWaves>), dim3(blocks), dim3(64 * kBlockWaves), lds, st, a);
+  }
+  else if (a.G != 0) {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, 1>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, true, 1>), dim3(blocks), dim3(64), lds, st, a);
   }
   else {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, false>), dim3(blocks), dim3(64), lds, st, a);
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false, 1>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, false, 1>), dim3(blocks), dim3(64), lds, st, a);
   }
   return hipGetLastError();
 }

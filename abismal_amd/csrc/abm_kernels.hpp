@@ -5,16 +5,14 @@
 
 namespace abm {
 
-// tail-help workspace of one single-end launch (see HelpWave in abm_kernels_core.hpp); all null = off.
-//   ctl:  [0] waves retired, [32] owners registered, [64 + k] slot + 1 of the k-th registered owner
-//   tick: per wave 32 words: ticket (u64: epoch << 44 | chunks << 22 | next chunk), chunks done
-//   desc: per wave kHelpDescWords words: job header + the block's segment table
-//   res:  per wave cap/2 words of distances (two u16) + cap words of positions
-// ctl and tick are zeroed before every launch.
+// workspace of the single-end kernel's in-block help (HelpWave in abm_kernels_core.hpp), one slot per wave of the
+// grid; all null = off.  `flags` is zeroed before every launch.
+//   seg:   kHelpSegWords words: the open job's segment table
+//   flags: kHelpFlagWords words: per chunk, the job number whose results the buffer holds
+//   res:   cap/2 words of distances (two u16) + cap words of positions
 struct HelpArgs {
-  u32 *ctl, *tick, *desc, *res;
-  unsigned long long *stats;  // optional [4]: jobs, chunks, chunks done by their owner, chunks done by helpers
-  u32 cap;  // candidates per job (multiple of 128)
+  u32 *seg, *flags, *res;
+  u32 cap;  // candidates per job (multiple of 128, at most 128 * kHelpFlagWords)
 };
 
 struct SeArgs {
@@ -23,11 +21,8 @@ struct SeArgs {
   const u64 *packed;  // [n][4][W]
   const u32 *lens;    // [n]
   const u32 *order;   // [n] processing order (heaviest first), or null
-  // this launch maps order[*list_begin .. *list_end) (device words; null = 0 / n_reads)
-  const u32 *list_begin, *list_end;
-  u32 budget;         // main kernel: candidates after which a read is given up (need_big set); 0 = none
-  u8 *need_big;       // [n] reads the main kernel gave up
   u64 n_reads;
+  u32 lds_per_wave;   // bytes of LDS per wave (se_lds_bytes)
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
   u32 max_len;        // longest read of the batch
   u32 tb_extra;       // tb_extra_bytes()
@@ -109,10 +104,12 @@ hipError_t launch_compact_cigars(const Hit *d_res, const u32 *d_cig, const u32 *
                                  unsigned long long *d_off, u32 *d_blob, void *tmp, size_t *tmp_bytes, hipStream_t st);
 hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned long long *d_off, u64 n, u32 *d_blob,
                                 hipStream_t st);
-hipError_t launch_map_se(const SeArgs &a, u32 max_len, u32 n_waves, bool timed, hipStream_t st, bool heavy = false);
-// bytes of the help workspace for a grid of n_waves: {zeroed part (ctl + tick), total}
+// n_waves = waves of the grid; block_waves = waves per workgroup (1, or se_block_waves() with in-block help)
+hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, u32 block_waves, bool timed, hipStream_t st);
+u32 se_block_waves();
+// bytes of the help workspace for a grid of n_waves: {zeroed part (the flags, at its start), total}
 void se_help_bytes(u32 n_waves, u32 cap, size_t &zeroed, size_t &total);
 void se_help_carve(char *base, u32 n_waves, u32 cap, HelpArgs &h);
-int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
+int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac, u32 block_waves = 1);
 
 }  // namespace abm

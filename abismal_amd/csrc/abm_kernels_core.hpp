@@ -368,10 +368,10 @@ __device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, con
       if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
     }
   }
-  __syncthreads();
+  wave_sync();
   d_a = static_cast<i16>(lds.hres[lane]);
   d_b = static_cast<i16>(lds.hres[64 + lane]);
-  __syncthreads();
+  wave_sync();
 }
 
 // ---- flattened candidates of one 64-offset block ---------------------------------------
@@ -400,10 +400,10 @@ __device__ __forceinline__ void locate(const WaveLds &lds, const Segs &sg, u32 c
                                        bool &valid, int &owner, u32 &entry_at, bool &three) {
   const int lane = lane_id();
   lds.mark[lane] = 0;
-  __syncthreads();
+  wave_sync();
   if (sg.na && sg.start_a - c0 < 64u) lds.mark[sg.start_a - c0] = static_cast<u16>(2 * lane + 1);
   if (sg.nb && sg.start_b() - c0 < 64u) lds.mark[sg.start_b() - c0] = static_cast<u16>(2 * lane + 2);
-  __syncthreads();
+  wave_sync();
   const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
   const int seg = m ? m - 1 : carry;
   carry = rdlane(seg, 63);
@@ -418,123 +418,62 @@ __device__ __forceinline__ void locate(const WaveLds &lds, const Segs &sg, u32 c
   entry_at = three ? bb + (c - sb) : ba + (c - sa);
 }
 
-// ---- tail help: idle waves take filter chunks of a heavy read --------------------------
+// ---- in-block help: idle waves of a workgroup take filter chunks of a block-mate's heavy read -------------
 // Reads differ in cost by four orders of magnitude: a homopolymer or satellite read puts one to two
-// million candidates through the filter, 128 per dependent memory round trip, and keeps its wave
-// busy for 0.2-0.3 s -- long after a small batch's other reads are done.  Once some wave has run out
-// of reads (ctl.retired > 0), a wave that meets a block with many candidates ("owner") publishes the
-// block's segment table as a job; retired waves ("helpers") claim 128-candidate chunks of it, run
-// the same filter_chunk as the owner does, and write distance + position per candidate into the
-// owner's result buffer.  The owner takes chunks too, waits until all are in, and then replays the
-// results IN ORDER through the candidate set exactly as before -- distances are a pure function of
-// (read, position), so which wave computed them cannot show in the output.
+// million candidates through the filter, 128 per dependent memory round trip, and keeps its wave busy
+// for 0.2-0.3 s -- long after a small batch's other reads are done.  The single-end kernel therefore
+// runs kBlockWaves waves per workgroup, each mapping its own reads exactly as a one-wave workgroup would
+// (own LDS region, no workgroup barrier after start-up).  A wave that has run out of reads does not exit:
+// it watches its block-mates.  A mate ("owner") that meets a block with many candidates while some wave
+// of its workgroup is idle opens a JOB: its segment table goes to its slot in global memory, the chunks
+// [0, n) of 128 candidates become claimable from BOTH ends through one LDS word -- the owner takes them
+// from the front in order, exactly as it would alone; helpers take them from the back, run the same
+// filter against the owner's read (which they read straight from the owner's LDS) and put distance +
+// position per candidate into the owner's result buffer.  Where the two meet, the owner stops computing
+// and replays the helpers' results from the buffer, still in the reference's order.  Distances are a
+// pure function of (read, position), so which wave computed them cannot show in the output.
 //
-// Protocol (placement-independent; cdna_hip_programming.md, Guideline 16, recipe R1): payload
-// stores are agent-scope (write-through), drained with s_waitcnt vmcnt(0) before the signalling
-// atomic; the consumer polls ONE word relaxed, then one agent-scope acquire, then loads.  Every
-// counter is an atomic RMW.  All control words are zeroed by the launch function before every launch.
-#define ABM_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ABM_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ABM_AGENT_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-constexpr u32 kHelpMin = 1024;        // candidates in a block from which its owner asks for help
-constexpr u32 kHelpChunk = 128;       // candidates per claimed chunk (one filter step)
-constexpr u64 kTickRetired = 0xFFFFFull;  // epoch field of an owner that has no reads left
-constexpr u32 kHelpHeaderWords = 32, kHelpDescWords = kHelpHeaderWords + 5 * 64;
-constexpr u32 kHelpSpinLimit = 1u << 24;
-constexpr u32 kHelpRounds = 8;          // rounds of window loads in flight per lane in a claimed chunk (the machine is mostly idle then)  // polls before a wait gives up and flags the launch
-
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#ifndef ABM_HELP_FENCES
-#define ABM_HELP_FENCES 1
+// Everything stays inside one CU: owner and helpers share its LDS and its vector L1, so workgroup-scope
+// ordering suffices (no agent-scope fence, no cross-XCD visibility protocol); results reach the owner
+// through global memory only because 16 K candidates x 6 bytes per wave would not fit LDS.
+constexpr u32 kHelpMin = 1024;        // candidates in a block from which its owner opens a job
+constexpr u32 kHelpChunk = 128;       // candidates per chunk (one filter step)
+constexpr u32 kHelpFlagWords = 128;   // chunks per job at most = cap / 128
+constexpr u32 kHelpSegWords = 5 * 64;  // a job's segment table: five words per lane
+constexpr u32 kHelpSpinLimit = 1u << 24;  // polls before a wait gives up and flags the launch
+#ifndef ABM_HELP_ROUNDS
+#define ABM_HELP_ROUNDS 8  // rounds of window loads in flight per lane in a helper's chunk (it has nothing else to hold)
 #endif
-// Every load of handed-off bytes here is an agent-scope load (bypasses this CU's L1); the acquire of
-// recipe R1 is kept on top of that unless a build switches it off for measurement.
-__device__ __forceinline__ void acquire_agent() {
-  if (ABM_HELP_FENCES) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ u64 uni64(u64 v) {
-  return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) | static_cast<u32>(uni(static_cast<int>(v)));
-}
 
-struct HelpWave {  // one wave's view of the help workspace (see HelpArgs)
-  HelpArgs h;
-  u32 grid, slot;
-  u64 r;            // read being mapped (owner side)
-  u32 epoch;        // jobs this wave has published
-  bool registered;  // this wave's slot is on the owners' list
-  bool on;          // some wave has retired: help can arrive
+#define ABM_WG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define ABM_WG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// per-workgroup control block at the start of dynamic LDS (only when kBlockWaves > 1)
+template <u32 NW> struct BlockCtl {
+  u32 retired;        // waves that have no reads left
+  u32 span[NW];       // wave w's open job: hi << 16 | lo, unclaimed chunks = [lo, hi); 0 = none
+  u32 epoch[NW];      // job number of wave w (tags the per-chunk flags)
+  u32 done[NW];       // chunks of the current job its helpers have finished
+  u32 info[NW][6];    // enc | g_to_a << 8, g0, total, c_base, L, unused
+};
+
+struct HelpWave {  // one wave's view of the help machinery
+  HelpArgs h;       // global workspace (null = help off)
+  u32 *span, *epoch_w, *done_w, *info_w;  // this wave's words in the control block
+  const u32 *retired;
+  u32 slot;         // global wave number: its slot in the workspace
+  u32 epoch;        // jobs this wave has opened
   bool failed;      // a bounded wait gave up
-  bool mismatch;    // ABM_HELP_SELFCHECK build only: a result read back differs from the owner's own computation
+  bool mismatch;    // ABM_HELP_SELFCHECK build only
 
-  __device__ __forceinline__ unsigned long long *tick(u32 s) const { return reinterpret_cast<unsigned long long *>(h.tick + 32ull * s); }
-  __device__ __forceinline__ u32 *done(u32 s) const { return h.tick + 32ull * s + 2; }
-  __device__ __forceinline__ u32 *desc(u32 s) const { return h.desc + static_cast<u64>(kHelpDescWords) * s; }
+  __device__ __forceinline__ u32 *seg(u32 s) const { return h.seg + static_cast<u64>(kHelpSegWords) * s; }
+  __device__ __forceinline__ u32 *flags(u32 s) const { return h.flags + static_cast<u64>(kHelpFlagWords) * s; }
   __device__ __forceinline__ u32 *res_d(u32 s) const { return h.res + static_cast<u64>(s) * (h.cap / 2 + h.cap); }
   __device__ __forceinline__ u32 *res_p(u32 s) const { return res_d(s) + h.cap / 2; }
-
-  __device__ __forceinline__ bool available() {
-    if (h.ctl == nullptr || epoch >= 0xFFFF0u) return false;
-    if (!on) on = uni(static_cast<int>(ABM_AGENT_LOAD(h.ctl))) != 0;
-    return on;
-  }
-  // owner: make candidates [c_base, c_base + n_chunks * 128) of the block a job
-  __device__ __forceinline__ void publish(const Segs &sg, u32 enc, bool g_to_a, u32 g0, u32 total, u32 c_base, u32 L,
-                                          u32 n_chunks) {
-    const int lane = lane_id();
-    u32 *d = desc(slot);
-    u32 hv = 0;
-    if (lane == 0) hv = static_cast<u32>(r);
-    if (lane == 1) hv = static_cast<u32>(r >> 32);
-    if (lane == 2) hv = enc | (g_to_a ? 256u : 0u);
-    if (lane == 3) hv = g0;
-    if (lane == 4) hv = total;
-    if (lane == 5) hv = c_base;
-    if (lane == 6) hv = L;
-    if (lane < 8) ABM_AGENT_STORE(d + lane, hv);
-    u32 *sv = d + kHelpHeaderWords + lane;
-    ABM_AGENT_STORE(sv, sg.start_a);
-    ABM_AGENT_STORE(sv + 64, sg.na);
-    ABM_AGENT_STORE(sv + 128, sg.lo2);
-    ABM_AGENT_STORE(sv + 192, sg.nb);
-    ABM_AGENT_STORE(sv + 256, sg.lo3);
-    if (lane == 0) ABM_AGENT_STORE(done(slot), 0u);
-    drain_stores();
-    ++epoch;
-    if (lane == 0) ABM_AGENT_STORE(tick(slot), (static_cast<unsigned long long>(epoch) << 44) | (static_cast<unsigned long long>(n_chunks) << 22));
-    if (!registered) {
-      if (lane == 0) {
-        const u32 at = ABM_AGENT_ADD(h.ctl + 32, 1u);
-        ABM_AGENT_STORE(h.ctl + 64 + at, slot + 1u);
-      }
-      registered = true;
-    }
-  }
-  // next unclaimed chunk of slot s's current job: returns the ticket as it was before the claim
-  __device__ __forceinline__ u64 claim(u32 s) const {
-    unsigned long long t = 0;
-    if (lane_id() == 0) t = ABM_AGENT_ADD(tick(s), 1ull);
-    return uni64(t);
-  }
-  __device__ __forceinline__ void store_chunk(u32 s, u32 chunk, int ha, int hb, u32 pa, u32 pb) const {
-    const int lane = lane_id();
-    ABM_AGENT_STORE(res_d(s) + chunk * 64u + lane, (static_cast<u32>(ha) & 0xFFFFu) | (static_cast<u32>(hb) << 16));
-    ABM_AGENT_STORE(res_p(s) + chunk * 128u + lane, pa);
-    ABM_AGENT_STORE(res_p(s) + chunk * 128u + 64u + lane, pb);
-    drain_stores();
-    if (lane == 0) ABM_AGENT_ADD(done(s), 1u);
-  }
-  __device__ __forceinline__ void wait_done(u32 n_chunks) {
-    for (u32 spins = 0;; ++spins) {
-      const u32 d = static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(done(slot)))));
-      if (d >= n_chunks) break;
-      if (spins > kHelpSpinLimit) { failed = true; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    acquire_agent();
-  }
-  __device__ __forceinline__ void retire_owner() const {
-    if (h.ctl != nullptr && lane_id() == 0) ABM_AGENT_STORE(tick(slot), static_cast<unsigned long long>(kTickRetired << 44));
+  __device__ __forceinline__ bool wanted() const {  // some wave of this workgroup is idle
+    return h.seg != nullptr && uni(static_cast<int>(ABM_WG_LOAD(retired))) != 0;
   }
 };
 
@@ -571,7 +510,7 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
       qbits[e * WB + 1] = (m >> (64 - L)) | (~0ull << L);
     }
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // distances and positions of candidates [c0, c0 + 128) of a flattened block (two per lane: c0 + lane
@@ -589,40 +528,9 @@ __device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &
   if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
   pa = ea - (g0 + static_cast<u32>(oa));
   pb = eb - (g0 + static_cast<u32>(ob));
-  hamming_coop<kHelpRounds>(ix.genome, lds, qpk, nwords, pa, va, pb, vb, ha, hb);
+  hamming_coop<ABM_HELP_ROUNDS>(ix.genome, lds, qpk, nwords, pa, va, pb, vb, ha, hb);
   if (!va) ha = 0x7fff;
   if (!vb) hb = 0x7fff;
-}
-
-// Owner side of a job: publish candidates [c_base, c_base + n_chunks * 128) of the block, take chunks
-// like any helper, and return once every chunk's results are in this wave's buffer.  Out of line on
-// purpose: it runs only in the tail of a launch and must not cost the mapping loop registers.
-// Everything is passed by value (nothing of the caller's has its address taken: its state stays in
-// registers); returns the wave's new job count | failed << 31.
-__device__ __attribute__((noinline)) u32 help_fill_job(DevIndex ix, WaveLds lds, HelpWave hw, const u64 *qpk,
-                                                      const u32 *idx3, u32 nwords, u32 start_a, u32 na, u32 lo2, u32 nb,
-                                                      u32 lo3, u32 enc, bool g_to_a, u32 g0, u32 total, u32 c_base, u32 L,
-                                                      u32 n_chunks) {
-  Segs sg;
-  sg.start_a = start_a; sg.na = na; sg.lo2 = lo2; sg.nb = nb; sg.lo3 = lo3;
-  hw.publish(sg, enc, g_to_a, g0, total, c_base, L, n_chunks);
-  u32 mine = 0;
-  for (;;) {
-    const u32 idx = static_cast<u32>(hw.claim(hw.slot)) & ((1u << 22) - 1);
-    if (idx >= n_chunks) break;
-    int ha, hb;
-    u32 pa, pb;
-    filter_chunk(ix, lds, qpk, idx3, nwords, sg, g0, total, c_base + idx * kHelpChunk, ha, hb, pa, pb);
-    hw.store_chunk(hw.slot, idx, ha, hb, pa, pb);
-    ++mine;
-  }
-  hw.wait_done(n_chunks);
-  if (hw.h.stats != nullptr && lane_id() == 0) {  // diagnostics: jobs, chunks, chunks the owner did itself
-    ABM_AGENT_ADD(hw.h.stats, 1ull);
-    ABM_AGENT_ADD(hw.h.stats + 1, static_cast<unsigned long long>(n_chunks));
-    ABM_AGENT_ADD(hw.h.stats + 2, static_cast<unsigned long long>(mine));
-  }
-  return hw.epoch | (hw.failed ? 0x80000000u : 0u);
 }
 
 // One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
@@ -645,28 +553,17 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-// How a seed pass is run: kPlain (paired-end), kMain (single-end kernel for ordinary reads: a read
-// whose candidates exceed a budget is given up and left to the heavy kernel), kHeavy (single-end
-// kernel for the few reads with very many candidates: more window loads in flight per lane, and,
-// in an ABM_HEAVY_HELP build, idle waves share the filter work).
-enum PassMode { kPlain = 0, kMain = 1, kHeavy = 2 };
+// How a seed pass is run: kPlain (paired-end kernels), kMain (single-end kernel: a heavy block's filter
+// work can be shared with idle waves of the workgroup, see HelpWave)
+enum PassMode { kPlain = 0, kMain = 1 };
 struct PassCtl {
-  u32 budget_left;  // kMain: candidates this read may still put through the filter
-  bool gave_up;     // kMain: the budget ran out; the read's state is meaningless from here on
-  HelpWave *hw;     // kHeavy with help
+  HelpWave *hw;  // kMain with in-block help; null otherwise
 };
-#ifndef ABM_HEAVY_HELP
-#define ABM_HEAVY_HELP 0
-#endif
-#ifndef ABM_HEAVY_ROUNDS
-#define ABM_HEAVY_ROUNDS 8
-#endif
 template <bool SPECIFIC, bool TIMED, bool COOP, int MODE, class Set>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
                                           u32 flags, u32 L, Set &S, WorkTally &wt, PassCtl *pc = nullptr) {
-  constexpr bool HELP = MODE == kHeavy && ABM_HEAVY_HELP != 0;
-  constexpr u32 kRoundsHere = MODE == kHeavy ? ABM_HEAVY_ROUNDS : kCoopRounds;
-  HelpWave *hw = HELP ? pc->hw : nullptr;
+  constexpr bool HELP = MODE == kMain && COOP;
+  HelpWave *hw = (HELP && pc != nullptr) ? pc->hw : nullptr;
   const int lane = lane_id();
   const u64 *qpk = lds.qpk + enc * lds.W;
   const u64 *qb = lds.qbits + enc * lds.WB;
@@ -680,7 +577,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
   if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
     for (u32 k = lane; k < (1u << kPosCacheBits); k += 64) lds.pcache[k] = 0;
-    __syncthreads();
+    wave_sync();
   }
   for (u32 g0 = 0; g0 < n_off && !S.sure_ambig; g0 += 64) {
     ABM_STAMP(ta);
@@ -726,11 +623,6 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     sg.start_a = wave_excl_sum(sg.na + sg.nb, total);
     ABM_STAMP(tb_);
     if (TIMED) wt.t_probe += tb_ - ta;
-    if constexpr (MODE == kMain) {
-      // a read with this many candidates belongs to the heavy kernel: stop here, it is mapped again there
-      if (total > pc->budget_left) { pc->gave_up = true; S.sure_ambig = true; break; }
-      pc->budget_left -= total;
-    }
 
     // ordered replay of one 64-candidate sub-chunk (check_hits + update, :1133-1149, :394-404)
     auto replay = [&](bool valid, int h, int hmax, u32 pos) {
@@ -769,50 +661,6 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       }
     };
 
-    if constexpr (HELP && COOP) {
-      // A block with very many candidates while some wave sits idle: its distances are computed as jobs
-      // that idle waves share (help_fill_job: out of line, it needs none of the set's state), in sub-jobs
-      // that fit this wave's result buffer; the results are then replayed here in the reference's order.
-      if (total >= kHelpMin && hw != nullptr && hw->available()) {
-        ABM_STAMP(tc);
-        for (u32 c_base = 0; c_base < total && !S.sure_ambig; c_base += hw->h.cap) {
-          const u32 cnt = min(hw->h.cap, total - c_base);
-          const u32 n_chunks = (cnt + kHelpChunk - 1) / kHelpChunk;
-          const u32 hs = help_fill_job(ix, lds, *hw, qpk, idx3, nwords, sg.start_a, sg.na, sg.lo2, sg.nb, sg.lo3, enc, g_to_a, g0,
-                                       total, c_base, L, n_chunks);
-          hw->epoch = hs & 0x7FFFFFFFu;
-          hw->registered = true;
-          hw->failed |= (hs >> 31) != 0;
-          wt.cands += cnt / 64 + (static_cast<u32>(lane) < cnt % 64 ? 1u : 0u);  // (tallies are per lane and summed at the end)
-          wt.words += (cnt / 64 + (static_cast<u32>(lane) < cnt % 64 ? 1u : 0u)) * nwords;
-          const u32 *rd = hw->res_d(hw->slot), *rp = hw->res_p(hw->slot);
-          u32 nd = ABM_AGENT_LOAD(rd + lane), npa = ABM_AGENT_LOAD(rp + lane), npb = ABM_AGENT_LOAD(rp + 64 + lane);
-          for (u32 k = 0; k < n_chunks && !S.sure_ambig; ++k) {
-            const u32 dd = nd, pa = npa, pb = npb;
-            if (k + 1 < n_chunks) {
-              nd = ABM_AGENT_LOAD(rd + (k + 1) * 64u + lane);
-              npa = ABM_AGENT_LOAD(rp + (k + 1) * 128u + lane);
-              npb = ABM_AGENT_LOAD(rp + (k + 1) * 128u + 64u + lane);
-            }
-            const int ha = static_cast<int>(dd & 0xFFFFu), hb = static_cast<int>(dd >> 16);
-#ifdef ABM_HELP_SELFCHECK  // test build: every result read back is recomputed by the owner and must agree
-            {
-              int xa, xb;
-              u32 ya, yb;
-              filter_chunk(ix, lds, qpk, idx3, nwords, sg, g0, total, c_base + k * kHelpChunk, xa, xb, ya, yb);
-              if (__any(xa != ha || xb != hb || (xa != 0x7fff && ya != pa) || (xb != 0x7fff && yb != pb))) hw->mismatch = true;
-            }
-#endif
-            replay(ha != 0x7fff, ha, ha, pa);
-            if (!S.sure_ambig) replay(hb != 0x7fff, hb, hb, pb);
-          }
-        }
-        ABM_STAMP(td);
-        if (TIMED) wt.t_stream += td - tc;
-        continue;
-      }
-    }
-
     int carry = 0;
     // Candidates are taken 128 at a time, two per lane (c0+lane and c0+64+lane): both index entries,
     // then both genome windows, are in flight together, which halves the dependent round trips of a
@@ -832,129 +680,190 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       if (nva) nea = ta3 ? idx3[ea_at] : ix.index[ea_at];
       if (nvb) neb = tb3 ? idx3[eb_at] : ix.index[eb_at];
     };
-    if (total) fetch_entries(0);
-    for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
-      ABM_STAMP(tc);
-      const bool va = nva, vb = nvb;
-      const int oa = noa, ob = nob;
-      const u32 ea = nea, eb = neb;
-      if (c0 + 128 < total) fetch_entries(c0 + 128);
-      const u32 pa = ea - (g0 + static_cast<u32>(oa)), pb = eb - (g0 + static_cast<u32>(ob));
-      // the same genome position is proposed again and again (neighbouring seeds of one hit, the
-      // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
-      // saves the 1-2 HBM lines of a window.  Distances are a pure function of (pos, encoding),
-      // so a cache hit is exact by construction.
-      u64 *slot_a = lds.pcache + ((pa * 2654435761u) >> (32 - kPosCacheBits));
-      u64 *slot_b = lds.pcache + ((pb * 2654435761u) >> (32 - kPosCacheBits));
-      const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
-      const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
-      int ha, hma, hb, hmb;
-      if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
-        hamming_coop<kRoundsHere>(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
-        hma = ha; hmb = hb;
+    // A block with very many candidates while a wave of this workgroup is idle becomes a series of jobs (at
+    // most the result buffer's capacity each) whose chunks helpers claim from the back (HelpWave); otherwise
+    // -- always, in a one-wave workgroup -- the loop below is the plain sequential one.
+    bool shared = false;
+    if constexpr (HELP) shared = hw != nullptr && total >= kHelpMin && hw->wanted();
+    const u32 per_job = shared ? hw->h.cap : total;
+    if (total && !shared) fetch_entries(0);
+    for (u32 c_base = 0; c_base < total && !S.sure_ambig; c_base += per_job) {
+      const u32 n_chunks = (min(per_job, total - c_base) + kHelpChunk - 1) / kHelpChunk;
+      bool computing = true;  // false once the helpers own the rest of this job's chunks
+      if constexpr (HELP) if (shared) {
+        // open the job: segment table to this wave's slot, then the claim word (release order)
+        u32 *sv = hw->seg(hw->slot) + lane;
+        sv[0] = sg.start_a; sv[64] = sg.na; sv[128] = sg.lo2; sv[192] = sg.nb; sv[256] = sg.lo3;
+        if (lane == 0) {
+          hw->info_w[0] = enc | (g_to_a ? 256u : 0u); hw->info_w[1] = g0; hw->info_w[2] = total; hw->info_w[3] = c_base; hw->info_w[4] = L;
+          ABM_WG_STORE(hw->done_w, 0u);
+        }
+        ++hw->epoch;
+        wg_release();
+        if (lane == 0) {
+          ABM_WG_STORE(hw->epoch_w, hw->epoch);
+          ABM_WG_STORE(hw->span, n_chunks << 16);
+        }
+        carry = seg_before(sg, c_base);
+        fetch_entries(c_base);
       }
-      else
-        hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
-      if (hit_a) { ha = static_cast<i16>(static_cast<u16>(ca >> 32)); hma = static_cast<i16>(static_cast<u16>(ca >> 48)); }
-      if (hit_b) { hb = static_cast<i16>(static_cast<u16>(cb >> 32)); hmb = static_cast<i16>(static_cast<u16>(cb >> 48)); }
-      if (va && !hit_a)
-        *slot_a = static_cast<u64>(pa) | (static_cast<u64>(static_cast<u16>(ha)) << 32) | (static_cast<u64>(static_cast<u16>(hma)) << 48);
-      if (vb && !hit_b)
-        *slot_b = static_cast<u64>(pb) | (static_cast<u64>(static_cast<u16>(hb)) << 32) | (static_cast<u64>(static_cast<u16>(hmb)) << 48);
-      if (!va) { ha = hma = 0x7fff; }
-      if (!vb) { hb = hmb = 0x7fff; }
-      wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
-      wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * nwords;
-      wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
-      ABM_STAMP(td);
-      if (TIMED) wt.t_stream += td - tc;
-      replay(va, ha, hma, pa);
-      if (!S.sure_ambig) replay(vb, hb, hmb, pb);
-      ABM_STAMP(tc);
-      if (TIMED) wt.t_replay += tc - td;
+      for (u32 k = 0; k < n_chunks && !S.sure_ambig; ++k) {
+        const u32 c0 = c_base + k * kHelpChunk;
+        ABM_STAMP(tc);
+        if constexpr (HELP) if (shared && computing) {  // take chunk k from the front, if the helpers have left it
+          u32 old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(hw->span, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          old = static_cast<u32>(uni(static_cast<int>(old)));
+          computing = (old & 0xFFFFu) < (old >> 16);
+        }
+        int ha, hma, hb, hmb;
+        u32 pa, pb;
+        bool va, vb;
+        if (computing) {
+          va = nva; vb = nvb;
+          const int oa = noa, ob = nob;
+          const u32 ea = nea, eb = neb;
+          if (c0 + 128 < total) fetch_entries(c0 + 128);
+          pa = ea - (g0 + static_cast<u32>(oa));
+          pb = eb - (g0 + static_cast<u32>(ob));
+          // the same genome position is proposed again and again (neighbouring seeds of one hit, the
+          // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
+          // saves the 1-2 HBM lines of a window.  Distances are a pure function of (pos, encoding),
+          // so a cache hit is exact by construction.
+          u64 *slot_a = lds.pcache + ((pa * 2654435761u) >> (32 - kPosCacheBits));
+          u64 *slot_b = lds.pcache + ((pb * 2654435761u) >> (32 - kPosCacheBits));
+          const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
+          const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
+          if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
+            hamming_coop(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+            hma = ha; hmb = hb;
+          }
+          else
+            hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
+          if (hit_a) { ha = static_cast<i16>(static_cast<u16>(ca >> 32)); hma = static_cast<i16>(static_cast<u16>(ca >> 48)); }
+          if (hit_b) { hb = static_cast<i16>(static_cast<u16>(cb >> 32)); hmb = static_cast<i16>(static_cast<u16>(cb >> 48)); }
+          if (va && !hit_a)
+            *slot_a = static_cast<u64>(pa) | (static_cast<u64>(static_cast<u16>(ha)) << 32) | (static_cast<u64>(static_cast<u16>(hma)) << 48);
+          if (vb && !hit_b)
+            *slot_b = static_cast<u64>(pb) | (static_cast<u64>(static_cast<u16>(hb)) << 32) | (static_cast<u64>(static_cast<u16>(hmb)) << 48);
+          if (!va) { ha = hma = 0x7fff; }
+          if (!vb) { hb = hmb = 0x7fff; }
+          wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
+          wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * nwords;
+          wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
+        }
+        else {
+          // a helper computed this chunk: wait for its flag, then take distance + position from the buffer
+          if constexpr (HELP) {
+            const u32 *fl = hw->flags(hw->slot) + k;
+            for (u32 spins = 0; static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(fl)))) != hw->epoch; ++spins) {
+              if (spins > kHelpSpinLimit) { hw->failed = true; break; }
+              __builtin_amdgcn_s_sleep(4);
+            }
+            wg_acquire();
+            const u32 dd = ABM_WG_LOAD(hw->res_d(hw->slot) + k * 64u + lane);
+            pa = ABM_WG_LOAD(hw->res_p(hw->slot) + k * 128u + lane);
+            pb = ABM_WG_LOAD(hw->res_p(hw->slot) + k * 128u + 64u + lane);
+            ha = hma = static_cast<int>(dd & 0xFFFFu);
+            hb = hmb = static_cast<int>(dd >> 16);
+            va = ha != 0x7fff; vb = hb != 0x7fff;
+#ifdef ABM_HELP_SELFCHECK  // test build: the owner recomputes every chunk it takes from the buffer
+            {
+              int xa, xb;
+              u32 ya, yb;
+              filter_chunk(ix, lds, qpk, idx3, nwords, sg, g0, total, c0, xa, xb, ya, yb);
+              if (__any(xa != ha || xb != hb || (xa != 0x7fff && ya != pa) || (xb != 0x7fff && yb != pb))) hw->mismatch = true;
+            }
+#endif
+          }
+          else { va = vb = false; ha = hma = hb = hmb = 0x7fff; pa = pb = 0; }
+        }
+        ABM_STAMP(td);
+        if (TIMED) wt.t_stream += td - tc;
+        replay(va, ha, hma, pa);
+        if (!S.sure_ambig) replay(vb, hb, hmb, pb);
+        ABM_STAMP(tc);
+        if (TIMED) wt.t_replay += tc - td;
+      }
+      if constexpr (HELP) if (shared) {
+        // close the job: no more claims, then wait for the chunks helpers still have in hand (their stores
+        // must not land in the next job's buffer)
+        u32 old = 0;
+        if (lane == 0) old = __hip_atomic_exchange(hw->span, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = static_cast<u32>(uni(static_cast<int>(old)));
+        const u32 theirs = n_chunks - min(n_chunks, old >> 16);
+        for (u32 spins = 0; static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(hw->done_w)))) < theirs; ++spins) {
+          if (spins > kHelpSpinLimit) { hw->failed = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
     }
   }
 }
 
-// A retired wave (no reads left) works for the owners that asked for help until every wave of the
-// launch has retired.  It attaches to one registered owner at a time (spread by its retirement
-// number), polls that owner's ticket -- one word, with sleeps in between: idle pollers must not
-// load the memory system the owners are waiting on -- and claims chunks of whatever job is open.
-__device__ __attribute__((noinline)) void help_others(DevIndex ix, WaveLds lds, const u64 *packed, HelpWave hw) {
+// A wave with no reads left stays and works for its block-mates until all of them are done: it scans
+// their claim words, takes a chunk from the back of an open job, and computes it against the owner's
+// read -- in place in the owner's LDS -- with more window loads in flight than the mapping loop affords.
+template <u32 NW>
+__device__ __forceinline__ void help_block_mates(const DevIndex &ix, const WaveLds &lds, BlockCtl<NW> *bc, unsigned char *wave_lds0,
+                                                 u32 per_wave_bytes, u32 my_wave, const HelpWave &hw, WorkTally &wt) {
   const int lane = lane_id();
-  if (hw.h.ctl == nullptr) return;
-  u32 my_seq = 0;
-  if (lane == 0) my_seq = ABM_AGENT_ADD(hw.h.ctl, 1u);
-  my_seq = static_cast<u32>(uni(static_cast<int>(my_seq)));
-  u32 attempt = 0, idle_polls = 0, n_reg = 0, s = 0xFFFFFFFFu;
-  u32 cur_slot = 0xFFFFFFFFu, cur_epoch = 0;
-  unsigned long long n_done = 0;
-  // the job being worked on (wave-uniform header + this lane's segment record)
+  if (lane == 0) __hip_atomic_fetch_add(&bc->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (hw.h.seg == nullptr) return;
+  u32 cur_mate = 0xFFFFFFFFu, cur_epoch = 0;
   Segs sg = {0, 0, 0, 0, 0};
   u32 j_enc = 0, j_g0 = 0, j_total = 0, j_cbase = 0, j_L = 0;
   bool j_g2a = false;
   for (u32 spins = 0; spins < kHelpSpinLimit; ++spins) {
-    if (s == 0xFFFFFFFFu) {  // (re)attach: look at the launch-wide words only here
-      if (static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(hw.h.ctl)))) >= hw.grid) break;  // nobody owns a read any more
-      n_reg = static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(hw.h.ctl + 32))));
-      if (n_reg == 0) { __builtin_amdgcn_s_sleep(127); continue; }
-      const u32 s1 = static_cast<u32>(uni(static_cast<int>(ABM_AGENT_LOAD(hw.h.ctl + 64 + (my_seq + attempt) % n_reg))));
-      if (s1 == 0) { __builtin_amdgcn_s_sleep(32); continue; }  // registration in flight
-      s = s1 - 1;
-      idle_polls = 0;
+    if (static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(&bc->retired)))) >= NW) break;
+    bool worked = false;
+    for (u32 m = 0; m < NW; ++m) {
+      if (m == my_wave) continue;
+      u32 got = 0xFFFFFFFFu;
+      if (lane == 0) {
+        u32 old = ABM_WG_LOAD(&bc->span[m]);
+        if ((old & 0xFFFFu) < (old >> 16) &&
+            __hip_atomic_compare_exchange_strong(&bc->span[m], &old, old - 0x10000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+          got = (old >> 16) - 1;
+      }
+      got = static_cast<u32>(uni(static_cast<int>(got)));
+      if (got == 0xFFFFFFFFu) continue;
+      wg_acquire();
+      const u32 e = static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(&bc->epoch[m]))));
+      const u32 mate_slot = hw.slot - my_wave + m;
+      if (m != cur_mate || e != cur_epoch) {  // a job not seen yet: its header (LDS) and segment table (the mate's slot)
+        const u32 i0 = ABM_WG_LOAD(&bc->info[m][0]);
+        j_enc = i0 & 255u; j_g2a = (i0 & 256u) != 0;
+        j_g0 = ABM_WG_LOAD(&bc->info[m][1]); j_total = ABM_WG_LOAD(&bc->info[m][2]);
+        j_cbase = ABM_WG_LOAD(&bc->info[m][3]); j_L = ABM_WG_LOAD(&bc->info[m][4]);
+        const u32 *sv = hw.seg(mate_slot) + lane;
+        sg.start_a = ABM_WG_LOAD(sv);
+        sg.na = ABM_WG_LOAD(sv + 64);
+        sg.lo2 = ABM_WG_LOAD(sv + 128);
+        sg.nb = ABM_WG_LOAD(sv + 192);
+        sg.lo3 = ABM_WG_LOAD(sv + 256);
+        cur_mate = m; cur_epoch = e;
+      }
+      // the owner's read, where it lies: the packed encodings open every wave's LDS region
+      const u64 *mate_qpk = reinterpret_cast<const u64 *>(wave_lds0 + static_cast<size_t>(m) * per_wave_bytes) + j_enc * lds.W;
+      int ha, hb;
+      u32 pa, pb;
+      filter_chunk(ix, lds, mate_qpk, j_g2a ? ix.index_a : ix.index_t, (j_L + 15) >> 4, sg, j_g0, j_total,
+                   j_cbase + got * kHelpChunk, ha, hb, pa, pb);
+      ABM_WG_STORE(hw.res_d(mate_slot) + got * 64u + lane, (static_cast<u32>(ha) & 0xFFFFu) | (static_cast<u32>(hb) << 16));
+      ABM_WG_STORE(hw.res_p(mate_slot) + got * 128u + lane, pa);
+      ABM_WG_STORE(hw.res_p(mate_slot) + got * 128u + 64u + lane, pb);
+      wg_release();
+      if (lane == 0) ABM_WG_STORE(hw.flags(mate_slot) + got, e);
+      wg_release();
+      if (lane == 0) __hip_atomic_fetch_add(&bc->done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      wt.cands += (ha != 0x7fff ? 1u : 0u) + (hb != 0x7fff ? 1u : 0u);
+      wt.words += ((ha != 0x7fff ? 1u : 0u) + (hb != 0x7fff ? 1u : 0u)) * ((j_L + 15) >> 4);
+      worked = true;
+      spins = 0;
     }
-    u64 t = 0;
-    if (lane == 0) t = ABM_AGENT_LOAD(hw.tick(s));
-    t = uni64(t);
-    const u64 epoch = t >> 44;
-    const u32 n_chunks = static_cast<u32>(t >> 22) & ((1u << 22) - 1), next = static_cast<u32>(t) & ((1u << 22) - 1);
-    if (epoch == kTickRetired) {
-      ++attempt; s = 0xFFFFFFFFu;
-      if (attempt % max(n_reg, 1u) == 0) __builtin_amdgcn_s_sleep(127);
-      continue;
-    }
-    if (epoch == 0 || next >= n_chunks) {
-      // nothing open here right now: the owner is narrowing or replaying, its next job comes soon.
-      // After a while look elsewhere (owners differ in how much work they have left).
-      __builtin_amdgcn_s_sleep(64);
-      if (++idle_polls >= 256) { ++attempt; s = 0xFFFFFFFFu; }
-      continue;
-    }
-    idle_polls = 0;
-    const u64 got = hw.claim(s);
-    const u64 g_epoch = got >> 44;
-    const u32 g_n = static_cast<u32>(got >> 22) & ((1u << 22) - 1), idx = static_cast<u32>(got) & ((1u << 22) - 1);
-    if (g_epoch == kTickRetired || g_epoch == 0 || idx >= g_n) continue;
-    if (s != cur_slot || static_cast<u32>(g_epoch) != cur_epoch) {  // a job not seen yet: fetch its descriptor
-      acquire_agent();
-      const u32 *d = hw.desc(s);
-      const u32 hv = lane < 8 ? ABM_AGENT_LOAD(d + lane) : 0u;
-      const u64 jr = (static_cast<u64>(rdlane(hv, 1)) << 32) | rdlane(hv, 0);
-      const u32 e = rdlane(hv, 2);
-      j_enc = e & 255u; j_g2a = (e & 256u) != 0;
-      j_g0 = rdlane(hv, 3); j_total = rdlane(hv, 4); j_cbase = rdlane(hv, 5); j_L = rdlane(hv, 6);
-      const u32 *sv = d + kHelpHeaderWords + lane;
-      sg.start_a = ABM_AGENT_LOAD(sv);
-      sg.na = ABM_AGENT_LOAD(sv + 64);
-      sg.lo2 = ABM_AGENT_LOAD(sv + 128);
-      sg.nb = ABM_AGENT_LOAD(sv + 192);
-      sg.lo3 = ABM_AGENT_LOAD(sv + 256);
-      // the owner's read, in the encoding of this call, into this wave's (idle) LDS
-      const u64 *src = packed + (jr * 4 + j_enc) * lds.W;
-      __syncthreads();
-      for (u32 k = lane; k < lds.W; k += 64) lds.qpk[j_enc * lds.W + k] = src[k];
-      __syncthreads();
-      cur_slot = s; cur_epoch = static_cast<u32>(g_epoch);
-    }
-    int ha, hb;
-    u32 pa, pb;
-    filter_chunk(ix, lds, lds.qpk + j_enc * lds.W, j_g2a ? ix.index_a : ix.index_t, (j_L + 15) >> 4, sg, j_g0, j_total,
-                 j_cbase + idx * kHelpChunk, ha, hb, pa, pb);
-    hw.store_chunk(s, idx, ha, hb, pa, pb);
-    ++n_done;
-    spins = 0;
+    if (!worked) __builtin_amdgcn_s_sleep(32);
   }
-  if (hw.h.stats != nullptr && lane == 0 && n_done) ABM_AGENT_ADD(hw.h.stats + 3, n_done);
 }
 
 // =============================================================================
@@ -1111,7 +1020,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   }
   emit(run, op);
   const int clip_head = (r + c) - (bw - 1);
-  __syncthreads();
+  wave_sync();
   // final order: [head clip] reversed(ops) [tail clip]
   const u32 full = n + (clip_head > 0) + (clip_tail > 0);  // the CIGAR's op count
   u32 *dst = cig_out;
@@ -1284,14 +1193,14 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
     s += two ? 2 : 1;
   }
   stage_windows(ix, lds, first, s - first, md);
-  __syncthreads();
+  wave_sync();
   const int t_start = max(0, bw_min - 1);
   const bool even = ((t_start - my_o) & 1) == 0;  // which of the lane's jobs is due on even steps
   ja.jl = jb.jl = my_o;
   int bp, bq;
   wavefront_pair(lds, even ? ja : jb, even ? jb : ja, even ? 0 : 1, even ? 1 : 0, L, bw_min, bw_max, bp, bq);
   lds.lbest[lane] = (even ? bp : bq) | ((even ? bq : bp) << 16);
-  __syncthreads();
+  wave_sync();
   int base = 0, mine = 0;
   for (int k = first; k < s;) {
     const bool two = k + 1 < s;
@@ -1307,9 +1216,9 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
     base += max(bwa, bwb);
     k += two ? 2 : 1;
   }
-  __syncthreads();
+  wave_sync();
   lds.lbest[lane] = mine;
-  __syncthreads();
+  wave_sync();
   return s;
 }
 
@@ -1354,7 +1263,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
     lds.jpos[rank] = e_pos;
     lds.jdf[rank] = (static_cast<u32>(e_d) << 16) | e_flags;
   }
-  __syncthreads();
+  wave_sync();
 
   int top = 0;
   u32 top_pos = 0, b_pos = 0, b_flags = 0;
@@ -1375,7 +1284,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
         if (sc == perfect ? pos != top_pos : gap > 3u) b_flags |= kFlagAmbig;
       }
     }
-    __syncthreads();
+    wave_sync();
   }
   best.diffs = 0x7fff; best.flags = static_cast<u16>(b_flags); best.pos = 0;
   if (b_pos == 0)
@@ -1391,9 +1300,9 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
     job.t0nib = static_cast<int>(t_beg & 15u);
   }
   if (lane == 0) { lds.jpos[0] = b_pos; lds.jdf[0] = (static_cast<u32>(b_diffs) << 16) | (b_flags & 0xFFFFu); }
-  __syncthreads();
+  wave_sync();
   stage_windows(ix, lds, 0, 1, md);
-  __syncthreads();
+  wave_sync();
   int bv, brow;
   wavefront<true>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
   // first maximum in row-major order: max value, then smallest row, then smallest column
@@ -1404,12 +1313,12 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   const int br = static_cast<int>(0xFFFFu - static_cast<u32>((topk >> 8) & 0xFFFFu));
   const int bc = static_cast<int>(0xFFu - static_cast<u32>(topk & 0xFFu));
   const int sc = static_cast<i16>(static_cast<int>(topk >> 32));
-  __syncthreads();
+  wave_sync();
   u32 alen = 0, pos = b_pos;
   int n_ins = 0, n_del = 0;
   wave_cigar(lds.tb, lds.ctmp, static_cast<int>(L), b_diffs, md, sc, br, bc, cig_out, sink, n_ops,
              n_ins, n_del, alen, pos, overflow);
-  __syncthreads();
+  wave_sync();
   // NM from the score found by the scoring pass (best_scr), as the reference does
   const int nm = edit_distance(top, alen, n_ins, n_del);
   if (long_enough(alen, static_cast<u32>(Ls), ix.min_len) && nm <= md) {

@@ -71,7 +71,7 @@ struct PeSet {
     const int worst = static_cast<i16>(0.4 * readlen);
     top = static_cast<u32>(worst) << 16;  // sentinel, handle 0 -> pos 0
     if (lane_id() == 0) { lpos[0] = 0; ld[0] = static_cast<i16>(worst); }
-    __syncthreads();
+    wave_sync();
     sz = 1;
     capacity = static_cast<int>(kPeCapSmall);
     cutoff = worst;
@@ -102,7 +102,7 @@ struct PeSet {
       sure_ambig = true;
       return 0;
     }
-    __syncthreads();
+    wave_sync();
     heapify();
     return todo & __ballot(mine && rank >= take);
   }
@@ -134,7 +134,7 @@ struct PeSet {
     if (lane < stop) heap[node] = pk;
     else if (lane == stop) heap[node] = key;
     if (((hole + 1) >> stop) == 1) top = key;
-    __syncthreads();
+    wave_sync();
   }
   // std::pop_heap on [0,n) (libstdc++ __adjust_heap: the hole follows the larger child -- the
   // right one on ties -- down to a leaf, then the last element sifts up from there); returns the
@@ -189,7 +189,7 @@ struct PeSet {
     if (lane < ts) heap[pidx] = pnew;
     else if (lane == ts) heap[pidx] = vk;
     top = ts == 0 ? vk : rdlane(pnew, 0);
-    __syncthreads();
+    wave_sync();
     return freed;
   }
   // pe_candidates::update, :824-842, on the heap
@@ -302,13 +302,13 @@ template <bool BIG> struct PeWave {
     }
     need_big |= P.overflow;
     const int n = P.sz;
-    __syncthreads();
+    wave_sync();
     if (P.heaped) freeze_heap_order(which, n);
     lsz[which] = n;
     max_set = max(max_set, n);
     heap_order[which] = P.heaped || n <= 1;
     worth[which] = n != static_cast<int>(kPeCapLarge) || P.cutoff != 0;  // should_align, :799-802
-    __syncthreads();
+    wave_sync();
   }
 
   // the list in the heap's array order (what best_single replays if no mating happens, :1715-1720)
@@ -319,18 +319,18 @@ template <bool BIG> struct PeWave {
     if (n <= 64) {
       u32 e = 0, p = 0;
       if (lane < n) { e = P.heap[lane]; p = lp[e & 0x7FFFu]; }
-      __syncthreads();
+      wave_sync();
       if (lane < n) { lp[lane] = p; ldv[lane] = static_cast<i16>(static_cast<int>(e) >> 16); }
     }
     else {  // through the per-wave scratch table
       for (int i = lane; i < n; i += 64) pl.tmp[i] = lp[P.heap[i] & 0x7FFFu];
-      __syncthreads();
+      wave_sync();
       for (int i = lane; i < n; i += 64) {
         lp[i] = pl.tmp[i];
         ldv[i] = static_cast<i16>(static_cast<int>(P.heap[i]) >> 16);
       }
     }
-    __syncthreads();
+    wave_sync();
   }
 
   // a list still in arrival order, put into the heap's array order after the fact (only needed
@@ -355,7 +355,7 @@ template <bool BIG> struct PeWave {
     int m = 1;
     while (m < n) m <<= 1;
     for (int i = lane; i < m; i += 64) buf[i] = i < n ? ld_list<BIG>(pl.lpos[which] + i) : 0xFFFFFFFFu;
-    __syncthreads();
+    wave_sync();
     // one compare-exchange pass of the bitonic network at distance j inside stage k, over
     // elements [0, cnt) of `v` whose global indices start at `base`
     auto pass = [&](u32 *v, int cnt, int base, int k, int j) {
@@ -367,7 +367,7 @@ template <bool BIG> struct PeWave {
           if ((x > y) == up) { v[i] = y; v[p] = x; }
         }
       }
-      __syncthreads();
+      wave_sync();
     };
     if (!BIG) {
       for (int k = 2; k <= m; k <<= 1)
@@ -384,11 +384,11 @@ template <bool BIG> struct PeWave {
       auto local = [&](int k_from, int k_to, int j_top) {  // stages k_from..k_to, distances j_top..1, block by block
         for (int b = 0; b < m; b += C) {
           for (int i = lane; i < C; i += 64) blk[i] = buf[b + i];
-          __syncthreads();
+          wave_sync();
           for (int k = k_from; k <= k_to; k <<= 1)
             for (int j = min(k >> 1, j_top); j > 0; j >>= 1) pass(blk, C, b, k, j);
           for (int i = lane; i < C; i += 64) buf[b + i] = blk[i];
-          __syncthreads();
+          wave_sync();
         }
       };
       local(2, C, C >> 1);  // stages that fit a block entirely
@@ -416,7 +416,7 @@ template <bool BIG> struct PeWave {
       out += __popcll(kept);
     }
     lsz[which] = out;
-    __syncthreads();
+    wave_sync();
   }
 
   // first index whose position is >= key (lists are sorted here)
@@ -455,7 +455,7 @@ template <bool BIG> struct PeWave {
         pl.lsc[which][i] = static_cast<i16>(mark);
       }
     }
-    __syncthreads();
+    wave_sync();
     // pass 2: run the marked entries through the wavefront DP, up to kSeCap jobs at a time
     #pragma unroll
     for (int which = 0; which < 2; ++which) {
@@ -477,7 +477,7 @@ template <bool BIG> struct PeWave {
             pl.lsc[which][i] = 0;  // claimed
           }
           n_jobs += take;
-          __syncthreads();
+          wave_sync();
           if (take < cnt) break;  // list full: the rest of this chunk is picked up next time
           cursor += 64;
         }
@@ -487,7 +487,7 @@ template <bool BIG> struct PeWave {
           s = score_round(a.ix, lds, first, n_jobs, static_cast<int>(L[end]), md, static_cast<int>(end * 4 * lds.W));
           if (lane < s - first) pl.lsc[which][pl.jidx[first + lane]] = static_cast<i16>(lds.lbest[lane]);
           n_aln += static_cast<u32>(s - first);
-          __syncthreads();
+          wave_sync();
         }
       }
     }
@@ -517,9 +517,9 @@ template <bool BIG> struct PeWave {
         job.t0nib = static_cast<int>(t_beg & 15u);
       }
       if (lane == 0) { lds.jpos[0] = pos; lds.jdf[0] = (static_cast<u32>(d) << 16) | (flags & 0xFFFFu); }
-      __syncthreads();
+      wave_sync();
       stage_windows(a.ix, lds, 0, 1, md);
-      __syncthreads();
+      wave_sync();
       int bv, brow;
       wavefront<true>(lds, job, Ln, bw, bw, bv, brow);
       const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
@@ -529,10 +529,10 @@ template <bool BIG> struct PeWave {
       const int br = static_cast<int>(0xFFFFu - static_cast<u32>((topk >> 8) & 0xFFFFu));
       const int bc = static_cast<int>(0xFFu - static_cast<u32>(topk & 0xFFu));
       const int sc = static_cast<i16>(static_cast<int>(topk >> 32));
-      __syncthreads();
+      wave_sync();
       wave_cigar(lds.tb, lds.ctmp, Ln, d, md, sc, br, bc, cig_out, sink(), nops, n_ins, n_del, alen, pos,
                  overflow);
-      __syncthreads();
+      wave_sync();
     }
     d = edit_distance(scoring, alen, n_ins, n_del);
     n_ops[end] = nops;
@@ -596,9 +596,9 @@ template <bool BIG> struct PeWave {
       int carry = 0;
       for (u32 c0 = 0; c0 < total && !best.sure_ambig(); c0 += 64) {
         lds.mark[lane] = 0;
-        __syncthreads();
+        wave_sync();
         if (cnt && start - c0 < 64u) lds.mark[start - c0] = static_cast<u16>(lane + 1);
-        __syncthreads();
+        wave_sync();
         const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
         const int owner = m ? m - 1 : carry;
         carry = rdlane(owner, 63);
@@ -652,7 +652,7 @@ template <bool BIG> struct PeWave {
           }
         }
         last_sa = rdlane(scr1, static_cast<int>(min(63u, total - 1 - c0)));
-        __syncthreads();
+        wave_sync();
       }
     }
     if (keep_pa == 0)
@@ -746,7 +746,7 @@ template <bool BIG> struct PeWave {
         for (int i = lane_id(); i < n; i += 64) { lp[i] = pl.lpos[which][i]; ldv[i] = pl.ld[which][i]; }
         if (lane_id() == 0) { u32 *h = log_head(seg); h[0] = static_cast<u32>(n); h[1] = lflags[which]; h[2] = static_cast<u32>(ends[which]); }
       }
-      __syncthreads();
+      wave_sync();
     }
     else {
       // best_single: every entry of each set, in array order, into that end's single-end set
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
       const u64 *src = (e ? a.packed2 : a.packed1) + r * 4 * a.W;
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[e * 4 * a.W + k] = src[k];
     }
-    __syncthreads();
+    wave_sync();
     for (u32 e8 = 0; e8 < 8; ++e8)
       for (u32 wb = 0; wb < a.WB; ++wb) {
         const u32 j = wb * 64 + lane, Le = e8 < 4 ? w.L[0] : w.L[1];
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
         const u64 word = __ballot(b);
         if (lane == 0) lds.qbits[e8 * a.WB + wb] = word;
       }
-    __syncthreads();
+    wave_sync();
     #pragma unroll
     for (int e = 0; e < 2; ++e)  // 44-46 bases: seeds reach past the end of the read (see ghost_bits)
       if (w.L[e] >= a.ix.min_len && w.L[e] < max(a.ix.window, w.L[e] >> 1) + kKeyWeight - 1)
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     h1.diffs = static_cast<i16>(0.4 * w.L[0]); h1.flags = 0; h1.pos = 0;
     h2.diffs = static_cast<i16>(0.4 * w.L[1]); h2.flags = 0; h2.pos = 0;
     if (!best.should_report(a.allow_ambig != 0)) {  // single-end fallback at half the error budget
-      if (BIG) { __syncthreads(); w.replay_singles(); }
+      if (BIG) { wave_sync(); w.replay_singles(); }
       long long tf0 = 0, tf1 = 0;
       ABM_STAMP(tf0);
       #pragma unroll
@@ -962,10 +962,10 @@ __global__ __launch_bounds__(256) void big_hist_kernel(const u8 *__restrict__ ne
                                                        u64 n, u32 *__restrict__ class_count) {
   __shared__ u32 hist[33];
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  __syncthreads();
+  wave_sync();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r < n && need_big[r]) atomicAdd(&hist[cls[r]], 1u);
-  __syncthreads();
+  wave_sync();
   if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], hist[threadIdx.x]);
 }
 __global__ void big_bases_kernel(u32 *class_count /*[33] in: counts, out: start of each class*/, u32 *total) {
@@ -980,14 +980,14 @@ __global__ __launch_bounds__(256) void big_scatter_kernel(const u8 *__restrict__
                                                           u32 *__restrict__ subset) {
   __shared__ u32 hist[33], base[33];
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  __syncthreads();
+  wave_sync();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool take = r < n && need_big[r];
   u32 c = 0, rank = 0;
   if (take) { c = cls[r]; rank = atomicAdd(&hist[c], 1u); }
-  __syncthreads();
+  wave_sync();
   if (threadIdx.x < 33 && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], hist[threadIdx.x]);
-  __syncthreads();
+  wave_sync();
   if (take) subset[base[c] + rank] = static_cast<u32>(r);
 }
 

@@ -434,8 +434,9 @@ def run_e2e(args, idx, fasta, L):
     import shutil
     import subprocess
     cli = os.path.join(ROOT, "abismal_amd", "abismal-amd")
-    if not os.path.exists(fasta):
-        return {"skipped": f"{fasta} is gone (index built by an earlier run without the e2e leg)"}
+    if not os.path.exists(fasta):  # (an earlier run without this leg removed it: the generator is deterministic)
+        import torch
+        synth_genome_fasta(fasta, args.genome_mbp, 1234, torch.device("cuda", 0))
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else args.workdir
     wd = os.path.join(shm, f"abismal_e2e_{os.getpid()}")
     os.makedirs(wd, exist_ok=True)

@@ -253,10 +253,14 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
 
-  // In-block help (HelpWave): the cooperative-filter kernel runs se_block_waves() waves per workgroup whose idle
-  // waves take filter chunks of their block-mates' heaviest reads; ABM_SE_HELP=0 selects one-wave workgroups.
-  abm::u32 block_waves = a.G != 0 ? abm::se_block_waves() : 1u;
-  if (const char *e = std::getenv("ABM_SE_HELP")) if (e[0] == '0') block_waves = 1;
+  // In-block help (HelpWave): the cooperative-filter kernel can run se_block_waves() waves per workgroup whose idle
+  // waves take filter chunks of their block-mates' heaviest reads.  Bit-exact and tested, but OFF by default
+  // (ABM_SE_HELP=1 switches it on): measured on MI355X at hg38 scale (scripts/r02_inblock.sh,
+  // profiles/r02_exp_inblock_help.log) the helpers do compute two thirds of the shared chunks, yet a 1 M-read launch
+  // takes 247 ms with it against 225 ms without (what is left of a heavy read -- the ordered replay of its survivors
+  // into the candidate set -- is serial), and the extra registers cost a 10 M-read launch 10-18 % (1000-1068 ms vs 903).
+  abm::u32 block_waves = 1u;
+  if (const char *e = std::getenv("ABM_SE_HELP")) if (e[0] == '1' && a.G != 0) block_waves = abm::se_block_waves();
   if (ctx->phase_stamps) block_waves = 1;  // (the stamped diagnostic build measures the plain per-read phases)
   if (block_waves > 1) {
     const uint64_t shape2 = shape ^ (0xB10Cull << 32);

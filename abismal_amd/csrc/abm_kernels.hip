@@ -112,6 +112,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   hw.slot = blockIdx.x * NW + wave;
   hw.epoch = 0;
   hw.failed = hw.mismatch = false;
+  hw.st_jobs = hw.st_chunks = hw.st_taken = hw.st_helped = 0;
   const CigarSink sink = {a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap};
   PassCtl pc;
   pc.hw = NW > 1 ? &hw : nullptr;
@@ -124,10 +125,14 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   // reads are handed out by one device-wide counter (zeroed before every launch):
   // work per read spans four orders of magnitude, so a static split would leave
   // the launch waiting on whichever wave drew the heaviest reads
+  // A wave's FIRST read is dealt statically -- wave w of workgroup b takes position w * (workgroups) + b of the
+  // heaviest-first order, so the heaviest reads of a batch land in different workgroups (a workgroup's idle
+  // waves can only help their own block-mates) -- the rest come from the counter.
+  const u64 dealt = static_cast<u64>(gridDim.x) * NW;
   auto next_read = [&]() -> u64 {
     unsigned long long v = 0;
     if (lane == 0) {
-      v = atomicAdd(a.next_read, 1ull);
+      v = atomicAdd(a.next_read, 1ull) + dealt;
       // exactly one wave draws the first index past the end: from here on only reads already in
       // flight are left, and the host may let the next batch's kernel in
       if (v == n_items && a.drained) __hip_atomic_store(a.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -135,7 +140,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) |
            static_cast<u32>(uni(static_cast<int>(v)));
   };
-  u64 r_next = next_read();
+  u64 r_next = static_cast<u64>(wave) * gridDim.x + blockIdx.x;
   while (r_next < n_items) {
     const u64 r = a.order ? static_cast<u64>(a.order[first + r_next]) : r_next;
     r_next = next_read();  // fetched early; its latency hides under this read's work
@@ -205,6 +210,12 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       atomicAdd(&a.work[4], static_cast<unsigned long long>(wt.updates));
       atomicAdd(&a.work[5], static_cast<unsigned long long>(n_aln));
       atomicAdd(&a.work[11], static_cast<unsigned long long>(wsum_hits));
+      if (NW > 1 && hw.st_jobs + hw.st_helped) {
+        atomicAdd(&a.work[12], static_cast<unsigned long long>(hw.st_jobs));
+        atomicAdd(&a.work[13], static_cast<unsigned long long>(hw.st_chunks));
+        atomicAdd(&a.work[14], static_cast<unsigned long long>(hw.st_chunks - hw.st_taken));
+        atomicAdd(&a.work[15], static_cast<unsigned long long>(hw.st_helped));
+      }
       if (TIMED) {
         atomicAdd(&a.work[6], static_cast<unsigned long long>(wt.t_probe));
         atomicAdd(&a.work[7], static_cast<unsigned long long>(wt.t_stream));

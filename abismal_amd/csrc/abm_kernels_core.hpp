@@ -467,6 +467,7 @@ struct HelpWave {  // one wave's view of the help machinery
   u32 epoch;        // jobs this wave has opened
   bool failed;      // a bounded wait gave up
   bool mismatch;    // ABM_HELP_SELFCHECK build only
+  u32 st_jobs, st_chunks, st_taken, st_helped;  // diagnostics: jobs opened, their chunks, chunks its helpers took; chunks this wave computed for others
 
   __device__ __forceinline__ u32 *seg(u32 s) const { return h.seg + static_cast<u64>(kHelpSegWords) * s; }
   __device__ __forceinline__ u32 *flags(u32 s) const { return h.flags + static_cast<u64>(kHelpFlagWords) * s; }
@@ -683,29 +684,37 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     // A block with very many candidates while a wave of this workgroup is idle becomes a series of jobs (at
     // most the result buffer's capacity each) whose chunks helpers claim from the back (HelpWave); otherwise
     // -- always, in a one-wave workgroup -- the loop below is the plain sequential one.
-    bool shared = false;
-    if constexpr (HELP) shared = hw != nullptr && total >= kHelpMin && hw->wanted();
-    const u32 per_job = shared ? hw->h.cap : total;
-    if (total && !shared) fetch_entries(0);
+    // (whether a job is shared is decided job by job: a block of a heavy read lasts for many jobs, and waves
+    // retire while it runs)
+    bool may_share = false;
+    if constexpr (HELP) may_share = hw != nullptr && total >= kHelpMin;
+    const u32 per_job = may_share ? hw->h.cap : total;
+    u32 primed_for = 0xFFFFFFFFu;  // candidate index the prefetched index entries belong to
+    if (total && !may_share) { fetch_entries(0); primed_for = 0; }
     for (u32 c_base = 0; c_base < total && !S.sure_ambig; c_base += per_job) {
       const u32 n_chunks = (min(per_job, total - c_base) + kHelpChunk - 1) / kHelpChunk;
       bool computing = true;  // false once the helpers own the rest of this job's chunks
-      if constexpr (HELP) if (shared) {
-        // open the job: segment table to this wave's slot, then the claim word (release order)
-        u32 *sv = hw->seg(hw->slot) + lane;
-        sv[0] = sg.start_a; sv[64] = sg.na; sv[128] = sg.lo2; sv[192] = sg.nb; sv[256] = sg.lo3;
-        if (lane == 0) {
-          hw->info_w[0] = enc | (g_to_a ? 256u : 0u); hw->info_w[1] = g0; hw->info_w[2] = total; hw->info_w[3] = c_base; hw->info_w[4] = L;
-          ABM_WG_STORE(hw->done_w, 0u);
+      bool shared = false;
+      if constexpr (HELP) if (may_share) {
+        shared = hw->wanted();
+        if (shared) {
+          // open the job: segment table to this wave's slot, then the claim word (release order)
+          u32 *sv = hw->seg(hw->slot) + lane;
+          sv[0] = sg.start_a; sv[64] = sg.na; sv[128] = sg.lo2; sv[192] = sg.nb; sv[256] = sg.lo3;
+          if (lane == 0) {
+            hw->info_w[0] = enc | (g_to_a ? 256u : 0u); hw->info_w[1] = g0; hw->info_w[2] = total; hw->info_w[3] = c_base; hw->info_w[4] = L;
+            ABM_WG_STORE(hw->done_w, 0u);
+          }
+          ++hw->epoch;
+          ++hw->st_jobs;
+          hw->st_chunks += n_chunks;
+          wg_release();
+          if (lane == 0) {
+            ABM_WG_STORE(hw->epoch_w, hw->epoch);
+            ABM_WG_STORE(hw->span, n_chunks << 16);
+          }
         }
-        ++hw->epoch;
-        wg_release();
-        if (lane == 0) {
-          ABM_WG_STORE(hw->epoch_w, hw->epoch);
-          ABM_WG_STORE(hw->span, n_chunks << 16);
-        }
-        carry = seg_before(sg, c_base);
-        fetch_entries(c_base);
+        if (primed_for != c_base) { carry = seg_before(sg, c_base); fetch_entries(c_base); primed_for = c_base; }
       }
       for (u32 k = 0; k < n_chunks && !S.sure_ambig; ++k) {
         const u32 c0 = c_base + k * kHelpChunk;
@@ -723,7 +732,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
           va = nva; vb = nvb;
           const int oa = noa, ob = nob;
           const u32 ea = nea, eb = neb;
-          if (c0 + 128 < total) fetch_entries(c0 + 128);
+          if (c0 + 128 < total) { fetch_entries(c0 + 128); primed_for = c0 + 128; }
           pa = ea - (g0 + static_cast<u32>(oa));
           pb = eb - (g0 + static_cast<u32>(ob));
           // the same genome position is proposed again and again (neighbouring seeds of one hit, the
@@ -792,6 +801,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         if (lane == 0) old = __hip_atomic_exchange(hw->span, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = static_cast<u32>(uni(static_cast<int>(old)));
         const u32 theirs = n_chunks - min(n_chunks, old >> 16);
+        hw->st_taken += theirs;
         for (u32 spins = 0; static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(hw->done_w)))) < theirs; ++spins) {
           if (spins > kHelpSpinLimit) { hw->failed = true; break; }
           __builtin_amdgcn_s_sleep(4);
@@ -806,7 +816,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
 // read -- in place in the owner's LDS -- with more window loads in flight than the mapping loop affords.
 template <u32 NW>
 __device__ __forceinline__ void help_block_mates(const DevIndex &ix, const WaveLds &lds, BlockCtl<NW> *bc, unsigned char *wave_lds0,
-                                                 u32 per_wave_bytes, u32 my_wave, const HelpWave &hw, WorkTally &wt) {
+                                                 u32 per_wave_bytes, u32 my_wave, HelpWave &hw, WorkTally &wt) {
   const int lane = lane_id();
   if (lane == 0) __hip_atomic_fetch_add(&bc->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (hw.h.seg == nullptr) return;
@@ -859,6 +869,7 @@ __device__ __forceinline__ void help_block_mates(const DevIndex &ix, const WaveL
       if (lane == 0) __hip_atomic_fetch_add(&bc->done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       wt.cands += (ha != 0x7fff ? 1u : 0u) + (hb != 0x7fff ? 1u : 0u);
       wt.words += ((ha != 0x7fff ? 1u : 0u) + (hb != 0x7fff ? 1u : 0u)) * ((j_L + 15) >> 4);
+      ++hw.st_helped;
       worked = true;
       spins = 0;
     }

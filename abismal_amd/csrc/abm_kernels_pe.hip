@@ -962,10 +962,10 @@ __global__ __launch_bounds__(256) void big_hist_kernel(const u8 *__restrict__ ne
                                                        u64 n, u32 *__restrict__ class_count) {
   __shared__ u32 hist[33];
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  wave_sync();
+  __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r < n && need_big[r]) atomicAdd(&hist[cls[r]], 1u);
-  wave_sync();
+  __syncthreads();
   if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], hist[threadIdx.x]);
 }
 __global__ void big_bases_kernel(u32 *class_count /*[33] in: counts, out: start of each class*/, u32 *total) {
@@ -980,14 +980,14 @@ __global__ __launch_bounds__(256) void big_scatter_kernel(const u8 *__restrict__
                                                           u32 *__restrict__ subset) {
   __shared__ u32 hist[33], base[33];
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  wave_sync();
+  __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool take = r < n && need_big[r];
   u32 c = 0, rank = 0;
   if (take) { c = cls[r]; rank = atomicAdd(&hist[c], 1u); }
-  wave_sync();
+  __syncthreads();
   if (threadIdx.x < 33 && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], hist[threadIdx.x]);
-  wave_sync();
+  __syncthreads();
   if (take) subset[base[c] + rank] = static_cast<u32>(r);
 }
 

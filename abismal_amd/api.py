@@ -15,7 +15,7 @@ PAIR_DTYPE = np.dtype([("aln_score", "<i2"), ("reserved", "<i2"), ("r1", HIT_DTY
 EXPORTED_SYMBOLS = [
     "abm_last_error", "abm_default_params", "abm_index_open", "abm_index_close",
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
-    "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_destroy",
+    "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_reserve", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
 ]
@@ -75,6 +75,7 @@ def load_library():
     lib.abm_index_window.restype = C.c_uint32
     lib.abm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.abm_ctx_destroy.argtypes = [C.c_void_p]
+    lib.abm_ctx_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]
     lib.abm_max_read_length.restype = C.c_uint32
     lib.abm_ctx_reads_too_long.argtypes = [C.c_void_p]
     lib.abm_ctx_reads_too_long.restype = C.c_uint64

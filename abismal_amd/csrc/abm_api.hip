@@ -856,6 +856,53 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
   });
 }
 
+// Sizes every workspace of the host entry points for batches of up to n reads (pairs) of up to max_len bases and
+// maps a few dummy reads, so that the first real batch pays neither allocations (device arrays, pinned staging)
+// nor the loading of the kernels' code object.  Set-up like the index upload; entirely optional.
+int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    if (n == 0) return;
+    const uint32_t L = std::min<uint32_t>(std::max<uint32_t>(max_len, 48), abm::kMaxReadLen);
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      HIPCHK(hipSetDevice(ctx->device));
+      const abm::u32 W = words_for(L);
+      const uint32_t stride = 4;
+      ctx->blob.reserve(n * L); ctx->off.reserve(n + 1);
+      ctx->packed.reserve(n * 4 * W); ctx->lens.reserve(n); ctx->order.reserve(n); ctx->cls.reserve(n); ctx->class33.reserve(33);
+      ctx->cig.reserve(n * stride); ctx->cig_n.reserve(n); ctx->status.reserve(1);
+      ctx->cig_arena.reserve(std::max<size_t>(1u << 16, (paired ? 2 : 1) * n)); ctx->cig_arena_count.reserve(1);
+      ctx->h_cn.reserve(n); ctx->h_slots.reserve(n * stride); ctx->h_arena.reserve(1u << 16);
+      if (!paired) ctx->res.reserve(n);
+      else {
+        ctx->blob2.reserve(n * L); ctx->off2.reserve(n + 1);
+        ctx->packed2.reserve(n * 4 * W); ctx->lens2.reserve(n);
+        ctx->need_big.reserve(n); ctx->subset.reserve(n); ctx->subset_count.reserve(1);
+        ctx->pe_out.reserve(n * 5); ctx->cig2h.reserve(n * stride); ctx->cig_n2h.reserve(n);
+        ctx->h_cn2.reserve(n); ctx->h_slots2.reserve(n * stride);
+      }
+    }
+    // a handful of reads through the real entry point: loads the code object, sizes the launch-shape caches
+    const uint64_t m = 8;
+    std::string blob(m * L, 'A');
+    for (uint64_t i = 0; i < blob.size(); ++i) blob[i] = "ACGT"[(i * 7 + i / 3) & 3];
+    std::vector<uint64_t> off(m + 1);
+    for (uint64_t i = 0; i <= m; ++i) off[i] = i * L;
+    std::vector<abm_hit> hits(m), h2(m);
+    std::vector<abm_pair> pairs(m);
+    std::vector<uint32_t> cig(m * (L + 2)), cig2(m * (L + 2));
+    std::vector<uint64_t> co(m + 1), co2(m + 1);
+    abm_params par;
+    abm_default_params(&par);
+    int rc;
+    if (!paired) rc = abm_map_se_batch(ctx, ABM_SE_T_RICH, &par, m, blob.data(), off.data(), hits.data(), cig.data(), cig.size(), co.data());
+    else rc = abm_map_pe_batch(ctx, ABM_PE_NORMAL, &par, m, blob.data(), off.data(), blob.data(), off.data(), pairs.data(), hits.data(),
+                               h2.data(), cig.data(), co.data(), cig2.data(), co2.data(), cig.size());
+    if (rc != 0) throw std::runtime_error(g_error);
+  });
+}
+
 // CIGARs of the context's last device call that were longer than their slot (count > cig_stride): each lies
 // whole in the arena, beginning at the index its slot's first word holds.
 int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint64_t *n_ops) {

@@ -654,6 +654,39 @@ int cmd_map(int argc, char **argv) {
     }
   }
   n_gpus = static_cast<int>(ctxs.size()) / per_gpu;
+  {
+    // set-up, like the index upload: workspaces for full batches of reads as long as the input's first one, and the
+    // kernels' code loaded, before the clock of the run starts (a longer read later only makes the buffers grow)
+    uint32_t first_len = 100;
+    if (gzFile zf = gzopen(opt.reads[0].c_str(), "rb")) {
+      char line[65536];
+      if (gzgets(zf, line, sizeof(line)) && gzgets(zf, line, sizeof(line))) first_len = static_cast<uint32_t>(std::strcspn(line, "\r\n"));
+      gzclose(zf);
+    }
+    size_t reserve_reads = (opt.batch ? opt.batch : (paired ? (1u << 21) : (1u << 23))) + 256;
+    {  // (no more than the input can hold: a record is at least two sequence-length lines)
+      struct stat sb;
+      if (::stat(opt.reads[0].c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+        unsigned char magic[2] = {0, 0};
+        const int fd = ::open(opt.reads[0].c_str(), O_RDONLY);
+        const bool gz = fd >= 0 && ::pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (fd >= 0) ::close(fd);
+        if (!gz) reserve_reads = std::min<size_t>(reserve_reads, static_cast<size_t>(sb.st_size) / (2 * std::max<uint32_t>(first_len, 1) + 4) + 256);
+      }
+    }
+    std::vector<std::thread> warm;
+    std::exception_ptr werr;
+    std::mutex wmu;
+    for (abm_ctx *c : ctxs)
+      warm.emplace_back([&, c] {
+        if (abm_ctx_reserve(c, reserve_reads, first_len, paired ? 1 : 0) != 0) {
+          std::lock_guard<std::mutex> lk(wmu);
+          if (!werr) werr = std::make_exception_ptr(std::runtime_error(std::string("preparing GPU context: ") + abm_last_error()));
+        }
+      });
+    for (auto &t : warm) t.join();
+    if (werr) std::rethrow_exception(werr);
+  }
   const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();  // file -> host -> HBM
 
   // ---- output file.  A slice's place is fixed in slice order; then whichever thread is free pwrite()s it.

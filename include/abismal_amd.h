@@ -77,6 +77,11 @@ uint32_t abm_index_window(const abm_index *ix);
  * transfers overlap another batch's kernels.  Destroy every context before
  * abm_index_close. */
 int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out);
+/* Optional set-up: sizes the context's workspaces for host-buffer batches of up to n reads (pairs, if paired != 0)
+ * of up to max_len bases and runs a few dummy reads through the kernels, so that the first real batch pays neither
+ * allocations nor code loading (the reference's counterpart: the per-thread scratch built before the batch loop,
+ * src/abismal.cpp:1535-1539, :1919-1929). */
+int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired);
 void abm_ctx_destroy(abm_ctx *ctx);
 
 /* Single-end batch, host buffers.  Replaces the loop body of

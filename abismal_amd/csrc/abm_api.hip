@@ -213,9 +213,10 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.size_frac = size_frac;
   a.GW = abm::se_window_words(eff_len, size_frac);
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
-  // cooperative window loads (hamming_coop): not for genomes with IUPAC letters, whose admission rule needs
-  // full_compare's word-by-word running sums; ABM_COOP_WINDOWS=0 switches them off (experiments)
-  a.G = ctx->ix->h.multibit_genome ? 0u : (W <= 7 ? 4u : (W <= 15 ? 8u : 0u));
+  // cooperative window loads from the genome's bit planes (hamming_planes): not for genomes with IUPAC letters (no
+  // planes; their admission rule needs full_compare's word-by-word running sums) nor for reads beyond 448 bases; ABM_COOP_WINDOWS=0 switches them off (experiments)
+  // (G lanes x 64 bases cover a window of eff_len + 63 bases)
+  a.G = a.ix.planes[0] == nullptr ? 0u : (eff_len <= 4 * abm::kPlaneBlock - 64 ? 4u : (eff_len <= 8 * abm::kPlaneBlock - 64 ? 8u : 0u));
   if (const char *e = std::getenv("ABM_COOP_WINDOWS")) if (e[0] == '0') a.G = 0;
   a.mode = mode;
   a.valid_frac = params->valid_frac;
@@ -511,8 +512,12 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
                                 h.index_a.size() * 4};
           const void *src[7] = {h.genome.data(),    h.counter.data(), h.counter_t.data(), h.counter_a.data(),
                                 h.index.data(),     h.index_t.data(), h.index_a.data()};
-          size_t offs[7], total = 0;
+          size_t offs[9], total = 0;
           for (int k = 0; k < 7; ++k) { offs[k] = total; total += up(sz[k] + 64); }
+          // the filter's bit-plane copies of the genome (DevIndex::planes), derived on the device
+          const uint64_t n_bases = h.chrom_starts.empty() ? 0 : h.chrom_starts.back();
+          const uint64_t n_blocks = h.multibit_genome ? 0 : (n_bases + abm::kPlaneBlock - 1) / abm::kPlaneBlock + 16;
+          for (int k = 7; k < 9; ++k) { offs[k] = total; total += up(n_blocks * 16 + 128); }
           void *arena = nullptr;
           HIPCHK(hipMalloc(&arena, total));
           try {
@@ -530,6 +535,16 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
             rep.dix.max_candidates = h.max_candidates;
             rep.dix.window = h.window;
             rep.dix.min_len = abm::kKeyWeight + h.window - 1;
+            rep.dix.planes[0] = rep.dix.planes[1] = nullptr;
+            if (n_blocks) {
+              auto *p0 = reinterpret_cast<abm::u64 *>(base + offs[7]), *p1 = reinterpret_cast<abm::u64 *>(base + offs[8] + 64);
+              abm::u32 *d_bad = reinterpret_cast<abm::u32 *>(base + offs[8]);  // (the first 64 bytes of copy 1's array are free)
+              HIPCHK(abm::launch_make_planes(rep.dix.genome, h.genome.size(), n_bases, n_blocks, p0, p1, d_bad, nullptr));
+              abm::u32 bad = 0;
+              HIPCHK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+              if (!bad) { rep.dix.planes[0] = p0; rep.dix.planes[1] = p1; }
+              if (const char *e = std::getenv("ABM_PLANES_COPIES")) if (e[0] == '1') rep.dix.planes[1] = p0;  // experiments only
+            }
           }
           catch (...) { (void)hipFree(arena); throw; }
           rep.arena = arena;

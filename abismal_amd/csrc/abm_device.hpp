@@ -36,7 +36,15 @@ struct DevIndex {
   u32 max_candidates;
   u32 window;   // seed window of this index: 20, or 12 (--enable-short, src/AbismalIndex.hpp:73-77)
   u32 min_len;  // shortest read that is mapped: key_weight + window - 1 (src/abismal.cpp:212-213)
+  // The genome once more for the Hamming filter, as two bit planes: block k = 64 bases = {u64 low bits, u64 high
+  // bits} of the base codes (code = index of the base's bit in its one-hot nibble).  A 100-base window is 2-3
+  // blocks (32-48 bytes) instead of 64 bytes of nibbles, and the two copies are laid out half a 128-byte line
+  // apart -- block k of planes[c] is at byte 16 k + 64 c of a line-aligned array -- so that every window lies
+  // inside ONE line of one of them.  Null when the genome has nibbles that are not one-hot.
+  const u64 *planes[2];
 };
+constexpr u32 kPlaneBlock = 64;       // bases per bit-plane block
+constexpr u32 kPlaneLineBlocks = 8;   // blocks per 128-byte line
 
 struct Hit {  // == abm_hit
   i16 diffs;

@@ -61,6 +61,44 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 }
 
 // =============================================================================
+// Index upload: the genome's bit planes (DevIndex::planes).  Thread per block of 64 bases.
+// =============================================================================
+__device__ __forceinline__ u32 every_fourth_bit(u64 t) {  // bits 0, 4, 8, ... of t -> 16 contiguous bits
+  t &= 0x1111111111111111ull;
+  t = (t | (t >> 3)) & 0x0303030303030303ull;
+  t = (t | (t >> 6)) & 0x000F000F000F000Full;
+  t = (t | (t >> 12)) & 0x000000FF000000FFull;
+  t = (t | (t >> 24)) & 0xFFFFull;
+  return static_cast<u32>(t);
+}
+__global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict__ genome, u64 n_words, u64 n_bases,
+                                                          u64 n_blocks, u64 *__restrict__ p0, u64 *__restrict__ p1,
+                                                          u32 *__restrict__ bad) {
+  const u64 b = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  u64 lo = 0, hi = 0;
+  bool odd = false;
+  for (u32 k = 0; k < 4; ++k) {
+    const u64 w = 4 * b + k;
+    const u64 x = w < n_words ? genome[w] : 0ull;
+    // code of a one-hot nibble 1, 2, 4, 8 = 0, 1, 2, 3: low bit from bits 1|3, high bit from bits 2|3
+    lo |= static_cast<u64>(every_fourth_bit((x >> 1) | (x >> 3))) << (16 * k);
+    hi |= static_cast<u64>(every_fourth_bit((x >> 2) | (x >> 3))) << (16 * k);
+    const u64 ones = (x & 0x1111111111111111ull) + ((x >> 1) & 0x1111111111111111ull) +
+                     ((x >> 2) & 0x1111111111111111ull) + ((x >> 3) & 0x1111111111111111ull);
+    u64 want = 0x1111111111111111ull;  // exactly one bit per nibble, for the nibbles that are part of the genome
+    const u64 first = 16 * w;
+    if (first >= n_bases) want = 0;
+    else if (n_bases - first < 16) want &= (1ull << (4 * (n_bases - first))) - 1;
+    const u64 care = want * 15ull;
+    if ((ones & care) != want) odd = true;
+  }
+  p0[2 * b] = lo; p0[2 * b + 1] = hi;
+  p1[2 * b] = lo; p1[2 * b + 1] = hi;
+  if (odd) atomicOr(bad, 1u);
+}
+
+// =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
 template <bool TIMED, bool COOP, u32 NW>
@@ -84,7 +122,9 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   lds.qpk = reinterpret_cast<u64 *>(mine);
   lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
-  lds.gwin = lds.qbits + 4 * a.WB;
+  lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
+  lds.qmask = lds.qbits + 4 * a.WB;
+  lds.gwin = lds.qmask + 4 * lds.MB * 4;
   lds.pcache = lds.gwin + kMaxJobs * a.GW;
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
   lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
@@ -102,7 +142,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   const u32 call_rc = a.mode == 2 ? 0xCu /*0,0,1,1*/ : 0x2u /*0,1*/;
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
-  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int MODE = kMain;
   HelpWave hw;
   hw.h = a.help;
@@ -164,6 +204,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
           const u64 word = __ballot(b);
           if (lane == 0) lds.qbits[e * a.WB + wb] = word;
         }
+      if constexpr (COOP) build_qmasks(lds, L);
       wave_sync();
       if (L < max(a.ix.window, L >> 1) + kKeyWeight - 1)  // 44-46 bases: seeds reach past the end of the read
         ghost_bits(a.packed, a.lens, r, L, a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits);
@@ -222,6 +263,10 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         atomicAdd(&a.work[8], static_cast<unsigned long long>(wt.t_replay));
         atomicAdd(&a.work[9], static_cast<unsigned long long>(wt.t_align));
         atomicAdd(&a.work[10], static_cast<unsigned long long>(phase_stamp() - t_begin));
+        if (NW == 1) {  // (the in-block help slots are free in a one-wave workgroup)
+          atomicAdd(&a.work[14], static_cast<unsigned long long>(wt.fifo_updates));
+          atomicAdd(&a.work[15], static_cast<unsigned long long>(wt.steps));
+        }
       }
     }
   }
@@ -393,7 +438,9 @@ u32 tb_extra_bytes(u32 GW, u32 max_len, double valid_frac) {
 
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac) {
   const u32 GW = se_window_words(max_len, valid_frac);
-  size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) +
+  const u32 MB = (max_len + kPlaneBlock - 1) / kPlaneBlock;
+  size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + static_cast<size_t>(4) * MB * 4 * 8 +
+             (static_cast<size_t>(8) << kPosCacheBits) +
              static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
              2 * kSeCap * 4 + 64 * 4 + 64 * 2;
   b += tb_extra_bytes(GW, max_len, valid_frac);
@@ -421,6 +468,14 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   constexpr int kSeWavesPerCu = 20;
   return min(per_cu * static_cast<int>(block_waves), kSeWavesPerCu) / static_cast<int>(block_waves) * static_cast<int>(block_waves) *
          prop.multiProcessorCount;
+}
+
+hipError_t launch_make_planes(const u64 *d_genome, u64 n_words, u64 n_bases, u64 n_blocks, u64 *d_planes0,
+                              u64 *d_planes1, u32 *d_bad, hipStream_t st) {
+  if (n_blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(make_planes_kernel, dim3(static_cast<u32>((n_blocks + 255) / 256)), dim3(256), 0, st, d_genome,
+                     n_words, n_bases, n_blocks, d_planes0, d_planes1, d_bad);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,

@@ -69,49 +69,120 @@ struct SeSet {
     sift_up(hole, vk);
     return freed;
   }
-  // m = popcount(run) consecutive updates, each with diffs == cutoff == every
-  // slot's diffs, the set being full.  With all keys equal, pop_heap on 50
-  // elements (len 49) walks hole 0 -> 2 -> 6 -> 14 -> 30 (always the right child:
-  // "right < left" is false), the displaced last element lands in 30 without
-  // rising, and the new element stays at 49: a 6-deep shift register over slots
-  // {0,2,6,14,30,49}.  The evicted element's payload slot is recycled for the
-  // newcomer.  Lanes of `run` carry the candidates (cand_pos) in order.
-  __device__ __forceinline__ void fifo_run(u64 run, u32 cand_pos, u32 f) {
-    static_assert(kSeCap == 50, "chain derived for a 50-element heap");
-    const int chain[6] = {0, 2, 6, 14, 30, 49};
+  // pop_heap + overwrite + push_heap on the FULL set (50 elements) in straight-line code: the evicted maximum's
+  // payload slot takes (f, p) and the key d enters.  Same result as pop_max + sift_up above, derived from
+  // libstdc++'s __adjust_heap / __push_heap:
+  //  * the hole left by the root walks down 0 -> p1 -> .. -> pm, always to the right child unless it compares
+  //    less than the left one, while the node has two children in the 49-element heap (node < 24): every sibling
+  //    comparison is made at once (one DPP move + one ballot) and the walk is bit tests on the result;
+  //  * the displaced last element vk then rises from pm while the element above compares less -- and the element
+  //    above hole p(i) at that point is the one that started in p(i) -- so the net effect on the path is: nodes
+  //    above p(j) take their path child's key, p(j) takes vk, nodes below keep theirs, where j is the deepest
+  //    path index >= 1 whose original key does not compare less than vk (0 if there is none);
+  //  * the newcomer enters at 49 and rises along 24, 11, 5, 2, 0 while the parent compares less.
+  // Returns the key left at the root.
+  __device__ __forceinline__ int replace_top(int d, u32 f, u32 p) {
+    static_assert(kSeCap == 50, "paths derived for a 50-element heap");
+    const int left = __builtin_amdgcn_update_dpp(0, hk, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    const u64 right_wins = __ballot(!(key_d(hk) < key_d(left)));  // bit r, r even: the hole moves to r rather than r - 1
+    auto down = [&](int node) { const int r = 2 * node + 2; return ((right_wins >> r) & 1ull) ? r : r - 1; };
+    const int root = rdlane(hk, 0), vk = rdlane(hk, 49);
+    const int p1 = down(0), p2 = down(p1), p3 = down(p2), p4 = down(p3);
+    const bool five = p4 < 24;
+    const int p5 = five ? down(p4) : 63;  // (lane 63 is not part of the set: a harmless stand-in)
+    const int k1 = rdlane(hk, p1), k2 = rdlane(hk, p2), k3 = rdlane(hk, p3), k4 = rdlane(hk, p4), k5 = rdlane(hk, p5);
+    const int dv = key_d(vk);
+    int j = 0;
+    if (key_d(k1) >= dv) j = 1;
+    if (key_d(k2) >= dv) j = 2;
+    if (key_d(k3) >= dv) j = 3;
+    if (key_d(k4) >= dv) j = 4;
+    if (five && key_d(k5) >= dv) j = 5;
+    wrlane(hk, 0, j == 0 ? vk : k1);
+    wrlane(hk, p1, j > 1 ? k2 : (j == 1 ? vk : k1));
+    wrlane(hk, p2, j > 2 ? k3 : (j == 2 ? vk : k2));
+    wrlane(hk, p3, j > 3 ? k4 : (j == 3 ? vk : k3));
+    wrlane(hk, p4, j > 4 ? k5 : (j == 4 ? vk : k4));
+    wrlane(hk, p5, j == 5 ? vk : k5);
+    const int slot = root & 255;
+    wrlane(pf, slot, f);
+    wrlane(pp, slot, p);
+    const int nk = d * 256 + slot;
+    const int c24 = rdlane(hk, 24), c11 = rdlane(hk, 11), c5 = rdlane(hk, 5), c2 = rdlane(hk, 2), c0 = rdlane(hk, 0);
+    const bool b24 = key_d(c24) < d, b11 = b24 && key_d(c11) < d, b5 = b11 && key_d(c5) < d, b2 = b5 && key_d(c2) < d,
+               b0 = b2 && key_d(c0) < d;
+    wrlane(hk, 49, b24 ? c24 : nk);
+    wrlane(hk, 24, b24 ? (b11 ? c11 : nk) : c24);
+    wrlane(hk, 11, b11 ? (b5 ? c5 : nk) : c11);
+    wrlane(hk, 5, b5 ? (b2 ? c2 : nk) : c5);
+    wrlane(hk, 2, b2 ? (b0 ? c0 : nk) : c2);
+    const int top = b0 ? nk : c0;
+    wrlane(hk, 0, top);
+    return top;
+  }
+
+  // A RUN of survivors that tie with the cutoff while the set is full and heap[0], heap[24] and heap[49] all sit at
+  // the cutoff c (tandem repeats, homopolymer reads: hundreds of thousands of such updates per read).  Each is
+  // pop_heap + overwrite + push_heap as in replace_top, and under these conditions that is a shift register:
+  //  * the displaced last element heap[49] has distance c, the maximum, so it comes to rest at the deepest node of
+  //    the hole's path that holds a c (j in replace_top; the c's of a path are a prefix of it, the heap being a
+  //    heap), and everything above moves up one node: the path's c-prefix p0..pj takes p1..pj, heap[49];
+  //  * the newcomer (distance c) enters at 49 and stays there, its parent 24 not comparing less;
+  //  * every node keeps its distance, so the sibling comparisons -- hence the path -- are the same for the next tie.
+  // So a tie is: evict heap[0]'s payload, shift keys along the chain p0 <- p1 <- .. <- pj <- 49, put the newcomer
+  // (with the evicted payload slot) at 49.  After n = chain length updates every old element is gone and the payload
+  // slots are back in the same places, so of a run of m only the last n + m % n (at most 13) need to be played.
+  // `ties` = lanes whose candidate has distance c; the leading ones of `todo` that are ties are consumed.
+  // Returns how many updates were applied (0: conditions not met, nothing done).
+  __device__ __forceinline__ int tie_run(u64 &todo, u64 ties, u32 cand_pos, u32 f) {
+    static_assert(kSeCap == 50, "paths derived for a 50-element heap");
+    const int lane = lane_id();
+    const int c = cutoff;
+    if (sz != static_cast<int>(kSeCap) || key_d(rdlane(hk, 0)) != c || key_d(rdlane(hk, 24)) != c || key_d(rdlane(hk, 49)) != c)
+      return 0;
+    const u64 brk = todo & ~ties;
+    u64 run = brk ? (todo & ((brk & (0 - brk)) - 1)) : todo;
+    if (run == 0) return 0;
     const int m = __popcll(run);
-    int oldk[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) oldk[i] = rdlane(hk, chain[i]);
-    // the (up to) six newest candidates of the run, newest first
-    int lanes_new[6];
-    u64 rest = run;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      lanes_new[j] = rest ? 63 - __builtin_clzll(rest) : 0;
-      if (rest) rest &= ~(1ull << lanes_new[j]);
+    todo &= ~run;
+    // the hole's path and its c-prefix
+    const int left = __builtin_amdgcn_update_dpp(0, hk, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    const u64 right_wins = __ballot(!(key_d(hk) < key_d(left)));
+    auto down = [&](int node) { const int r = 2 * node + 2; return ((right_wins >> r) & 1ull) ? r : r - 1; };
+    const int p1 = down(0), p2 = down(p1), p3 = down(p2), p4 = down(p3);
+    const int p5 = p4 < 24 ? down(p4) : 63;
+    const bool e1 = key_d(rdlane(hk, p1)) == c, e2 = e1 && key_d(rdlane(hk, p2)) == c, e3 = e2 && key_d(rdlane(hk, p3)) == c,
+               e4 = e3 && key_d(rdlane(hk, p4)) == c, e5 = e4 && p4 < 24 && key_d(rdlane(hk, p5)) == c;
+    const int n = 2 + (e1 ? 1 : 0) + (e2 ? 1 : 0) + (e3 ? 1 : 0) + (e4 ? 1 : 0) + (e5 ? 1 : 0);  // chain length incl. 49
+    // where each lane's key comes from in one shift
+    int src = lane;
+    wrlane(src, 0, e1 ? p1 : 49);
+    if (e1) wrlane(src, p1, e2 ? p2 : 49);
+    if (e2) wrlane(src, p2, e3 ? p3 : 49);
+    if (e3) wrlane(src, p3, e4 ? p4 : 49);
+    if (e4) wrlane(src, p4, e5 ? p5 : 49);
+    if (e5) wrlane(src, p5, 49);
+    // the survivors that leave a trace: the last n + m % n of the run
+    int play = m;
+    while (play >= 2 * n) play -= n;
+    u64 last = 0, rest = run;
+    for (int k = 0; k < play; ++k) {
+      const int top = 63 - __builtin_clzll(rest);
+      last |= 1ull << top;
+      rest &= ~(1ull << top);
     }
-    const int c256 = cutoff * 256, mm = m % 6;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      // final content of chain[i] = element (m + i) of the sequence old[0..5], new[1..m];
-      // newcomer k recycles the payload slot of old[(k-1) % 6]
-      if (m + i < 6) {
-        int k_old = oldk[0];
-#pragma unroll
-        for (int t = 1; t < 6; ++t) if (m + i == t) k_old = oldk[t];
-        wrlane(hk, chain[i], k_old);
-      }
-      else {
-        int k_slot = oldk[i % 6];  // (m + i) % 6 with mm == 0
-#pragma unroll
-        for (int t = 1; t < 6; ++t) if (mm == t) k_slot = oldk[(t + i) % 6];
-        const int slot = k_slot & 255;
-        wrlane(hk, chain[i], c256 + slot);
-        wrlane(pp, slot, rdlane(cand_pos, lanes_new[5 - i]));
-        wrlane(pf, slot, f);
-      }
+    const int c256 = c * 256;
+    while (last) {
+      const int l = __builtin_ctzll(last);
+      last &= last - 1;
+      const int slot = rdlane(hk, 0) & 255;
+      const u32 p = rdlane(cand_pos, l);
+      hk = __builtin_amdgcn_ds_bpermute(src << 2, hk);
+      wrlane(hk, 49, c256 + slot);
+      wrlane(pp, slot, p);
+      wrlane(pf, slot, f);
     }
+    return m;
   }
 
   // se_candidates::update, :394-404
@@ -120,16 +191,18 @@ struct SeSet {
       if (best_p == 0) { best_d = 0; best_f = f; best_p = p; }
       else if (p != best_p || f != best_f) best_f |= kFlagAmbig;
     }
+    int top;
+    if (d != 0 && sz == static_cast<int>(kSeCap)) top = key_d(replace_top(d, f, p));
     else {
-      int slot;
-      if (sz == static_cast<int>(kSeCap)) slot = pop_max(sz);
-      else slot = sz++;
-      wrlane(pf, slot, f);
-      wrlane(pp, slot, p);
-      sift_up(sz - 1, d * 256 + slot);
+      if (d != 0) {
+        const int slot = sz++;
+        wrlane(pf, slot, f);
+        wrlane(pp, slot, p);
+        sift_up(sz - 1, d * 256 + slot);
+      }
+      top = top_d();
     }
     sure_ambig = (best_f & kFlagAmbig) && best_d == 0;
-    const int top = top_d();
     cutoff = specific ? min(cutoff, top) : top;
   }
 };
@@ -138,6 +211,7 @@ struct SeSet {
 struct WaveLds {
   u64 *qpk;    // [4][W] packed encodings
   u64 *qbits;  // [4][WB] 2-letter bit strings, bit j = bit2(nibble j), 1 past the end
+  u64 *qmask;  // [4][MB][4] per block of 64 read bases: which of them admit genome code 0, 1, 2, 3 (cooperative filter)
   u16 *mark;   // [64]
   u32 *ctmp;   // [ctmp_cap] reversed CIGAR scratch
   u8 *tb;      // traceback bytes
@@ -147,7 +221,7 @@ struct WaveLds {
   int *lbest;  // [64]
   u64 *pcache; // [1 << kPosCacheBits] candidate cache: pos | diffs<<32 | max-prefix-diffs<<48
   u16 *hres;   // [128] distances of the candidates of one step (cooperative window loads)
-  u32 W, WB, GW;
+  u32 W, WB, GW, MB;
   u32 G;       // lanes that share one candidate's window (4 or 8), 0 = one lane per window
 };
 constexpr u32 kPosCacheBits = 8;
@@ -185,14 +259,33 @@ __device__ __forceinline__ u32 first_not(u32 lo, u32 hi, u32 &probes, Below belo
 // of 44-46 bases limit = L - i is BELOW the starting length for the last offsets, so the reference
 // keeps extending past the end of the read, through whatever its reused buffer holds there (the
 // ghost bits the kernel puts into qb: ghost_bits).
-__device__ __forceinline__ u32 narrow2(const u64 *__restrict__ genome, const u32 *__restrict__ tbl,
+// The genome letter at position q as the narrowing loops need it: its 2-letter bit / its 3-letter sort symbol.
+// PLANES: from the bit planes (the cooperative filter's copy of the genome, so the narrowing probes and the
+// windows share one array and its cache lines; the nibble array is then only read by the alignments).
+template <bool PLANES>
+__device__ __forceinline__ u32 genome_bit2(const DevIndex &ix, u64 q) {
+  if constexpr (PLANES) return static_cast<u32>(ix.planes[0][2 * (q / kPlaneBlock)] >> (q % kPlaneBlock)) & 1u;  // codes 1 (C), 3 (T)
+  else return bit2(gnib(ix.genome, q));
+}
+template <bool PLANES>
+__device__ __forceinline__ u32 genome_sortsym3(const DevIndex &ix, u64 q, bool g_to_a) {
+  if constexpr (PLANES) {
+    const u64 *b = ix.planes[0] + 2 * (q / kPlaneBlock);
+    const u32 code = (static_cast<u32>(b[0] >> (q % kPlaneBlock)) & 1u) | ((static_cast<u32>(b[1] >> (q % kPlaneBlock)) & 1u) << 1);
+    return sortsym3(1u << code, g_to_a);
+  }
+  else return sortsym3(gnib(ix.genome, q), g_to_a);
+}
+
+template <bool PLANES>
+__device__ __forceinline__ u32 narrow2(const DevIndex &ix, const u32 *__restrict__ tbl,
                                        const u64 *qb, u32 n_bits, u32 qbase, u32 limit, u32 maxc, u32 &lo,
                                        u32 &hi, u32 &probes) {
   u32 p = kKeyWeight, plo = lo, phi = hi;
   for (; p != limit && (hi - lo) > maxc && qbase + p < n_bits + 4096u; ++p) {
     plo = lo; phi = hi;
     const u32 ones = first_not(lo, hi, probes, [&](u32 k) {
-      return bit2(gnib(genome, static_cast<u64>(tbl[k]) + p)) < 1u;
+      return genome_bit2<PLANES>(ix, static_cast<u64>(tbl[k]) + p) < 1u;
     });
     const u32 at = qbase + p;
     const bool one = at < n_bits ? ((qb[at >> 6] >> (at & 63u)) & 1ull) != 0 : true;
@@ -207,7 +300,8 @@ __device__ __forceinline__ u32 narrow2(const u64 *__restrict__ genome, const u32
 // same midpoint and share probes until their paths part, so both advance in lockstep here and a
 // probe whose index coincides is loaded once.  Each bisection still sees exactly its own probe
 // sequence, so the boundaries are the reference's even where the bucket tail is unsorted.
-__device__ __forceinline__ u32 narrow3(const u64 *__restrict__ genome, const u32 *__restrict__ tbl,
+template <bool PLANES>
+__device__ __forceinline__ u32 narrow3(const DevIndex &ix, const u32 *__restrict__ tbl,
                                        bool g_to_a, const u64 *qpk, u32 qbase, u32 limit, u32 maxc,
                                        u32 &lo, u32 &hi, u32 &probes) {
   const u32 mid_sym = g_to_a ? 2u : 1u, top_sym = g_to_a ? 8u : 4u;
@@ -220,10 +314,10 @@ __device__ __forceinline__ u32 narrow3(const u64 *__restrict__ genome, const u32
       const int h1 = n1 >> 1, h2 = n2 >> 1;
       const u32 m1 = l1 + static_cast<u32>(h1), m2 = l2 + static_cast<u32>(h2);
       u32 s1 = 0, s2 = 0;
-      if (n1 > 0) { s1 = sortsym3(gnib(genome, static_cast<u64>(tbl[m1]) + p), g_to_a); ++probes; }
+      if (n1 > 0) { s1 = genome_sortsym3<PLANES>(ix, static_cast<u64>(tbl[m1]) + p, g_to_a); ++probes; }
       if (n2 > 0) {
         if (n1 > 0 && m2 == m1) s2 = s1;
-        else { s2 = sortsym3(gnib(genome, static_cast<u64>(tbl[m2]) + p), g_to_a); ++probes; }
+        else { s2 = genome_sortsym3<PLANES>(ix, static_cast<u64>(tbl[m2]) + p, g_to_a); ++probes; }
       }
       if (n1 > 0) { if (s1 < mid_sym) { l1 = m1 + 1; n1 -= h1 + 1; } else n1 = h1; }
       if (n2 > 0) { if (s2 < top_sym) { l2 = m2 + 1; n2 -= h2 + 1; } else n2 = h2; }
@@ -327,43 +421,70 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
 #define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (scripts/se_variant.sh): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
 #endif
 constexpr u32 kCoopRounds = ABM_COOP_ROUNDS;  // rounds of window loads in flight per lane
+
+// Per block of 64 read bases and per encoding: the four masks "read base j admits genome code c" (bit c of the
+// read's nibble; everything past the read admits every code, like the 0xF padding of the packed words).
+__device__ __forceinline__ void build_qmasks(const WaveLds &lds, u32 L) {
+  const int lane = lane_id();
+  const u32 nblk = (L + kPlaneBlock - 1) / kPlaneBlock;
+  for (u32 e = 0; e < 4; ++e)
+    for (u32 s = 0; s < nblk; ++s) {
+      const u32 i = s * kPlaneBlock + static_cast<u32>(lane);
+      const u32 nib = i < L ? q_nibble(lds.qpk + e * lds.W, i) : 15u;
+      const u64 m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
+      if (lane == 0) {
+        u64 *q = lds.qmask + (e * lds.MB + s) * 4;
+        q[0] = m0; q[1] = m1; q[2] = m2; q[3] = m3;
+      }
+    }
+}
+
+// Hamming distances of 128 candidates (two per lane: pos_a of lane c = candidate c, pos_b = candidate 64 + c)
+// against the genome's bit planes (DevIndex::planes).  G lanes share a candidate: lane s of the group loads block
+// (pos >> 6) + s of the window -- one 16-byte load, every window inside one 128-byte line of one of the two
+// copies -- and counts the mismatches of read bases [64 s, 64 s + 64): the genome bits it needs beyond its own
+// block arrive by DPP from the next lane.  mismatches = 64 - popcount(the mask of the code each genome base has).
+// Identical to full_compare's sum over whole words for a one-hot genome (src/abismal.cpp:1093-1122; the early exit
+// there changes a distance only when the hit is rejected anyway).
 template <u32 kRounds = kCoopRounds>
-__device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, const WaveLds &lds, const u64 *qpk,
-                                             u32 nwords, u32 pos_a, bool want_a, u32 pos_b, bool want_b,
-                                             int &d_a, int &d_b) {
+__device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
+                                               u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
   const int lane = lane_id();
   const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
-  const bool has0 = 2 * sub < nwords, has1 = 2 * sub + 1 < nwords;
-  const u64 q0 = has0 ? qpk[2 * sub] : 0ull, q1 = has1 ? qpk[2 * sub + 1] : 0ull;
+  const bool counts = sub * kPlaneBlock < L;  // this lane has read bases to compare
+  u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  if (counts) { const u64 *q = qm + sub * 4; m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; }
   for (u32 pass = 0; pass * kRounds * per_round < 128; ++pass) {
-    u64 x0[kRounds], x1[kRounds];
-    u32 shifts = 0;  // (pos & 15) of the eight rounds' candidates, four bits each
+    u64 xl[kRounds], xh[kRounds];
+    u32 shifts = 0;  // (pos & 63) of the rounds' candidates, eight bits each
 #pragma unroll
     for (u32 r = 0; r < kRounds; ++r) {
       const u32 slot = (pass * kRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
       const bool second = (pass * kRounds + r) * per_round >= 64;
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
-      shifts |= (cp & 15u) << (4 * r);
-      const bool act = (((second ? wb : wa) >> c) & 1ull) && 2 * sub <= nwords;
-      x0[r] = 0; x1[r] = 0;
+      shifts |= (cp & 63u) << (8 * r);
+      const u32 b0 = cp / kPlaneBlock, b1 = (cp + L - 1) / kPlaneBlock;
+      const bool act = (((second ? wb : wa) >> c) & 1ull) && b0 + sub <= b1;
+      xl[r] = 0; xh[r] = 0;
       if (act) {
-        const u64 *g = genome + (cp >> 4) + 2 * sub;
-        x0[r] = g[0];
-        x1[r] = g[1];
+        const u64 *g = ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub);
+        xl[r] = g[0];
+        xh[r] = g[1];
       }
     }
 #pragma unroll
     for (u32 r = 0; r < kRounds; ++r) {
       const u32 slot = (pass * kRounds + r) * per_round + grp;
-      const u32 sh = ((shifts >> (4 * r)) & 15u) << 2;
-      // the word after this lane's pair is the next lane's first word
-      const u64 x2 = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r] >> 32)))) << 32) |
-                     static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r])));
-      int d = 0;
-      if (has0) d += 16 - __popcll(q0 & ((x0[r] >> sh) | ((x1[r] << (63 - sh)) << 1)));
-      if (has1) d += 16 - __popcll(q1 & ((x1[r] >> sh) | ((x2 << (63 - sh)) << 1)));
+      const u32 sh = (shifts >> (8 * r)) & 63u;
+      const u64 nl = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(xl[r] >> 32)))) << 32) |
+                     static_cast<u32>(dpp_row_shl1(static_cast<int>(xl[r])));
+      const u64 nh = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(xh[r] >> 32)))) << 32) |
+                     static_cast<u32>(dpp_row_shl1(static_cast<int>(xh[r])));
+      const u64 gl = (xl[r] >> sh) | ((nl << (63 - sh)) << 1), gh = (xh[r] >> sh) | ((nh << (63 - sh)) << 1);
+      const u64 match = (~gh & ((~gl & m0) | (gl & m1))) | (gh & ((~gl & m2) | (gl & m3)));
+      int d = counts ? 64 - __popcll(match) : 0;
       d = group_sum(d, G);
       if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
     }
@@ -516,8 +637,8 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
 
 // distances and positions of candidates [c0, c0 + 128) of a flattened block (two per lane: c0 + lane
 // and c0 + 64 + lane), reached out of sequence -- what a claimed chunk of a job computes
-__device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qpk, const u32 *idx3,
-                                             u32 nwords, const Segs &sg, u32 g0, u32 total, u32 c0, int &ha, int &hb,
+__device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qm, const u32 *idx3,
+                                             u32 L, const Segs &sg, u32 g0, u32 total, u32 c0, int &ha, int &hb,
                                              u32 &pa, u32 &pb) {
   int carry = seg_before(sg, c0);
   bool va, vb = false, ta3, tb3 = false;
@@ -529,7 +650,7 @@ __device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &
   if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
   pa = ea - (g0 + static_cast<u32>(oa));
   pb = eb - (g0 + static_cast<u32>(ob));
-  hamming_coop<ABM_HELP_ROUNDS>(ix.genome, lds, qpk, nwords, pa, va, pb, vb, ha, hb);
+  hamming_planes<ABM_HELP_ROUNDS>(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
   if (!va) ha = 0x7fff;
   if (!vb) hb = 0x7fff;
 }
@@ -540,6 +661,7 @@ __device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &
 // for the Hamming filter; survivors are replayed in order into the set.
 struct WorkTally {
   u32 seed_iters, probes, cands, words, updates, cache_hits;
+  u32 fifo_updates, steps;  // diagnostic build only
   // diagnostic build only (TIMED): shader cycles per phase, from s_memtime
   long long t_probe, t_stream, t_replay, t_align, t_total;
 };
@@ -602,8 +724,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
       if (SPECIFIC) {
         u32 probes = 0;
-        const u32 len2 = narrow2(ix.genome, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
-        const u32 len3 = narrow3(ix.genome, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
+        const u32 len2 = narrow2<COOP>(ix, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
+        const u32 len3 = narrow3<COOP>(ix, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
         chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;
         wt.probes += probes;
@@ -635,22 +757,13 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         wt.updates += static_cast<u32>(offered - __popcll(todo));
       }
       while (todo && !S.sure_ambig) {
-        if constexpr (Set::kFifo) if (S.sz == static_cast<int>(kSeCap)) {
-          // Saturated, all-equal regime (tandem repeats / homopolymer reads): the
-          // set is full and every slot's distance equals the cutoff.  A survivor at
-          // exactly that distance evicts heap[0] and, all keys comparing equal,
-          // libstdc++'s pop_heap/push_heap reduce to a shift along one fixed chain
-          // of slots (see fifo_run).  A run of such survivors is applied at once.
-          const u64 uneq = __ballot(lane < static_cast<int>(kSeCap) && SeSet::key_d(S.hk) != S.cutoff);
-          if (uneq == 0) {
-            const u64 brk = todo & ~__ballot(valid && h == S.cutoff);
-            const u64 run = brk ? (todo & ((brk & (0 - brk)) - 1)) : todo;
-            if (run) {
-              S.fifo_run(run, pos, flags);
-              wt.updates += static_cast<u32>(__popcll(run));
-              todo &= ~run;
-              continue;
-            }
+        if constexpr (Set::kFifo) {
+          // full set, survivors that tie with the cutoff: applied a run at a time (SeSet::tie_run)
+          const int applied = S.tie_run(todo, __ballot(valid && h == S.cutoff), pos, flags);
+          if (applied) {
+            wt.updates += static_cast<u32>(applied);
+            if (TIMED) wt.fifo_updates += static_cast<u32>(applied);
+            continue;
           }
         }
         const int l = __builtin_ctzll(todo);
@@ -719,6 +832,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       for (u32 k = 0; k < n_chunks && !S.sure_ambig; ++k) {
         const u32 c0 = c_base + k * kHelpChunk;
         ABM_STAMP(tc);
+        if (TIMED) ++wt.steps;
         if constexpr (HELP) if (shared && computing) {  // take chunk k from the front, if the helpers have left it
           u32 old = 0;
           if (lane == 0) old = __hip_atomic_fetch_add(hw->span, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -744,7 +858,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
           const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
           const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
           if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
-            hamming_coop(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+            hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
             hma = ha; hmb = hb;
           }
           else
@@ -780,7 +894,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
             {
               int xa, xb;
               u32 ya, yb;
-              filter_chunk(ix, lds, qpk, idx3, nwords, sg, g0, total, c0, xa, xb, ya, yb);
+              filter_chunk(ix, lds, lds.qmask + enc * lds.MB * 4, idx3, L, sg, g0, total, c0, xa, xb, ya, yb);
               if (__any(xa != ha || xb != hb || (xa != 0x7fff && ya != pa) || (xb != 0x7fff && yb != pb))) hw->mismatch = true;
             }
 #endif
@@ -854,11 +968,12 @@ __device__ __forceinline__ void help_block_mates(const DevIndex &ix, const WaveL
         sg.lo3 = ABM_WG_LOAD(sv + 256);
         cur_mate = m; cur_epoch = e;
       }
-      // the owner's read, where it lies: the packed encodings open every wave's LDS region
-      const u64 *mate_qpk = reinterpret_cast<const u64 *>(wave_lds0 + static_cast<size_t>(m) * per_wave_bytes) + j_enc * lds.W;
+      // the owner's read masks, where they lie: packed encodings, bit strings, then the masks open every wave's LDS region
+      const u64 *mate_qm = reinterpret_cast<const u64 *>(wave_lds0 + static_cast<size_t>(m) * per_wave_bytes) + 4 * lds.W + 4 * lds.WB +
+                           j_enc * lds.MB * 4;
       int ha, hb;
       u32 pa, pb;
-      filter_chunk(ix, lds, mate_qpk, j_g2a ? ix.index_a : ix.index_t, (j_L + 15) >> 4, sg, j_g0, j_total,
+      filter_chunk(ix, lds, mate_qm, j_g2a ? ix.index_a : ix.index_t, j_L, sg, j_g0, j_total,
                    j_cbase + got * kHelpChunk, ha, hb, pa, pb);
       ABM_WG_STORE(hw.res_d(mate_slot) + got * 64u + lane, (static_cast<u32>(ha) & 0xFFFFu) | (static_cast<u32>(hb) << 16));
       ABM_WG_STORE(hw.res_p(mate_slot) + got * 128u + lane, pa);

@@ -770,6 +770,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.qbits = lds.qpk + 8 * a.W;
   lds.gwin = lds.qbits + 8 * a.WB;
+  lds.qmask = nullptr; lds.MB = 0;  // (the cooperative filter's read masks: single-end kernel only)
   lds.pcache = lds.gwin + kMaxJobs * a.GW;
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
   lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);

@@ -270,3 +270,32 @@ def test_ghost_reads(oracle, tmp_path_factory, mode, maxc):
         oracle.index_free(oix)
         ctx.close()
         ix.close()
+
+
+@pytest.mark.parametrize("max_len", [150, 192, 193, 240, 300, 448, 449])
+def test_read_lengths_around_the_filter_lane_groups(ctx, oracle, trex_index, max_len):
+    """The cooperative filter shares a candidate's window among 4 lanes up to 192 bases and among 8 up to 448
+    (64 bases of bit planes per lane); longer batches take the one-lane-per-window path.  Same results either side."""
+    import bench
+    from tests.test_gpu_se_parity import compare_se
+    names, starts, gw = bench.read_index_genome(trex_index)
+    dec = np.frombuffer(b"NACNGNNNTNNNNNNN", dtype=np.uint8)
+    rng = np.random.default_rng(max_len)
+    reads = []
+    for k in range(400):
+        L = max_len if k == 0 else int(rng.integers(60, max_len + 1))
+        p = int(rng.integers(int(starts[1]) + 20000, int(starts[2]) - 3000))
+        idx = np.arange(p, p + L)
+        s = dec[(gw[idx >> 4] >> ((idx & 15).astype(np.uint64) << np.uint64(2))) & np.uint64(15)].copy()
+        s[s == ord("C")] = ord("T")
+        mut = rng.random(L) < 0.03
+        s[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+        reads.append(bytes(s).decode().replace("N", "A"))
+    res, cig, off = ctx.map_se(reads)
+    oix = oracle.index_load(trex_index)
+    try:
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, threads=4)
+    finally:
+        oracle.index_free(oix)
+    compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"reads up to {max_len} bases")
+    assert (res["pos"] != 0).mean() > 0.8

@@ -289,7 +289,8 @@ __device__ __forceinline__ u32 narrow2(const DevIndex &ix, const u32 *__restrict
     });
     const u32 at = qbase + p;
     const bool one = at < n_bits ? ((qb[at >> 6] >> (at & 63u)) & 1ull) != 0 : true;
-    if (one) lo = ones; else hi = ones;
+    lo = one ? ones : lo;  // (selects on values: written as stores to one of two references, lo and hi end up in scratch memory)
+    hi = one ? hi : ones;
   }
   if (lo == hi) { --p; lo = plo; hi = phi; }
   return p;
@@ -324,12 +325,75 @@ __device__ __forceinline__ u32 narrow3(const DevIndex &ix, const u32 *__restrict
     }
     const u32 b1 = l1, b2 = l2;
     const u32 sym = sortsym3(q_nibble(qpk, qbase + p), g_to_a);
-    if (sym == 0) hi = b1;
-    else if (sym == mid_sym) { lo = b1; hi = b2; }
-    else lo = b2;
+    const u32 nlo = sym == 0 ? lo : (sym == mid_sym ? b1 : b2), nhi = sym == 0 ? b1 : (sym == mid_sym ? b2 : hi);
+    lo = nlo;
+    hi = nhi;
   }
   if (lo == hi) { --p; lo = plo; hi = phi; }
   return p;
+}
+
+// narrow2 and narrow3 of one seed offset advanced TOGETHER: every round issues the next probe of the 2-letter
+// bisection and of both 3-letter bisections before any of them is waited for (three dependent chains of
+// index-entry -> genome-letter loads in flight per lane instead of one after the other).  Each chain sees exactly
+// the probe sequence and the updates it has in narrow2 / narrow3; a chain with nothing to probe in a round reads
+// entry 0 of its table and ignores it.
+template <bool PLANES>
+__device__ __forceinline__ void narrow_both(const DevIndex &ix, const u32 *__restrict__ tbl3, bool g_to_a, const u64 *qb,
+                                            u32 n_bits, const u64 *qpk, u32 qbase, u32 limit, u32 maxc, u32 &lo2, u32 &hi2,
+                                            u32 &len2, u32 &lo3, u32 &hi3, u32 &len3, u32 &probes) {
+  const u32 *__restrict__ tbl2 = ix.index;
+  const u32 mid_sym = g_to_a ? 2u : 1u, top_sym = g_to_a ? 8u : 4u;
+  u32 pA = kKeyWeight, ploA = lo2, phiA = hi2, blA = 0;
+  int bnA = 0;
+  auto goA = [&]() { return pA != limit && (hi2 - lo2) > maxc && qbase + pA < n_bits + 4096u; };
+  bool actA = goA();
+  if (actA) { blA = lo2; bnA = static_cast<int>(hi2 - lo2); }
+  u32 pB = kKeyWeight3, ploB = lo3, phiB = hi3, l1 = 0, l2 = 0;
+  int n1 = 0, n2 = 0;
+  auto goB = [&]() { return pB != limit && (hi3 - lo3) > maxc; };
+  bool actB = goB();
+  if (actB) { l1 = l2 = lo3; n1 = n2 = static_cast<int>(hi3 - lo3); }
+  while (actA || actB) {
+    const int hA = bnA >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
+    const u32 kA = blA + static_cast<u32>(hA), m1 = l1 + static_cast<u32>(h1), m2 = l2 + static_cast<u32>(h2);
+    const bool dA = actA, d1 = actB && n1 > 0, d2 = actB && n2 > 0 && !(d1 && m2 == m1);
+    const u32 eA = tbl2[dA ? kA : 0u], e1 = tbl3[d1 ? m1 : 0u], e2 = tbl3[d2 ? m2 : 0u];
+    const u32 sA = genome_bit2<PLANES>(ix, static_cast<u64>(eA) + pA);
+    const u32 s1 = genome_sortsym3<PLANES>(ix, static_cast<u64>(e1) + pB, g_to_a);
+    u32 s2 = genome_sortsym3<PLANES>(ix, static_cast<u64>(e2) + pB, g_to_a);
+    probes += (dA ? 1u : 0u) + (d1 ? 1u : 0u) + (d2 ? 1u : 0u);
+    if (actA) {  // one step of first_not (std::lower_bound's probe sequence), then find_candidates' update
+      if (sA < 1u) { blA = kA + 1; bnA -= hA + 1; } else bnA = hA;
+      if (bnA <= 0) {
+        const u32 at = qbase + pA;
+        const bool one = at < n_bits ? ((qb[at >> 6] >> (at & 63u)) & 1ull) != 0 : true;
+        lo2 = one ? blA : lo2;
+        hi2 = one ? hi2 : blA;
+        ++pA;
+        actA = goA();
+        if (actA) { ploA = lo2; phiA = hi2; blA = lo2; bnA = static_cast<int>(hi2 - lo2); }
+      }
+    }
+    if (actB) {
+      if (n2 > 0 && n1 > 0 && m2 == m1) s2 = s1;
+      if (n1 > 0) { if (s1 < mid_sym) { l1 = m1 + 1; n1 -= h1 + 1; } else n1 = h1; }
+      if (n2 > 0) { if (s2 < top_sym) { l2 = m2 + 1; n2 -= h2 + 1; } else n2 = h2; }
+      if (n1 <= 0 && n2 <= 0) {
+        const u32 sym = sortsym3(q_nibble(qpk, qbase + pB), g_to_a);
+        const u32 nlo = sym == 0 ? lo3 : (sym == mid_sym ? l1 : l2), nhi = sym == 0 ? l1 : (sym == mid_sym ? l2 : hi3);
+        lo3 = nlo;
+        hi3 = nhi;
+        ++pB;
+        actB = goB();
+        if (actB) { ploB = lo3; phiB = hi3; l1 = l2 = lo3; n1 = n2 = static_cast<int>(hi3 - lo3); }
+      }
+    }
+  }
+  if (lo2 == hi2) { --pA; lo2 = ploA; hi2 = phiA; }
+  if (lo3 == hi3) { --pB; lo3 = ploB; hi3 = phiB; }
+  len2 = pA;
+  len3 = pB;
 }
 
 // full_compare (src/abismal.cpp:1105-1122).  The reference adds one word's mismatches at a
@@ -417,6 +481,9 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
   if (G == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false);
   return v;
 }
+#ifndef ABM_NARROW_TOGETHER
+#define ABM_NARROW_TOGETHER true  // the two tables' narrowing loops of a seed offset run in lockstep (narrow_both)
+#endif
 #ifndef ABM_COOP_ROUNDS
 #define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (scripts/se_variant.sh): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
 #endif
@@ -465,14 +532,19 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
       shifts |= (cp & 63u) << (8 * r);
-      const u32 b0 = cp / kPlaneBlock, b1 = (cp + L - 1) / kPlaneBlock;
+      // (a group of four always fetches four blocks, 64 contiguous bytes: the memory pipeline merges the loads of a
+      // full quad of lanes into one request, and those of a partly active quad not at all -- measured, 2.5 requests per
+      // window against 1.2; a group of eight fetches the blocks its window has)
+      const u32 b0 = cp / kPlaneBlock, b1 = G == 4 ? b0 + 3 : (cp + L - 1) / kPlaneBlock;
       const bool act = (((second ? wb : wa) >> c) & 1ull) && b0 + sub <= b1;
-      xl[r] = 0; xh[r] = 0;
-      if (act) {
-        const u64 *g = ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub);
-        xl[r] = g[0];
-        xh[r] = g[1];
-      }
+      // Every lane loads, unconditionally, so that the rounds' loads are issued back to back (a load under a
+      // divergent branch is waited for inside it): a lane with nothing to fetch reads the array's first line.
+      // What it gets is never looked at -- its bits could only reach read positions past the end, whose masks
+      // admit every code, or candidates whose result is discarded.
+      const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+                         : ix.planes[0];
+      xl[r] = g[0];
+      xh[r] = g[1];
     }
 #pragma unroll
     for (u32 r = 0; r < kRounds; ++r) {
@@ -724,8 +796,13 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
       if (SPECIFIC) {
         u32 probes = 0;
-        const u32 len2 = narrow2<COOP>(ix, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
-        const u32 len3 = narrow3<COOP>(ix, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
+        u32 len2, len3;
+        if constexpr (ABM_NARROW_TOGETHER)
+          narrow_both<COOP>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, lo2, hi2, len2, lo3, hi3, len3, probes);
+        else {
+          len2 = narrow2<COOP>(ix, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
+          len3 = narrow3<COOP>(ix, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
+        }
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
         chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;
         wt.probes += probes;
@@ -1123,8 +1200,9 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   u32 n = 0;
   auto emit = [&](u32 run, int op) {
     if (n < sink.ctmp_cap) { if (lane == 0) ctmp[n] = (run << 4) | static_cast<u32>(op); }
-    if (op == 1) ins = static_cast<i16>(ins + static_cast<int>(static_cast<u8>(run)));
-    if (op == 2) del = static_cast<i16>(del + static_cast<int>(static_cast<u8>(run)));
+    const int r8 = static_cast<int>(static_cast<u8>(run));
+    ins = op == 1 ? static_cast<i16>(ins + r8) : ins;  // (value selects: conditional stores through the two references go to scratch)
+    del = op == 2 ? static_cast<i16>(del + r8) : del;
     ++n;
   };
   auto step = [&](int a) {

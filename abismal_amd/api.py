@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_reserve", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
-    "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
+    "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
 ]
 
 
@@ -79,6 +79,8 @@ def load_library():
     lib.abm_max_read_length.restype = C.c_uint32
     lib.abm_ctx_reads_too_long.argtypes = [C.c_void_p]
     lib.abm_ctx_reads_too_long.restype = C.c_uint64
+    lib.abm_ctx_filter_on_planes.argtypes = [C.c_void_p]
+    lib.abm_ctx_filter_on_planes.restype = C.c_int
     lib.abm_ctx_take_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.abm_ctx_long_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.abm_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
@@ -206,6 +208,9 @@ class Context:
 
     def reads_too_long(self):
         return int(self._lib.abm_ctx_reads_too_long(self.handle))
+
+    def filter_on_planes(self):
+        return bool(self._lib.abm_ctx_filter_on_planes(self.handle))
 
     def long_cigars(self):
         """abm_ctx_long_cigars: the arena (u32 ops) of CIGARs longer than their slot from the last device call."""

@@ -444,6 +444,7 @@ void abm_default_params(abm_params *p) {
 
 uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx) { return ctx ? ctx->too_long : 0; }
+int abm_ctx_filter_on_planes(const abm_ctx *ctx) { return ctx && ctx->dix.planes[0] != nullptr ? 1 : 0; }
 
 int abm_index_open(const char *path, abm_index **out) {
   return guarded([&] {
@@ -512,12 +513,14 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
                                 h.index_a.size() * 4};
           const void *src[7] = {h.genome.data(),    h.counter.data(), h.counter_t.data(), h.counter_a.data(),
                                 h.index.data(),     h.index_t.data(), h.index_a.data()};
-          size_t offs[9], total = 0;
+          size_t offs[10], total = 0;
           for (int k = 0; k < 7; ++k) { offs[k] = total; total += up(sz[k] + 64); }
           // the filter's bit-plane copies of the genome (DevIndex::planes), derived on the device
           const uint64_t n_bases = h.chrom_starts.empty() ? 0 : h.chrom_starts.back();
           const uint64_t n_blocks = h.multibit_genome ? 0 : (n_bases + abm::kPlaneBlock - 1) / abm::kPlaneBlock + 16;
           for (int k = 7; k < 9; ++k) { offs[k] = total; total += up(n_blocks * 16 + 128); }
+          const uint64_t nmap_words = n_blocks ? ((n_bases >> abm::kPlaneChunkBits) + 64) / 32 + 1 : 0;
+          offs[9] = total; total += up(nmap_words * 4 + 64);
           void *arena = nullptr;
           HIPCHK(hipMalloc(&arena, total));
           try {
@@ -536,13 +539,15 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
             rep.dix.window = h.window;
             rep.dix.min_len = abm::kKeyWeight + h.window - 1;
             rep.dix.planes[0] = rep.dix.planes[1] = nullptr;
+            rep.dix.nmap = nullptr;
             if (n_blocks) {
               auto *p0 = reinterpret_cast<abm::u64 *>(base + offs[7]), *p1 = reinterpret_cast<abm::u64 *>(base + offs[8] + 64);
               abm::u32 *d_bad = reinterpret_cast<abm::u32 *>(base + offs[8]);  // (the first 64 bytes of copy 1's array are free)
-              HIPCHK(abm::launch_make_planes(rep.dix.genome, h.genome.size(), n_bases, n_blocks, p0, p1, d_bad, nullptr));
+              auto *nmap = reinterpret_cast<abm::u32 *>(base + offs[9]);
+              HIPCHK(abm::launch_make_planes(rep.dix.genome, h.genome.size(), n_bases, n_blocks, p0, p1, nmap, d_bad, nullptr));
               abm::u32 bad = 0;
               HIPCHK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
-              if (!bad) { rep.dix.planes[0] = p0; rep.dix.planes[1] = p1; }
+              if (!bad) { rep.dix.planes[0] = p0; rep.dix.planes[1] = p1; rep.dix.nmap = nmap; }
               if (const char *e = std::getenv("ABM_PLANES_COPIES")) if (e[0] == '1') rep.dix.planes[1] = p0;  // experiments only
             }
           }

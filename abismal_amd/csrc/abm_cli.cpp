@@ -1416,6 +1416,9 @@ int cmd_map(int argc, char **argv) {
 }  // namespace
 
 int main(int argc, char **argv) {
+  // batches of several mapper threads overlap on a GPU, each on its own stream; the HIP runtime folds streams onto 4
+  // hardware queues unless told otherwise before it starts (paired-end: 1.8 -> 3.0 M reads/s with 16, bench.py --pe)
+  ::setenv("GPU_MAX_HW_QUEUES", "16", 0);
   try {
     if (argc < 2) { std::cout << "Program: abismal-amd\nVersion: " << kVersion << "\nUsage: abismal-amd <command> [options]\nCommands:\n    map:    map FASTQ reads to an index or a FASTA reference genome\n    idx:    make an index for a FASTA reference genome\n    sim:    simulate WGBS reads for a FASTA reference genome\n"; return EXIT_SUCCESS; }
     const std::string cmd = argv[1];

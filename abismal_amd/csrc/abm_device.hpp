@@ -42,9 +42,16 @@ struct DevIndex {
   // apart -- block k of planes[c] is at byte 16 k + 64 c of a line-aligned array -- so that every window lies
   // inside ONE line of one of them.  Null when the genome has nibbles that are not one-hot.
   const u64 *planes[2];
+  // Two bits cannot say "N" (a blank nibble, which matches nothing: the long N runs the index leaves out, the
+  // padding at both ends); the planes hold code 0 there.  nmap has one bit per chunk of 4096 bases, set if a window
+  // starting in the chunk could reach a blank; the filter redoes such candidates (rare: they lie within a read
+  // length of an N run) on the nibble array.
+  const u32 *nmap;
 };
 constexpr u32 kPlaneBlock = 64;       // bases per bit-plane block
 constexpr u32 kPlaneLineBlocks = 8;   // blocks per 128-byte line
+constexpr u32 kPlaneChunkBits = 12;   // nmap: log2 of the bases per chunk
+constexpr u32 kPlaneReach = 512;      // >= the bases a window of the cooperative filter spans (reads up to 448 + slack)
 
 struct Hit {  // == abm_hit
   i16 diffs;

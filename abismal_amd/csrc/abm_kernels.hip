@@ -73,11 +73,11 @@ __device__ __forceinline__ u32 every_fourth_bit(u64 t) {  // bits 0, 4, 8, ... o
 }
 __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict__ genome, u64 n_words, u64 n_bases,
                                                           u64 n_blocks, u64 *__restrict__ p0, u64 *__restrict__ p1,
-                                                          u32 *__restrict__ bad) {
+                                                          u32 *__restrict__ nmap, u32 *__restrict__ bad) {
   const u64 b = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (b >= n_blocks) return;
   u64 lo = 0, hi = 0;
-  bool odd = false;
+  bool multi = false, blank = false;
   for (u32 k = 0; k < 4; ++k) {
     const u64 w = 4 * b + k;
     const u64 x = w < n_words ? genome[w] : 0ull;
@@ -86,16 +86,22 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict_
     hi |= static_cast<u64>(every_fourth_bit((x >> 2) | (x >> 3))) << (16 * k);
     const u64 ones = (x & 0x1111111111111111ull) + ((x >> 1) & 0x1111111111111111ull) +
                      ((x >> 2) & 0x1111111111111111ull) + ((x >> 3) & 0x1111111111111111ull);
-    u64 want = 0x1111111111111111ull;  // exactly one bit per nibble, for the nibbles that are part of the genome
+    u64 part = 0x1111111111111111ull;  // the nibbles of this word that belong to the genome
     const u64 first = 16 * w;
-    if (first >= n_bases) want = 0;
-    else if (n_bases - first < 16) want &= (1ull << (4 * (n_bases - first))) - 1;
-    const u64 care = want * 15ull;
-    if ((ones & care) != want) odd = true;
+    if (first >= n_bases) part = 0;
+    else if (n_bases - first < 16) part &= (1ull << (4 * (n_bases - first))) - 1;
+    if (ones & (part * 14ull)) multi = true;                         // two or more bits: an IUPAC letter
+    if ((~(ones | (ones >> 1) | (ones >> 2)) & part) != 0) blank = true;  // no bit: N (src/dna_four_bit_bisulfite.hpp:156-165)
   }
   p0[2 * b] = lo; p0[2 * b + 1] = hi;
   p1[2 * b] = lo; p1[2 * b + 1] = hi;
-  if (odd) atomicOr(bad, 1u);
+  if (multi) atomicOr(bad, 1u);
+  if (blank) {
+    // a window that starts up to kPlaneReach bases before this block can see the blank
+    const u64 at = b * kPlaneBlock, from = at >= kPlaneReach ? at - kPlaneReach : 0;
+    for (u64 c = from >> kPlaneChunkBits; c <= (at + kPlaneBlock - 1) >> kPlaneChunkBits; ++c)
+      atomicOr(&nmap[c >> 5], 1u << (c & 31u));
+  }
 }
 
 // =============================================================================
@@ -465,16 +471,16 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   // spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
   // window loads with 8 rounds in flight, 16 waves at 128 registers 1029 ms (20 waves at 96 with spills:
   // 1386); with 2 rounds in flight 20 waves fit almost without spills: 923 ms (24 waves: 999).
-  constexpr int kSeWavesPerCu = 20;
+  constexpr int kSeWavesPerCu = 4 * ABM_SE_WAVES_PER_SIMD;
   return min(per_cu * static_cast<int>(block_waves), kSeWavesPerCu) / static_cast<int>(block_waves) * static_cast<int>(block_waves) *
          prop.multiProcessorCount;
 }
 
 hipError_t launch_make_planes(const u64 *d_genome, u64 n_words, u64 n_bases, u64 n_blocks, u64 *d_planes0,
-                              u64 *d_planes1, u32 *d_bad, hipStream_t st) {
+                              u64 *d_planes1, u32 *d_nmap, u32 *d_bad, hipStream_t st) {
   if (n_blocks == 0) return hipSuccess;
   hipLaunchKernelGGL(make_planes_kernel, dim3(static_cast<u32>((n_blocks + 255) / 256)), dim3(256), 0, st, d_genome,
-                     n_words, n_bases, n_blocks, d_planes0, d_planes1, d_bad);
+                     n_words, n_bases, n_blocks, d_planes0, d_planes1, d_nmap, d_bad);
   return hipGetLastError();
 }
 

@@ -97,9 +97,10 @@ constexpr u32 kPeTier1Cap = ABM_PE_TIER1_CAP;
 u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 // bit-plane copies of the genome for the Hamming filter (DevIndex::planes): n_blocks blocks of 64 bases each,
-// from the first n_words words of nibbles; *bad is set if a nibble below n_bases is not one-hot
+// from the first n_words words of nibbles; blank nibbles (N) mark their surroundings in nmap (DevIndex::nmap,
+// zeroed by the caller); *bad is set if a nibble below n_bases has two or more bits
 hipError_t launch_make_planes(const u64 *d_genome, u64 n_words, u64 n_bases, u64 n_blocks, u64 *d_planes0,
-                              u64 *d_planes1, u32 *d_bad, hipStream_t st);
+                              u64 *d_planes1, u32 *d_nmap, u32 *d_bad, hipStream_t st);
 hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W, u64 *d_packed,
                              u32 *d_lens, hipStream_t st);
 hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W,

@@ -481,6 +481,9 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
   if (G == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false);
   return v;
 }
+#ifndef ABM_NARROW_PLANES
+#define ABM_NARROW_PLANES false  // true (experiments only): narrowing reads the bit planes -- not exact where a probe lands on an N
+#endif
 #ifndef ABM_NARROW_TOGETHER
 #define ABM_NARROW_TOGETHER true  // the two tables' narrowing loops of a seed offset run in lockstep (narrow_both)
 #endif
@@ -506,6 +509,55 @@ __device__ __forceinline__ void build_qmasks(const WaveLds &lds, u32 L) {
     }
 }
 
+#ifdef ABM_EXP_FILTER_NIBBLES  // experiment: the round-1 cooperative filter on the nibble array
+template <u32 kRounds = kCoopRounds>
+__device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, const WaveLds &lds, const u64 *qpk,
+                                             u32 nwords, u32 pos_a, bool want_a, u32 pos_b, bool want_b,
+                                             int &d_a, int &d_b) {
+  const int lane = lane_id();
+  const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
+  const u64 wa = __ballot(want_a), wb = __ballot(want_b);
+  const bool has0 = 2 * sub < nwords, has1 = 2 * sub + 1 < nwords;
+  const u64 q0 = has0 ? qpk[2 * sub] : 0ull, q1 = has1 ? qpk[2 * sub + 1] : 0ull;
+  for (u32 pass = 0; pass * kRounds * per_round < 128; ++pass) {
+    u64 x0[kRounds], x1[kRounds];
+    u32 shifts = 0;  // (pos & 15) of the eight rounds' candidates, four bits each
+#pragma unroll
+    for (u32 r = 0; r < kRounds; ++r) {
+      const u32 slot = (pass * kRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
+      const bool second = (pass * kRounds + r) * per_round >= 64;
+      const u32 c = slot & 63u;
+      const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
+      shifts |= (cp & 15u) << (4 * r);
+      const bool act = (((second ? wb : wa) >> c) & 1ull) && 2 * sub <= nwords;
+      x0[r] = 0; x1[r] = 0;
+      if (act) {
+        const u64 *g = genome + (cp >> 4) + 2 * sub;
+        x0[r] = g[0];
+        x1[r] = g[1];
+      }
+    }
+#pragma unroll
+    for (u32 r = 0; r < kRounds; ++r) {
+      const u32 slot = (pass * kRounds + r) * per_round + grp;
+      const u32 sh = ((shifts >> (4 * r)) & 15u) << 2;
+      // the word after this lane's pair is the next lane's first word
+      const u64 x2 = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r] >> 32)))) << 32) |
+                     static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r])));
+      int d = 0;
+      if (has0) d += 16 - __popcll(q0 & ((x0[r] >> sh) | ((x1[r] << (63 - sh)) << 1)));
+      if (has1) d += 16 - __popcll(q1 & ((x1[r] >> sh) | ((x2 << (63 - sh)) << 1)));
+      d = group_sum(d, G);
+      if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
+    }
+  }
+  wave_sync();
+  d_a = static_cast<i16>(lds.hres[lane]);
+  d_b = static_cast<i16>(lds.hres[64 + lane]);
+  wave_sync();
+}
+
+#endif
 // Hamming distances of 128 candidates (two per lane: pos_a of lane c = candidate c, pos_b = candidate 64 + c)
 // against the genome's bit planes (DevIndex::planes).  G lanes share a candidate: lane s of the group loads block
 // (pos >> 6) + s of the window -- one 16-byte load, every window inside one 128-byte line of one of the two
@@ -524,14 +576,14 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
   if (counts) { const u64 *q = qm + sub * 4; m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; }
   for (u32 pass = 0; pass * kRounds * per_round < 128; ++pass) {
     u64 xl[kRounds], xh[kRounds];
-    u32 shifts = 0;  // (pos & 63) of the rounds' candidates, eight bits each
+    u64 shifts = 0;  // (pos & 63) of the rounds' candidates, eight bits each (up to eight rounds)
 #pragma unroll
     for (u32 r = 0; r < kRounds; ++r) {
       const u32 slot = (pass * kRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
       const bool second = (pass * kRounds + r) * per_round >= 64;
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
-      shifts |= (cp & 63u) << (8 * r);
+      shifts |= static_cast<u64>(cp & 63u) << (8 * r);
       // (a group of four always fetches four blocks, 64 contiguous bytes: the memory pipeline merges the loads of a
       // full quad of lanes into one request, and those of a partly active quad not at all -- measured, 2.5 requests per
       // window against 1.2; a group of eight fetches the blocks its window has)
@@ -549,7 +601,7 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
 #pragma unroll
     for (u32 r = 0; r < kRounds; ++r) {
       const u32 slot = (pass * kRounds + r) * per_round + grp;
-      const u32 sh = (shifts >> (8 * r)) & 63u;
+      const u32 sh = static_cast<u32>(shifts >> (8 * r)) & 63u;
       const u64 nl = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(xl[r] >> 32)))) << 32) |
                      static_cast<u32>(dpp_row_shl1(static_cast<int>(xl[r])));
       const u64 nh = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(xh[r] >> 32)))) << 32) |
@@ -709,7 +761,7 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
 
 // distances and positions of candidates [c0, c0 + 128) of a flattened block (two per lane: c0 + lane
 // and c0 + 64 + lane), reached out of sequence -- what a claimed chunk of a job computes
-__device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qm, const u32 *idx3,
+__device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qm, const u64 *qpk, const u32 *idx3,
                                              u32 L, const Segs &sg, u32 g0, u32 total, u32 c0, int &ha, int &hb,
                                              u32 &pa, u32 &pb) {
   int carry = seg_before(sg, c0);
@@ -722,7 +774,13 @@ __device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &
   if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
   pa = ea - (g0 + static_cast<u32>(oa));
   pb = eb - (g0 + static_cast<u32>(ob));
+  const u32 na = va ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
+  const u32 nb = vb ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
   hamming_planes<ABM_HELP_ROUNDS>(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
+  if (__any((na | nb) & 1u)) {
+    if (na & 1u) ha = hamming(ix.genome, qpk, (L + 15) >> 4, pa);
+    if (nb & 1u) hb = hamming(ix.genome, qpk, (L + 15) >> 4, pb);
+  }
   if (!va) ha = 0x7fff;
   if (!vb) hb = 0x7fff;
 }
@@ -792,13 +850,15 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
 #pragma unroll
       for (u32 j = 0; j < 16; ++j)
         k3 = k3 * 3u + trit(static_cast<u32>(win >> (j << 2)) & 15u, g_to_a);
+      // (keeping the specific pass's counters in LDS for the sensitive pass, which looks the first max(window, L/2)
+      // offsets up again, took 4.4 % of the line requests away and made the kernel 1.6 % slower: measured, removed)
       lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
       lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
       if (SPECIFIC) {
         u32 probes = 0;
         u32 len2, len3;
         if constexpr (ABM_NARROW_TOGETHER)
-          narrow_both<COOP>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, lo2, hi2, len2, lo3, hi3, len3, probes);
+          narrow_both<COOP && ABM_NARROW_PLANES>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, lo2, hi2, len2, lo3, hi3, len3, probes);
         else {
           len2 = narrow2<COOP>(ix, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
           len3 = narrow3<COOP>(ix, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
@@ -935,7 +995,18 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
           const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
           const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
           if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
+#ifdef ABM_EXP_FILTER_NIBBLES
+            hamming_coop(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+#else
+            // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
+            const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
+            const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
             hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+            if (__any((na | nb) & 1u)) {  // rare: redone on the nibble array, where an N is an N
+              if (na & 1u) ha = hamming(ix.genome, qpk, nwords, pa);
+              if (nb & 1u) hb = hamming(ix.genome, qpk, nwords, pb);
+            }
+#endif
             hma = ha; hmb = hb;
           }
           else
@@ -971,7 +1042,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
             {
               int xa, xb;
               u32 ya, yb;
-              filter_chunk(ix, lds, lds.qmask + enc * lds.MB * 4, idx3, L, sg, g0, total, c0, xa, xb, ya, yb);
+              filter_chunk(ix, lds, lds.qmask + enc * lds.MB * 4, qpk, idx3, L, sg, g0, total, c0, xa, xb, ya, yb);
               if (__any(xa != ha || xb != hb || (xa != 0x7fff && ya != pa) || (xb != 0x7fff && yb != pb))) hw->mismatch = true;
             }
 #endif
@@ -1050,7 +1121,8 @@ __device__ __forceinline__ void help_block_mates(const DevIndex &ix, const WaveL
                            j_enc * lds.MB * 4;
       int ha, hb;
       u32 pa, pb;
-      filter_chunk(ix, lds, mate_qm, j_g2a ? ix.index_a : ix.index_t, j_L, sg, j_g0, j_total,
+      const u64 *mate_qpk = reinterpret_cast<const u64 *>(wave_lds0 + static_cast<size_t>(m) * per_wave_bytes) + j_enc * lds.W;
+      filter_chunk(ix, lds, mate_qm, mate_qpk, j_g2a ? ix.index_a : ix.index_t, j_L, sg, j_g0, j_total,
                    j_cbase + got * kHelpChunk, ha, hb, pa, pb);
       ABM_WG_STORE(hw.res_d(mate_slot) + got * 64u + lane, (static_cast<u32>(ha) & 0xFFFFu) | (static_cast<u32>(hb) << 16));
       ABM_WG_STORE(hw.res_p(mate_slot) + got * 128u + lane, pa);

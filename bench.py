@@ -24,6 +24,13 @@ across ranks with the index replicated per GPU; the only collective is the
 end-of-run RCCL all-reduce of the mapping statistics.
 """
 import argparse
+import os
+
+# Paired-end steps of several (context, stream) slots overlap on the device (tier 2 ends in a few pairs that keep
+# single waves busy for seconds); the HIP runtime multiplexes streams onto 4 hardware queues unless told otherwise,
+# and must be told before it starts.  Measured at hg38 scale, 1 M pairs per step: 4 queues / 3 slots 1.8 M reads/s,
+# 16 queues / 12 slots 3.0 M reads/s (scripts/r02_pe_queues.sh).  Single-end is unaffected.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import json
 import os
 import struct
@@ -595,8 +602,8 @@ def dist_dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --pe: 16, so that the slots overlap)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 1; --pe: one per slot)")
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("ABM_BENCH_GENOME_MBP", 3100)))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ABM_BENCH_READS", 10_000_000)),
                     help="reads per step per GPU")
@@ -605,7 +612,7 @@ def main():
     ap.add_argument("--pe", action="store_true",
                     help="paired-end variant (BASELINE config 3): 2 x --read-len pairs from 150-500 bp fragments; "
                          "not the headline metric -- prints its own JSON line")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=12,
                     help="--pe only: consecutive steps alternate over this many (context, stream) slots")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="SE: number of different synthetic batches the steps cycle through")
@@ -625,6 +632,10 @@ def main():
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 16 if args.pe else 3
+    if args.warmup is None:
+        args.warmup = args.streams if args.pe else 1
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not under_launcher and args.gpus > 1:
@@ -684,6 +695,7 @@ def main():
     t0 = time.time()
     index = A.Index(idx)
     ctx = A.Context(index, local_rank)
+    filter_genome = "bit planes (cooperative window loads)" if ctx.filter_on_planes() else "nibble array (one lane per window)"
     t_load = time.time() - t0
     log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident)")
 
@@ -936,6 +948,7 @@ def main():
         "tail_help_per_launch": {k: round(v / max(1, launches), 1) for k, v in work["help"].items()} if "help" in work else None,
         "phase_shares_diagnostic": phases,
         "kernel_status": st_host,
+        "filter_genome": filter_genome,
         "long_cigars": {"slot_ops": stride, "reads_beyond_slot": n_long_cigars, "returned_through": "per-launch arena (abm_ctx_long_cigars)"},
         "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
     }

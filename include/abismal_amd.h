@@ -150,6 +150,11 @@ uint32_t abm_max_read_length(void); /* longest read the kernels map (the referen
  * everything else in their batch is mapped as usual. */
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx);
 
+/* Which form of the genome the Hamming filter of this context's device reads for batches of reads up to 448 bases:
+   1 = the bit planes derived at upload (cooperative window loads; every genome without IUPAC ambiguity letters),
+   0 = the nibble array, one lane per window (genomes with IUPAC letters).  Results are the same; the rate is not. */
+int abm_ctx_filter_on_planes(const abm_ctx *ctx);
+
 /* Measurement hook (no reference counterpart): exact work tallies accumulated
  * by every launch on this context since the previous call, then reset:
  * [0] seed offsets probed, [1] bucket-narrowing search probes, [2] candidates

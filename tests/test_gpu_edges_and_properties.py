@@ -299,3 +299,39 @@ def test_read_lengths_around_the_filter_lane_groups(ctx, oracle, trex_index, max
         oracle.index_free(oix)
     compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"reads up to {max_len} bases")
     assert (res["pos"] != 0).mean() > 0.8
+
+
+def test_windows_that_reach_into_an_n_run(oracle, workdir):
+    """Candidates whose genome window overlaps a long N run (blank nibbles: they match nothing, not even the padding
+    of a read's last word) are redone on the nibble array by the bit-plane filter.  Reads cut right at the edges of
+    an N run, at every distance 0..24 from it, and on both strands."""
+    import abismal_amd as A
+    from tests import synth
+    from tests.test_gpu_se_parity import compare_se
+    fa = os.path.join(workdir, "nrun.fa")
+    synth.repeat_rich_genome(fa, seed=11, n_chroms=2, chrom_len=400_000)
+    idx = os.path.join(workdir, "nrun.idx")
+    oracle.index_build(fa, idx, threads=4)
+    chroms = [np.frombuffer(rec.split(b"\n", 1)[1].replace(b"\n", b"").upper(), dtype=np.uint8)
+              for rec in open(fa, "rb").read().split(b">")[1:]]
+    reads = []
+    for ch in chroms:
+        mid = len(ch) // 2
+        for L in (100, 97, 150):
+            for k in range(25):
+                for seg in (ch[mid - L - k: mid - k], ch[mid + 3000 + k: mid + 3000 + k + L], ch[50 + k: 50 + k + L] if ch[0] == ord("N") else ch[k: k + L]):
+                    s = seg.copy()
+                    s[s == ord("C")] = ord("T")
+                    reads.append(bytes(s).decode())
+                    reads.append(bytes(synth.COMP[seg[::-1]]).decode().replace("C", "T"))
+    index = A.Index(idx)
+    ctx = A.Context(index, 0)
+    assert ctx.filter_on_planes()  # N runs (long ones stay blank nibbles) do not take the genome off the bit planes
+    res, cig, off = ctx.map_se(reads)
+    oix = oracle.index_load(idx)
+    try:
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, threads=4)
+    finally:
+        oracle.index_free(oix)
+    compare_se(res, cig, off, o_res, o_cig, o_n, reads, "reads at the edges of N runs")
+    assert (res["pos"] != 0).mean() > 0.5

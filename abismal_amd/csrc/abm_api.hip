@@ -362,7 +362,9 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : std::max(params->valid_frac, params->valid_frac);
   a.W = W; a.WB = WB; a.max_len = eff_len; a.GW = abm::se_window_words(eff_len, size_frac);
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
-  a.G = (W <= 7 ? 4u : 8u);  // only read by a paired-end build with cooperative window loads (ABM_PE_COOP)
+  // cooperative window loads from the bit planes, as in the single-end path (see there)
+  a.G = a.ix.planes[0] == nullptr ? 0u : (eff_len <= 4 * abm::kPlaneBlock - 64 ? 4u : (eff_len <= 8 * abm::kPlaneBlock - 64 ? 8u : 0u));
+  if (const char *e = std::getenv("ABM_COOP_WINDOWS")) if (e[0] == '0') a.G = 0;
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.min_frag = params->min_frag; a.max_frag = params->max_frag;

@@ -1020,7 +1020,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
           if (!va) { ha = hma = 0x7fff; }
           if (!vb) { hb = hmb = 0x7fff; }
           wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
-          wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * nwords;
+          // 8-byte words fetched per window: the read's words on the nibble array; on the bit planes a group of four
+          // lanes fetches four 16-byte blocks, a group of eight the blocks its window has (at most L / 64 + 2)
+          const u32 fetched = COOP ? (lds.G == 4 ? 8u : 2u * ((L + kPlaneBlock - 1) / kPlaneBlock + 1)) : nwords;
+          wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * fetched;
           wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
         }
         else {

@@ -11,9 +11,6 @@
 #include "abm_kernels_core.hpp"
 #include "abm_pe_set.hpp"
 
-#ifndef ABM_PE_COOP
-#define ABM_PE_COOP false
-#endif
 #ifndef ABM_PE_WAVES_PER_SIMD
 #define ABM_PE_WAVES_PER_SIMD 4
 #endif
@@ -49,7 +46,9 @@ struct PairBest {
   }
 };
 
-template <bool BIG> struct PeWave {
+// COOP: the seed passes filter on the genome's bit planes with cooperative window loads (hamming_planes), as the
+// single-end kernel does; otherwise one lane per window on the nibble array (genomes with IUPAC letters, reads > 448)
+template <bool BIG, bool COOP> struct PeWave {
   const PeArgs &a;
   WaveLds lds;      // qpk/qbits point at end 0; end 1 follows at +4W / +4WB
   PeLds pl;
@@ -74,6 +73,7 @@ template <bool BIG> struct PeWave {
     WaveLds w = lds;
     w.qpk = lds.qpk + end * 4 * lds.W;
     w.qbits = lds.qbits + end * 4 * lds.WB;
+    w.qmask = lds.qmask + end * 4 * lds.MB * 4;
     return w;
   }
   __device__ __forceinline__ u32 *cig_of(int end, u64 r) const { return (end ? a.cig2 : a.cig1) + r * a.cig_stride; }
@@ -91,10 +91,10 @@ template <bool BIG> struct PeWave {
     P.begin_read(L[end]);
     if (L[end] >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, ABM_PE_COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+      seed_pass<true, TIMED, COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, ABM_PE_COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+        seed_pass<false, TIMED, COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
       }
     }
     need_big |= P.overflow;
@@ -557,17 +557,18 @@ template <bool BIG> struct PeWave {
   }
 };
 
-template <bool BIG, bool TIMED>
+template <bool BIG, bool TIMED, bool COOP>
 __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  PeWave<BIG> w{a};
+  PeWave<BIG, COOP> w{a};
   WaveLds &lds = w.lds;
   lds.W = a.W; lds.WB = a.WB; lds.GW = a.GW;
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.qbits = lds.qpk + 8 * a.W;
-  lds.gwin = lds.qbits + 8 * a.WB;
-  lds.qmask = nullptr; lds.MB = 0;  // (the cooperative filter's read masks: single-end kernel only)
+  lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
+  lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
+  lds.gwin = lds.qmask + 8 * lds.MB * 4;
   lds.pcache = lds.gwin + kMaxJobs * a.GW;
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
   lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
         const u64 word = __ballot(b);
         if (lane == 0) lds.qbits[e8 * a.WB + wb] = word;
       }
+    if constexpr (COOP) { build_qmasks(w.lds_of(0), w.L[0]); build_qmasks(w.lds_of(1), w.L[1]); }
     wave_sync();
     #pragma unroll
     for (int e = 0; e < 2; ++e)  // 44-46 bases: seeds reach past the end of the read (see ghost_bits)
@@ -790,7 +792,9 @@ __global__ __launch_bounds__(256) void big_scatter_kernel(const u8 *__restrict__
 }
 
 size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big) {
-  size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
+  const u32 MB = (max_len + kPlaneBlock - 1) / kPlaneBlock;
+  size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + static_cast<size_t>(8) * MB * 4 * 8 +
+             (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
              static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + 64 * 2;
   if (!big) b += static_cast<size_t>(cap) * (4 + 2 * 4 + 4 * 2);
   b += tb_extra_bytes(GW, max_len, valid_frac);
@@ -801,22 +805,25 @@ int pe_resident_waves(size_t lds, bool big) {
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  const hipError_t e = big ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<true, false>, 64, lds)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<false, false>, 64, lds);
+  const hipError_t e = big ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<true, false, true>, 64, lds)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<false, false, true>, 64, lds);
   if (e != hipSuccess) return 0;
   return per_cu * prop.multiProcessorCount;
 }
 
+template <bool BIG, bool TIMED>
+static void launch_pe_variant(const PeArgs &a, size_t lds, u32 grid, hipStream_t st) {
+  // a.G != 0: the filter reads the genome's bit planes (cooperative window loads)
+  if (a.G != 0) hipLaunchKernelGGL((map_pe_kernel<BIG, TIMED, true>), dim3(grid), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((map_pe_kernel<BIG, TIMED, false>), dim3(grid), dim3(64), lds, st, a);
+}
+
 hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st) {
   if (grid == 0) return hipSuccess;
-  if (big && timed)
-    hipLaunchKernelGGL((map_pe_kernel<true, true>), dim3(grid), dim3(64), lds, st, a);
-  else if (big)
-    hipLaunchKernelGGL((map_pe_kernel<true, false>), dim3(grid), dim3(64), lds, st, a);
-  else if (timed)
-    hipLaunchKernelGGL((map_pe_kernel<false, true>), dim3(grid), dim3(64), lds, st, a);
-  else
-    hipLaunchKernelGGL((map_pe_kernel<false, false>), dim3(grid), dim3(64), lds, st, a);
+  if (big && timed) launch_pe_variant<true, true>(a, lds, grid, st);
+  else if (big) launch_pe_variant<true, false>(a, lds, grid, st);
+  else if (timed) launch_pe_variant<false, true>(a, lds, grid, st);
+  else launch_pe_variant<false, false>(a, lds, grid, st);
   return hipGetLastError();
 }
 

@@ -695,7 +695,8 @@ def main():
     t0 = time.time()
     index = A.Index(idx)
     ctx = A.Context(index, local_rank)
-    filter_genome = "bit planes (cooperative window loads)" if ctx.filter_on_planes() else "nibble array (one lane per window)"
+    on_planes = ctx.filter_on_planes()
+    filter_genome = "bit planes (cooperative window loads)" if on_planes else "nibble array (one lane per window)"
     t_load = time.time() - t0
     log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident)")
 
@@ -802,8 +803,11 @@ def main():
         return sum(stage.values()), stage
 
     fetched = per_launch["candidates"] - per_launch["window_cache_hits"]
+    # 8-byte words a fetched window costs: the read's words on the nibble array; four 16-byte blocks of the bit planes
+    # per group of four lanes (reads up to 192 bases), the blocks the window has per group of eight
+    words_per_window = nwords if not on_planes else (8 if L <= 192 else 2 * ((L + 63) // 64 + 1))
     k_bytes, k_stage = alg_bytes_per_read(per_launch["seed_offsets"] / n, per_launch["search_probes"] / n,
-                                          per_launch["candidates"] / n, fetched * nwords / n,
+                                          per_launch["candidates"] / n, fetched * words_per_window / n,
                                           per_launch["alignments"] / n, ops_per_read, C_windows=fetched / n)
     n_long_cigars = int((cig_n > stride).sum().item())
     avg_ms = kernel_ms / max(1, launches)

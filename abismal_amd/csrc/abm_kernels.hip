@@ -104,6 +104,13 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict_
   }
 }
 
+// bytes of LDS the staging area of the filter needs beyond the regions it lies over (see map_se_body)
+__host__ __device__ inline u32 se_stage_extra(u32 ctmp_cap, u32 GW) {
+  const u32 cap2 = (ctmp_cap + 1) & ~1u;
+  const u32 over = cap2 * 4 + 2 * kSeCap * 4 + kMaxJobs * GW * 8;
+  return (ABM_STAGE_WINDOWS && over < kStageBytes) ? ((kStageBytes - over + 15) & ~15u) : 0u;
+}
+
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
@@ -130,14 +137,22 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   lds.qbits = lds.qpk + 4 * a.W;
   lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
   lds.qmask = lds.qbits + 4 * a.WB;
-  lds.gwin = lds.qmask + 4 * lds.MB * 4;
-  lds.pcache = lds.gwin + kMaxJobs * a.GW;
-  // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
-  lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
-  lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
-  lds.jpos = lds.ctmp + a.ctmp_cap;
-  lds.jdf = lds.jpos + kSeCap;
-  lds.lbest = reinterpret_cast<int *>(lds.jdf + kSeCap);
+  // [stage extra | CIGAR scratch | alignment job lists | alignment windows] are contiguous and idle during the seed
+  // passes: the filter's LDS-DMA staging area (ABM_STAGE_WINDOWS) lies over them
+  {
+    unsigned char *p = reinterpret_cast<unsigned char *>(lds.qmask + 4 * lds.MB * 4);
+    const u32 cap2 = (a.ctmp_cap + 1) & ~1u;
+    lds.stage = ABM_STAGE_WINDOWS ? p : nullptr;
+    p += se_stage_extra(a.ctmp_cap, a.GW);
+    lds.ctmp = reinterpret_cast<u32 *>(p); p += cap2 * 4;
+    lds.jpos = reinterpret_cast<u32 *>(p); p += kSeCap * 4;
+    lds.jdf = reinterpret_cast<u32 *>(p); p += kSeCap * 4;
+    lds.gwin = reinterpret_cast<u64 *>(p); p += kMaxJobs * a.GW * 8;
+    lds.pcache = reinterpret_cast<u64 *>(p); p += (8u << kPosCacheBits) + a.tb_extra;
+    // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
+    lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
+    lds.lbest = reinterpret_cast<int *>(p);
+  }
   lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
   lds.hres = reinterpret_cast<u16 *>(lds.lbest);  // 128 x u16 = the 64 ints of lbest, idle during the seed passes
   lds.G = a.G;
@@ -447,7 +462,7 @@ size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_fra
   const u32 MB = (max_len + kPlaneBlock - 1) / kPlaneBlock;
   size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + static_cast<size_t>(4) * MB * 4 * 8 +
              (static_cast<size_t>(8) << kPosCacheBits) +
-             static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>(cig_stride) * 4 +
+             static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>((cig_stride + 1) & ~1u) * 4 + se_stage_extra(cig_stride, GW) +
              2 * kSeCap * 4 + 64 * 4 + 64 * 2;
   b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);

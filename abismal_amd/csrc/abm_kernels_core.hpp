@@ -212,6 +212,7 @@ struct WaveLds {
   u64 *qpk;    // [4][W] packed encodings
   u64 *qbits;  // [4][WB] 2-letter bit strings, bit j = bit2(nibble j), 1 past the end
   u64 *qmask;  // [4][MB][4] per block of 64 read bases: which of them admit genome code 0, 1, 2, 3 (cooperative filter)
+  u8 *stage;   // kStageRounds x 1 KiB (+ 32 bytes): window blocks land here straight from memory (single-end kernel; null: registers)
   u16 *mark;   // [64]
   u32 *ctmp;   // [ctmp_cap] reversed CIGAR scratch
   u8 *tb;      // traceback bytes
@@ -481,6 +482,9 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
   if (G == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false);
   return v;
 }
+#ifndef ABM_STAGE_WINDOWS
+#define ABM_STAGE_WINDOWS false  // single-end kernel: window blocks through LDS-DMA loads (hamming_planes_staged)
+#endif
 #ifndef ABM_NARROW_PLANES
 #define ABM_NARROW_PLANES false  // true (experiments only): narrowing reads the bit planes -- not exact where a probe lands on an N
 #endif
@@ -614,6 +618,58 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
     }
   }
   wave_sync();
+  d_a = static_cast<i16>(lds.hres[lane]);
+  d_b = static_cast<i16>(lds.hres[64 + lane]);
+  wave_sync();
+}
+
+// The same through LDS: the 16-byte window blocks of kStageRounds rounds (16 candidates each for groups of four)
+// are fetched by LDS-DMA loads (global_load_lds_dwordx4: no destination registers, the wave's 64 x 16 bytes land
+// lane-linear in a 1 KiB piece of lds.stage), so twice as many windows are in flight per lane as the register
+// version affords at 96 VGPRs; a lane then reads its own block and the next lane's (the bits past its block) back
+// with two ds_read_b128.  Same arithmetic, same results.
+constexpr u32 kStageRounds = 4;
+constexpr u32 kStageBytes = kStageRounds * 1024 + 32;
+__device__ __forceinline__ void hamming_planes_staged(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
+                                                      u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
+  const int lane = lane_id();
+  const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
+  const u64 wa = __ballot(want_a), wb = __ballot(want_b);
+  const bool counts = sub * kPlaneBlock < L;
+  u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  if (counts) { const u64 *q = qm + sub * 4; m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; }
+  typedef __attribute__((address_space(3))) void lds_void;
+  for (u32 pass = 0; pass * kStageRounds * per_round < 128; ++pass) {
+    u32 shifts = 0;  // (pos & 63) of the rounds' candidates, eight bits each
+#pragma unroll
+    for (u32 r = 0; r < kStageRounds; ++r) {
+      const u32 slot = (pass * kStageRounds + r) * per_round + grp;
+      const bool second = (pass * kStageRounds + r) * per_round >= 64;
+      const u32 c = slot & 63u;
+      const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
+      shifts |= (cp & 63u) << (8 * r);
+      const u32 b0 = cp / kPlaneBlock, b1 = G == 4 ? b0 + 3 : (cp + L - 1) / kPlaneBlock;
+      const bool act = (((second ? wb : wa) >> c) & 1ull) && b0 + sub <= b1;
+      const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+                         : ix.planes[0];
+      __builtin_amdgcn_global_load_lds(g, (lds_void *)(lds.stage + r * 1024), 16, 0, 0);  // (generic -> LDS address space)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (u32 r = 0; r < kStageRounds; ++r) {
+      const u32 slot = (pass * kStageRounds + r) * per_round + grp;
+      const u32 sh = (shifts >> (8 * r)) & 63u;
+      const u64 *blk = reinterpret_cast<const u64 *>(lds.stage + r * 1024 + lane * 16);
+      const u64 xl = blk[0], xh = blk[1], nl = blk[2], nh = blk[3];
+      const u64 gl = (xl >> sh) | ((nl << (63 - sh)) << 1), gh = (xh >> sh) | ((nh << (63 - sh)) << 1);
+      const u64 match = (~gh & ((~gl & m0) | (gl & m1))) | (gh & ((~gl & m2) | (gl & m3)));
+      int d = counts ? 64 - __popcll(match) : 0;
+      d = group_sum(d, G);
+      if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
+    }
+    wave_sync();  // the next pass's loads overwrite the pieces
+  }
   d_a = static_cast<i16>(lds.hres[lane]);
   d_b = static_cast<i16>(lds.hres[64 + lane]);
   wave_sync();
@@ -1001,7 +1057,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
             // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
             const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
             const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-            hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+            if constexpr (MODE == kMain && ABM_STAGE_WINDOWS)
+              hamming_planes_staged(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+            else
+              hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
             if (__any((na | nb) & 1u)) {  // rare: redone on the nibble array, where an N is an N
               if (na & 1u) ha = hamming(ix.genome, qpk, nwords, pa);
               if (nb & 1u) hb = hamming(ix.genome, qpk, nwords, pb);

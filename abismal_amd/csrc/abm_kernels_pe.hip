@@ -568,6 +568,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   lds.qbits = lds.qpk + 8 * a.W;
   lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
   lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
+  lds.stage = nullptr;  // (LDS-DMA staging of window blocks: single-end kernel only)
   lds.gwin = lds.qmask + 8 * lds.MB * 4;
   lds.pcache = lds.gwin + kMaxJobs * a.GW;
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)

@@ -82,7 +82,7 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
             f"{cnt['TCC_EA0_RDREQ_sum'] / 1e9:.2f} G read requests from the L2s to the fabric per launch, all of them 128-byte lines = "
             f"{nbytes / 1e12:.2f} TB = {nbytes / secs / 1e12:.2f} TB/s during the kernel ({secs * 1e3:.0f} ms under the counters).  "
             "`TCC_EA0_RDREQ` counts Infinity-Cache hits too, so this is fabric request traffic and an UPPER bound on HBM bytes "
-            "(MI355X_MICROARCH.md, HBM).  It is about 2.6x the kernel-tally bytes and 5x the strict bytes: every 8-72-byte "
-            "gather costs a whole 128-byte line.\n\n")
+            f"(MI355X_MICROARCH.md, HBM).  It is {nbytes / (rf['alg_bytes_per_read_kernel_tally'] * n_reads):.1f}x the kernel-tally bytes and "
+            f"{nbytes / (rf['alg_bytes_per_read_strict'] * n_reads):.1f}x the strict bytes: every 8-64-byte gather costs a whole 128-byte line.\n\n")
     f.write("Work per read in that run: " + ", ".join(f"{k} {v}" for k, v in line["work_per_read"].items()) + ".\n")
 print(open(os.path.join(dst, f"{tag}_README.md")).read())

@@ -129,6 +129,11 @@ struct abm_ctx {
   size_t arena_want = 0;                        // arena size the host entry points ask for (0 = default)
   uint64_t too_long = 0;                        // reads (pairs) beyond kMaxReadLen seen by the host entry points
   HostBuf<abm::u32> h_cn, h_slots, h_arena, h_cn2, h_slots2;
+  HostBuf<uint64_t> h_rel, h_rel2;  // offsets relative to the batch's first read (batches that do not start at 0)
+  HostBuf<abm::u32> h_tail;         // {arena count, status} of the last launch of a host-buffer entry point
+  DevBuf<abm::u32> finished;
+  bool host_results = false;        // set by abm_map_se_batch around its launches: arena and summary words in pinned memory
+  HostBuf<abm_hit> h_res;           // hits on their way out (a pinned target keeps the copy on the DMA engines)
   DevBuf<char> help_ws;  // tail-help workspace of the single-end kernel (see HelpArgs)
   unsigned launch_seq = 0;
   // every device entry point reuses this context's workspaces: a call first makes its stream wait for
@@ -226,12 +231,25 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.ctmp_cap = eff_len + 2;
   {  // arena for the CIGARs that outgrow their slot: few reads do, one op per read is ample
     const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, n));
-    ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
     ctx->cig_arena_count.reserve(1);
     HIPCHK(hipMemsetAsync(ctx->cig_arena_count.p, 0, 4, st));
-    a.cig_arena = ctx->cig_arena.p;
     a.cig_arena_count = ctx->cig_arena_count.p;
-    a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->cig_arena.cap, 0xFFFFFF00u));
+    if (ctx->host_results) {  // (abm_map_se_batch: the arena lies in pinned host memory, like the rest of its results)
+      ctx->h_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+      ctx->h_tail.reserve(2);
+      ctx->finished.reserve(1);
+      HIPCHK(hipMemsetAsync(ctx->finished.p, 0, 4, st));
+      ctx->h_tail.p[0] = ctx->h_tail.p[1] = 0;
+      a.cig_arena = ctx->h_arena.p;
+      a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->h_arena.cap, 0xFFFFFF00u));
+      a.finished = ctx->finished.p;
+      a.host_tail = ctx->h_tail.p;
+    }
+    else {
+      ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+      a.cig_arena = ctx->cig_arena.p;
+      a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->cig_arena.cap, 0xFFFFFF00u));
+    }
   }
   a.cig_n = d_cig_n;
   a.status = d_status;
@@ -291,6 +309,51 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
 // arena with slot[0] = where -- into the caller's compact blob + n + 1 offsets, in read order.  Host-side on
 // purpose: no kernel has to run after the mapping kernel, so a batch's results leave the GPU while the next
 // batch's (persistent, device-filling) mapping kernel is already running.
+// fn(lo, hi) over [0, n) on a few host threads (the batch entry points' passes over per-read arrays: with 8 M reads
+// per batch a single-threaded pass costs tens of ms -- hundreds while the CLI's parser threads own the memory bus)
+template <class F> void parallel_ranges(uint64_t n, F &&fn) {
+  const unsigned nt = n > (1u << 18) ? 8u : 1u;
+  if (nt == 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err;
+  std::mutex emu;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try { fn(n * t / nt, n * (t + 1) / nt); }
+      catch (...) { std::lock_guard<std::mutex> lk(emu); err = std::current_exception(); }
+    });
+  for (auto &x : th) x.join();
+  if (err) std::rethrow_exception(err);
+}
+
+// offsets of a host batch: monotone?  longest read, reads beyond the kernels' cap; offsets relative to the first
+// (into `rel`, pinned, when the batch does not start at 0 -- else the caller's array is used as it is)
+struct OffsetScan { uint32_t max_len = 0; uint64_t too_long = 0; const uint64_t *use = nullptr; };
+OffsetScan scan_offsets(const uint64_t *seq_off, uint64_t n, HostBuf<uint64_t> &rel) {
+  OffsetScan out;
+  const uint64_t base = seq_off[0];
+  if (base != 0) rel.reserve(n + 1);
+  uint64_t *r = base != 0 ? rel.p : nullptr;
+  std::mutex mu;
+  parallel_ranges(n, [&](uint64_t lo, uint64_t hi) {
+    uint32_t ml = 0;
+    uint64_t tl = 0;
+    for (uint64_t i = lo; i < hi; ++i) {
+      if (seq_off[i + 1] < seq_off[i]) throw std::invalid_argument("seq_off not monotone");
+      const uint64_t len = seq_off[i + 1] - seq_off[i];
+      ml = std::max<uint32_t>(ml, static_cast<uint32_t>(std::min<uint64_t>(len, 0xFFFFFFFFu)));
+      tl += len > abm::kMaxReadLen;
+      if (r) r[i] = seq_off[i] - base;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    out.max_len = std::max(out.max_len, ml);
+    out.too_long += tl;
+  });
+  if (r) r[n] = seq_off[n] - base;
+  out.use = r ? r : seq_off;
+  return out;
+}
+
 void assemble_cigars(uint64_t n, uint32_t stride, const uint32_t *cn, const uint32_t *slots, const uint32_t *arena,
                      uint64_t arena_n, uint32_t *out_blob, uint64_t cap, uint64_t *out_off) {
   out_off[0] = 0;
@@ -308,18 +371,7 @@ void assemble_cigars(uint64_t n, uint32_t stride, const uint32_t *cn, const uint
       std::memcpy(out_blob + out_off[i], src, k * 4ull);
     }
   };
-  const unsigned nt = n > (1u << 18) ? 8u : 1u;
-  if (nt == 1) { fill(0, n); return; }
-  std::vector<std::thread> th;
-  std::exception_ptr err;
-  std::mutex emu;
-  for (unsigned t = 0; t < nt; ++t)
-    th.emplace_back([&, t] {
-      try { fill(n * t / nt, n * (t + 1) / nt); }
-      catch (...) { std::lock_guard<std::mutex> lk(emu); err = std::current_exception(); }
-    });
-  for (auto &x : th) x.join();
-  if (err) std::rethrow_exception(err);
+  parallel_ranges(n, fill);
 }
 
 void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob1,
@@ -587,7 +639,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->ix->replicas.erase(it);
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->help_ws.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->help_ws.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -698,24 +750,25 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     HIPCHK(hipSetDevice(ctx->device));
     const hipStream_t st = ctx->stream;
     const uint64_t base = seq_off[0], bytes = seq_off[n] - base;
-    uint32_t max_len = 0;
-    std::vector<uint64_t> rel(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) rel[i] = seq_off[i] - base;
-    for (uint64_t i = 0; i < n; ++i) {
-      if (seq_off[i + 1] < seq_off[i]) throw std::invalid_argument("seq_off not monotone");
-      max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off[i + 1] - seq_off[i]));
-    }
     // reads beyond the kernels' length cap are not mapped (the reference takes reads below 32767 bases); they come
     // back without a hit and are counted (abm_ctx_reads_too_long), the rest of the batch is unaffected
-    for (uint64_t i = 0; i < n; ++i) ctx->too_long += (seq_off[i + 1] - seq_off[i]) > abm::kMaxReadLen;
+    HostTrace t0;
+    const OffsetScan scan = scan_offsets(seq_off, n, ctx->h_rel);
+    const uint32_t max_len = scan.max_len;
+    ctx->too_long += scan.too_long;
+    t0.mark("  offsets scanned");
     // one pass: upload, map, hits + compact CIGARs back
     auto run = [&](uint64_t m, const char *blob, uint64_t nbytes, const uint64_t *offs, uint32_t stride, bool take_turn) {
       ctx->blob.reserve(std::max<uint64_t>(nbytes, 1));
       ctx->off.reserve(m + 1);
-      ctx->res.reserve(m);
-      ctx->cig_n.reserve(m);
       ctx->status.reserve(1);
-      ctx->cig.reserve(m * stride);
+      // The kernel writes hits, op counts and CIGAR slots (28 bytes per read) straight into pinned host memory:
+      // device-to-host copies queued behind it are carried out by copy kernels, which get no compute unit while
+      // another context's device-filling mapping kernel runs -- a finished batch's results used to sit on the
+      // device for as long as the next batch's kernel ran (0.4-0.7 s in the CLI's timeline).
+      ctx->h_res.reserve(m);
+      ctx->h_cn.reserve(m);
+      ctx->h_slots.reserve(m * stride);
       HostTrace t2;
       if (nbytes) HIPCHK(hipMemcpyAsync(ctx->blob.p, blob, nbytes, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(ctx->off.p, offs, (m + 1) * 8, hipMemcpyHostToDevice, st));
@@ -730,15 +783,20 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
         if (take_turn) turn.lock();  // (the handful of reads of a long-CIGAR rerun just go ahead)
         __atomic_store_n(ctx->drained, 0u, __ATOMIC_RELAXED);
         ctx->signal_drained = true;
-        se_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, max_len, reinterpret_cast<abm_hit *>(ctx->res.p),
-                  ctx->cig.p, stride, ctx->cig_n.p, ctx->status.p, st);
+        ctx->host_results = true;
+        try {
+          se_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, max_len, ctx->h_res.p, ctx->h_slots.p, stride, ctx->h_cn.p,
+                    ctx->status.p, st);
+        }
+        catch (...) { ctx->host_results = false; ctx->signal_drained = false; throw; }
+        ctx->host_results = false;
         ctx->signal_drained = false;
-        HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
         while (__atomic_load_n(ctx->drained, __ATOMIC_RELAXED) == 0u && hipStreamQuery(st) == hipErrorNotReady)
           std::this_thread::sleep_for(std::chrono::microseconds(100));
         if (take_turn) turn.unlock();
         t2.mark("  map: drained");
         HIPCHK(hipStreamSynchronize(st));
+        status = ctx->h_tail.p[1];  // (written by the kernel's last wave, with the arena count)
         t2.mark("  map: tail");
       }
       if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW | ABM_STATUS_READ_TOO_LONG))
@@ -750,26 +808,15 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     const uint32_t stride = 4;
     HostTrace tr;
     for (;;) {
-      const uint32_t status = run(n, seq_blob + base, bytes, rel.data(), stride, true);
+      const uint32_t status = run(n, seq_blob + base, bytes, scan.use, stride, true);
       tr.mark("upload+map");
       if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) break;
-      if (ctx->cig_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
-      ctx->arena_want = ctx->cig_arena.cap * 4;
+      if (ctx->h_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
+      ctx->arena_want = ctx->h_arena.cap * 4;
     }
-    ctx->h_cn.reserve(n);
-    ctx->h_slots.reserve(n * stride);
-    uint32_t arena_n = 0;
-    HIPCHK(hipMemcpyAsync(out_res, ctx->res.p, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_cn.p, ctx->cig_n.p, n * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_slots.p, ctx->cig.p, n * stride * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&arena_n, ctx->cig_arena_count.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    ctx->h_arena.reserve(std::max<uint32_t>(arena_n, 1));
-    if (arena_n) {
-      HIPCHK(hipMemcpyAsync(ctx->h_arena.p, ctx->cig_arena.p, arena_n * 4ull, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-    }
+    const uint32_t arena_n = ctx->h_tail.p[0];
     tr.mark("hits+cigars back");
+    parallel_ranges(n, [&](uint64_t lo, uint64_t hi) { std::memcpy(out_res + lo, ctx->h_res.p + lo, (hi - lo) * sizeof(abm_hit)); });
     assemble_cigars(n, stride, ctx->h_cn.p, ctx->h_slots.p, ctx->h_arena.p, arena_n, out_cig_blob, cig_capacity, out_cig_off);
     tr.mark("cigars assembled");
   });
@@ -802,16 +849,12 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     if (n == 0) return;
     HIPCHK(hipSetDevice(ctx->device));
     const hipStream_t st = ctx->stream;
-    uint32_t max_len = 0;
-    std::vector<uint64_t> rel1(n + 1), rel2(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) { rel1[i] = seq_off1[i] - seq_off1[0]; rel2[i] = seq_off2[i] - seq_off2[0]; }
-    for (uint64_t i = 0; i < n; ++i) {
-      if (seq_off1[i + 1] < seq_off1[i] || seq_off2[i + 1] < seq_off2[i]) throw std::invalid_argument("seq_off not monotone");
-      max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off1[i + 1] - seq_off1[i]));
-      max_len = std::max<uint32_t>(max_len, static_cast<uint32_t>(seq_off2[i + 1] - seq_off2[i]));
+    const OffsetScan scan1 = scan_offsets(seq_off1, n, ctx->h_rel), scan2 = scan_offsets(seq_off2, n, ctx->h_rel2);
+    const uint32_t max_len = std::max(scan1.max_len, scan2.max_len);
+    if (scan1.too_long + scan2.too_long) {  // (pairs with an end beyond the cap: counted once; rare, so a plain pass)
+      for (uint64_t i = 0; i < n; ++i)
+        ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kMaxReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kMaxReadLen;
     }
-    for (uint64_t i = 0; i < n; ++i)
-      ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kMaxReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kMaxReadLen;
     abm_pair *d_pair = nullptr;
     abm_hit *d_se1 = nullptr, *d_se2 = nullptr;
     auto run = [&](uint64_t m, const char *b1, uint64_t nb1, const uint64_t *o1, const char *b2, uint64_t nb2,
@@ -850,8 +893,8 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     };
     const uint32_t stride = 4;
     for (;;) {
-      const uint32_t status = run(n, seq_blob1 + seq_off1[0], rel1[n], rel1.data(), seq_blob2 + seq_off2[0], rel2[n],
-                                  rel2.data(), stride);
+      const uint32_t status = run(n, seq_blob1 + seq_off1[0], seq_off1[n] - seq_off1[0], scan1.use, seq_blob2 + seq_off2[0],
+                                  seq_off2[n] - seq_off2[0], scan2.use, stride);
       if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) break;
       if (ctx->cig_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
       ctx->arena_want = ctx->cig_arena.cap * 4;
@@ -896,7 +939,7 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
       ctx->cig.reserve(n * stride); ctx->cig_n.reserve(n); ctx->status.reserve(1);
       ctx->cig_arena.reserve(std::max<size_t>(1u << 16, (paired ? 2 : 1) * n)); ctx->cig_arena_count.reserve(1);
       ctx->h_cn.reserve(n); ctx->h_slots.reserve(n * stride); ctx->h_arena.reserve(1u << 16);
-      if (!paired) ctx->res.reserve(n);
+      if (!paired) { ctx->res.reserve(n); ctx->h_res.reserve(n); }
       else {
         ctx->blob2.reserve(n * L); ctx->off2.reserve(n + 1);
         ctx->packed2.reserve(n * 4 * W); ctx->lens2.reserve(n);

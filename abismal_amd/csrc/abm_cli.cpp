@@ -103,6 +103,19 @@ struct RawBuf {
   const char *data() const { return p; }
   void swap(RawBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
 };
+// std::vector<T>'s resize/data/[] for plain-data T without the zero fill (a batch's result arrays are a few
+// hundred megabytes that the C ABI overwrites entirely; filling them first, single-threaded, cost a 8 M-read
+// batch 0.3 s before its upload could start)
+template <class T> struct PodVec {
+  RawBuf b;
+  void resize(size_t n) { b.resize(n * sizeof(T)); }
+  void assign(size_t n, T v) { resize(n); for (size_t i = 0; i < n; ++i) data()[i] = v; }
+  size_t size() const { return b.size() / sizeof(T); }
+  T *data() { return reinterpret_cast<T *>(b.p); }
+  const T *data() const { return reinterpret_cast<const T *>(b.p); }
+  T &operator[](size_t i) { return data()[i]; }
+  const T &operator[](size_t i) const { return data()[i]; }
+};
 struct RawPool {
   std::mutex mu;
   std::vector<RawBuf> free_list;
@@ -178,10 +191,10 @@ struct Batch {
   RawBuf blob[2];                    // carry + the slices' reads concatenated, as the C ABI takes them
   RawBuf off_bytes[2];               // ... and their n + 1 offsets (uint64_t)
   uint64_t *off_of(int e) { return reinterpret_cast<uint64_t *>(off_bytes[e].p); }
-  std::vector<abm_hit> se[2];
-  std::vector<abm_pair> pairs;
-  std::vector<uint32_t> cig[2];
-  std::vector<uint64_t> cig_off[2];
+  PodVec<abm_hit> se[2];
+  PodVec<abm_pair> pairs;
+  PodVec<uint32_t> cig[2];
+  PodVec<uint64_t> cig_off[2];
   int slices_left = 0;               // not yet written
 };
 
@@ -1055,6 +1068,9 @@ int cmd_map(int argc, char **argv) {
           // most -batch reads -- and into two even when one would do, if each half still has a few million reads:
           // a batch's output is formatted and written while the next one is being mapped.
           auto target = [&]() -> size_t {
+            // (the very first batch is small: the device starts on the first million reads while the rest of the
+            // input is still being cut and parsed, instead of idling until a full batch or the input's extent is there)
+            if (n_batches == 0) return std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, 1u << 20));
             if (!cut_done) return batch_reads;
             const size_t left = static_cast<size_t>(n_slices - next_to_map) * slice_reads;
             size_t k = (left + batch_reads - 1) / batch_reads;

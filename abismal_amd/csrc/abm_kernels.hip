@@ -293,6 +293,15 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   }
   if (lane == 0 && (overflow || too_long || hw.failed || hw.mismatch))
     atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u) | (hw.failed ? 8u : 0u) | (hw.mismatch ? 16u : 0u));
+  if (a.host_tail != nullptr && lane == 0) {  // the last wave to get here publishes the launch's two summary words
+    __threadfence();
+    const u32 before = atomicAdd(a.finished, 1u);
+    if (before + 1u == gridDim.x * NW) {
+      __threadfence();
+      a.host_tail[0] = __hip_atomic_load(a.cig_arena_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.host_tail[1] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 #ifndef ABM_SE_BLOCK_WAVES

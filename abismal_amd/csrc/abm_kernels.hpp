@@ -41,6 +41,9 @@ struct SeArgs {
   u32 *status;        // ABM_STATUS_* bits
   unsigned long long *next_read;  // work counter, zero at launch
   u32 *drained;       // optional host-visible flag, set once every read has been handed to a wave
+  u32 *finished;      // optional: waves that have run to their end (zero at launch) ...
+  u32 *host_tail;     // ... the last of which writes {arena count, status} here (pinned host memory): a host that takes
+                      // its results from pinned buffers then needs no device-to-host copy at all after the kernel
   u32 *read_cycles;   // optional [n], diagnostic kernel only: per-read shader cycles / 1024
   unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments

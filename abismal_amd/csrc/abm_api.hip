@@ -273,11 +273,11 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
 
   // In-block help (HelpWave): the cooperative-filter kernel can run se_block_waves() waves per workgroup whose idle
-  // waves take filter chunks of their block-mates' heaviest reads.  Bit-exact and tested, but OFF by default
-  // (ABM_SE_HELP=1 switches it on): measured on MI355X at hg38 scale (scripts/r02_inblock.sh,
-  // profiles/r02_exp_inblock_help.log) the helpers do compute two thirds of the shared chunks, yet a 1 M-read launch
-  // takes 247 ms with it against 225 ms without (what is left of a heavy read -- the ordered replay of its survivors
-  // into the candidate set -- is serial), and the extra registers cost a 10 M-read launch 10-18 % (1000-1068 ms vs 903).
+  // waves take filter chunks of their block-mates' heaviest reads.  Bit-exact and tested.  It shortens only launches
+  // that are as long as their costliest reads -- measured at hg38 scale with the round-2 kernels
+  // (scripts/r02_help_sizes.sh, profiles/r02_exp_inblock_help_by_size.log): 1 M reads 137 vs 148 ms (the helpers
+  // compute 71 % of the shared chunks), 2 M reads 223 vs 223 ms, 4 M reads 412 vs 358 ms (the four-wave kernel's
+  // extra spills cost every read).  Eleven milliseconds on small launches only: OFF by default, ABM_SE_HELP=1 switches it on.
   abm::u32 block_waves = 1u;
   if (const char *e = std::getenv("ABM_SE_HELP")) if (e[0] == '1' && a.G != 0) block_waves = abm::se_block_waves();
   if (ctx->phase_stamps) block_waves = 1;  // (the stamped diagnostic build measures the plain per-read phases)

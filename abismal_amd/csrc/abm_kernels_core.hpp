@@ -513,55 +513,6 @@ __device__ __forceinline__ void build_qmasks(const WaveLds &lds, u32 L) {
     }
 }
 
-#ifdef ABM_EXP_FILTER_NIBBLES  // experiment: the round-1 cooperative filter on the nibble array
-template <u32 kRounds = kCoopRounds>
-__device__ __forceinline__ void hamming_coop(const u64 *__restrict__ genome, const WaveLds &lds, const u64 *qpk,
-                                             u32 nwords, u32 pos_a, bool want_a, u32 pos_b, bool want_b,
-                                             int &d_a, int &d_b) {
-  const int lane = lane_id();
-  const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
-  const u64 wa = __ballot(want_a), wb = __ballot(want_b);
-  const bool has0 = 2 * sub < nwords, has1 = 2 * sub + 1 < nwords;
-  const u64 q0 = has0 ? qpk[2 * sub] : 0ull, q1 = has1 ? qpk[2 * sub + 1] : 0ull;
-  for (u32 pass = 0; pass * kRounds * per_round < 128; ++pass) {
-    u64 x0[kRounds], x1[kRounds];
-    u32 shifts = 0;  // (pos & 15) of the eight rounds' candidates, four bits each
-#pragma unroll
-    for (u32 r = 0; r < kRounds; ++r) {
-      const u32 slot = (pass * kRounds + r) * per_round + grp;  // < 128; a round lies entirely in one half
-      const bool second = (pass * kRounds + r) * per_round >= 64;
-      const u32 c = slot & 63u;
-      const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
-      shifts |= (cp & 15u) << (4 * r);
-      const bool act = (((second ? wb : wa) >> c) & 1ull) && 2 * sub <= nwords;
-      x0[r] = 0; x1[r] = 0;
-      if (act) {
-        const u64 *g = genome + (cp >> 4) + 2 * sub;
-        x0[r] = g[0];
-        x1[r] = g[1];
-      }
-    }
-#pragma unroll
-    for (u32 r = 0; r < kRounds; ++r) {
-      const u32 slot = (pass * kRounds + r) * per_round + grp;
-      const u32 sh = ((shifts >> (4 * r)) & 15u) << 2;
-      // the word after this lane's pair is the next lane's first word
-      const u64 x2 = (static_cast<u64>(static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r] >> 32)))) << 32) |
-                     static_cast<u32>(dpp_row_shl1(static_cast<int>(x0[r])));
-      int d = 0;
-      if (has0) d += 16 - __popcll(q0 & ((x0[r] >> sh) | ((x1[r] << (63 - sh)) << 1)));
-      if (has1) d += 16 - __popcll(q1 & ((x1[r] >> sh) | ((x2 << (63 - sh)) << 1)));
-      d = group_sum(d, G);
-      if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
-    }
-  }
-  wave_sync();
-  d_a = static_cast<i16>(lds.hres[lane]);
-  d_b = static_cast<i16>(lds.hres[64 + lane]);
-  wave_sync();
-}
-
-#endif
 // Hamming distances of 128 candidates (two per lane: pos_a of lane c = candidate c, pos_b = candidate 64 + c)
 // against the genome's bit planes (DevIndex::planes).  G lanes share a candidate: lane s of the group loads block
 // (pos >> 6) + s of the window -- one 16-byte load, every window inside one 128-byte line of one of the two
@@ -1051,9 +1002,6 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
           const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
           const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
           if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
-#ifdef ABM_EXP_FILTER_NIBBLES
-            hamming_coop(ix.genome, lds, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
-#else
             // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
             const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
             const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
@@ -1065,7 +1013,6 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
               if (na & 1u) ha = hamming(ix.genome, qpk, nwords, pa);
               if (nb & 1u) hb = hamming(ix.genome, qpk, nwords, pb);
             }
-#endif
             hma = ha; hmb = hb;
           }
           else

@@ -465,11 +465,11 @@ __device__ __forceinline__ void hamming2(const u64 *__restrict__ genome, const u
 // ---- candidate filter, cooperative form ----------------------------------------------
 // A lane that fetches its own candidate's window issues one load per word, and with ~20 waves
 // sharing a CU's L1 the line has often been evicted again before the next word asks for it: a
-// window then costs several L1 misses instead of 1.44 lines.  Here G lanes (4 for reads up to
-// 112 bp, 8 up to 240 bp) share a candidate: lane s of the group loads words 2s and 2s+1 of the
-// window in ONE 16-byte load, so a whole window is covered by a single instruction and its lanes
-// coalesce into one or two line requests.  Each lane counts the mismatches of its two words (the
-// word after them comes from the next lane), the group adds up, and the sums travel through LDS
+// window then costs several L1 misses.  Here G lanes (4 for reads up to 192 bp, 8 up to 448 bp)
+// share a candidate and fetch its window from the genome's bit planes (DevIndex::planes), one
+// 16-byte block of 64 bases per lane: a whole window is covered by a single instruction whose
+// lanes coalesce into one line request.  Each lane counts the mismatches of its 64 read bases (the
+// bits past its block come from the next lane), the group adds up, and the sums travel through LDS
 // to the lanes that own the candidates.  The 128 candidates of a step are slots 0..63 (lane's
 // first) and 64..127 (lane's second); 64/G of them are fetched per round, kCoopRounds rounds in
 // flight (few: registers are better spent on a fifth wave per SIMD).
@@ -859,6 +859,9 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         k3 = k3 * 3u + trit(static_cast<u32>(win >> (j << 2)) & 15u, g_to_a);
       // (keeping the specific pass's counters in LDS for the sensitive pass, which looks the first max(window, L/2)
       // offsets up again, took 4.4 % of the line requests away and made the kernel 1.6 % slower: measured, removed)
+      // (likewise keeping the specific pass's distances, one byte per candidate, so that the sensitive pass fetches no
+      // window for a bucket entry it has seen: 290 of 2,850 candidates per read found there, -7 % lines, and 2.3 KB more LDS
+      // per wave cost 15 % of the time -- profiles/r02_exp_distance_memo.log)
       lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
       lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
       if (SPECIFIC) {

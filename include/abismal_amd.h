@@ -93,7 +93,12 @@ void abm_ctx_destroy(abm_ctx *ctx);
  * offsets in out_cig_off (reads without a hit get an empty CIGAR).
  * cig_capacity is out_cig_blob's size in ops: a few ops per read are typical,
  * at most read length + 2; ABM_ERR_CAPACITY (-2) is returned if it does not
- * suffice, and the call can be repeated with a larger buffer. */
+ * suffice, and the call can be repeated with a larger buffer.
+ * The caller's buffers may be ordinary (pageable) memory: the kernel writes its
+ * results into pinned staging buffers of the context (grow-only, see
+ * abm_ctx_reserve) and the call copies them out on a few host threads, so
+ * nothing has to cross the bus after the kernel while another context's batch
+ * occupies the device. */
 #define ABM_ERR_CAPACITY (-2)
 int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                      const char *seq_blob, const uint64_t *seq_off, abm_hit *out_res,

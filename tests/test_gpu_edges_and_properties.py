@@ -317,7 +317,7 @@ def test_windows_that_reach_into_an_n_run(oracle, workdir):
     reads = []
     for ch in chroms:
         mid = len(ch) // 2
-        for L in (100, 97, 150):
+        for L in (100, 97, 150, 300):  # (300: a window shared by eight lanes)
             for k in range(25):
                 for seg in (ch[mid - L - k: mid - k], ch[mid + 3000 + k: mid + 3000 + k + L], ch[50 + k: 50 + k + L] if ch[0] == ord("N") else ch[k: k + L]):
                     s = seg.copy()
@@ -335,3 +335,24 @@ def test_windows_that_reach_into_an_n_run(oracle, workdir):
         oracle.index_free(oix)
     compare_se(res, cig, off, o_res, o_cig, o_n, reads, "reads at the edges of N runs")
     assert (res["pos"] != 0).mean() > 0.5
+    # the same for pairs: end 1 cut at the edge of the N run, end 2 from 150-400 bases further out, opposite strand
+    from tests.test_gpu_pe_parity import compare_pe
+    r1, r2 = [], []
+    rng = np.random.default_rng(4)
+    for ch in chroms:
+        mid = len(ch) // 2
+        for L in (100, 150):
+            for k in range(25):
+                gap = int(rng.integers(150, 400))
+                a, b = ch[mid - L - k: mid - k], ch[mid - k - gap - L: mid - k - gap]         # left of the run
+                c, d = ch[mid + 3000 + k: mid + 3000 + k + L], ch[mid + 3000 + k + gap: mid + 3000 + k + gap + L]  # right of it
+                for fwd, rev in ((b, a), (c, d)):
+                    r1.append(bytes(fwd).decode().replace("C", "T"))
+                    r2.append(bytes(synth.COMP[rev[::-1]]).decode().replace("G", "A"))
+    gpu = ctx.map_pe(r1, r2)
+    oix = oracle.index_load(idx)
+    try:
+        orc = oracle.map_pe(oix, r1, r2, mode=0)
+    finally:
+        oracle.index_free(oix)
+    compare_pe(gpu, orc, "pairs at the edges of N runs")

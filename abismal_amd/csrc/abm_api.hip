@@ -221,8 +221,8 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   // cooperative window loads from the genome's bit planes (hamming_planes): not for genomes with IUPAC letters (no
   // planes; their admission rule needs full_compare's word-by-word running sums) nor for reads beyond 448 bases; ABM_COOP_WINDOWS=0 switches them off (experiments)
   // (G lanes x 64 bases cover a window of eff_len + 63 bases)
-  a.G = a.ix.planes[0] == nullptr ? 0u : (eff_len <= 4 * abm::kPlaneBlock - 64 ? 4u : (eff_len <= 8 * abm::kPlaneBlock - 64 ? 8u : 0u));
-  if (const char *e = std::getenv("ABM_COOP_WINDOWS")) if (e[0] == '0') a.G = 0;
+  a.G = a.ix.planes[0] == nullptr ? 0u : (eff_len <= 2 * abm::kPlaneBlock ? 2u : (eff_len <= 4 * abm::kPlaneBlock - 64 ? 4u : (eff_len <= 8 * abm::kPlaneBlock - 64 ? 8u : 0u)));
+  if (const char *e = std::getenv("ABM_COOP_WINDOWS")) { if (e[0] == '0') a.G = 0; else if (e[0] == '4' && a.G == 2) a.G = 4; }
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.res = reinterpret_cast<abm::Hit *>(d_res);

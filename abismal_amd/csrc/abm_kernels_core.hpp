@@ -574,6 +574,44 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
   wave_sync();
 }
 
+// Reads of up to 128 bases: TWO lanes per candidate, each fetching two consecutive blocks (32 bytes: lane s of the
+// pair takes blocks s and s + 1 of the window, so the middle block is asked for twice and costs nothing more) and
+// counting 64 read bases against them -- no exchange between the lanes, and 32 candidates per round instead of 16:
+// the kernel is bound by vector-instruction issue once its windows are single lines (76 % of the SIMDs' cycles),
+// and this halves the filter's instructions per candidate.  One round (32 windows, 8 registers) in flight per pass.
+__device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
+                                                     u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
+  const int lane = lane_id();
+  const u32 sub = lane & 1u, grp = lane >> 1;
+  const u64 wa = __ballot(want_a), wb = __ballot(want_b);
+  const bool counts = sub * kPlaneBlock < L;
+  u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  if (counts) { const u64 *q = qm + sub * 4; m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; }
+#pragma unroll 1
+  for (u32 pass = 0; pass < 4; ++pass) {
+    const u32 slot = pass * 32 + grp;  // < 128; passes 0-1 are the lanes' first candidates, 2-3 their second
+    const bool second = pass >= 2;
+    const u32 c = slot & 63u;
+    const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
+    const u32 sh = cp & 63u;
+    const u32 b0 = cp / kPlaneBlock, b1 = b0 + 2;  // a window of up to 128 bases has at most three blocks
+    const bool act = ((second ? wb : wa) >> c) & 1ull;
+    // (unconditional loads, as in hamming_planes: a lane with nothing to fetch reads the array's first line)
+    const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+                       : ix.planes[0];
+    const u64 xl = g[0], xh = g[1], nl = g[2], nh = g[3];
+    const u64 gl = (xl >> sh) | ((nl << (63 - sh)) << 1), gh = (xh >> sh) | ((nh << (63 - sh)) << 1);
+    const u64 match = (~gh & ((~gl & m0) | (gl & m1))) | (gh & ((~gl & m2) | (gl & m3)));
+    int d = counts ? 64 - __popcll(match) : 0;
+    d += __builtin_amdgcn_update_dpp(0, d, 0xB1 /*quad_perm 1,0,3,2*/, 0xf, 0xf, false);
+    if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
+  }
+  wave_sync();
+  d_a = static_cast<i16>(lds.hres[lane]);
+  d_b = static_cast<i16>(lds.hres[64 + lane]);
+  wave_sync();
+}
+
 // The same through LDS: the 16-byte window blocks of kStageRounds rounds (16 candidates each for groups of four)
 // are fetched by LDS-DMA loads (global_load_lds_dwordx4: no destination registers, the wave's 64 x 16 bytes land
 // lane-linear in a 1 KiB piece of lds.stage), so twice as many windows are in flight per lane as the register
@@ -783,7 +821,8 @@ __device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &
   pb = eb - (g0 + static_cast<u32>(ob));
   const u32 na = va ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
   const u32 nb = vb ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-  hamming_planes<ABM_HELP_ROUNDS>(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
+  if (lds.G == 2) hamming_planes_pairs(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
+  else hamming_planes<ABM_HELP_ROUNDS>(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
   if (__any((na | nb) & 1u)) {
     if (na & 1u) ha = hamming(ix.genome, qpk, (L + 15) >> 4, pa);
     if (nb & 1u) hb = hamming(ix.genome, qpk, (L + 15) >> 4, pb);
@@ -1009,7 +1048,9 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
             // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
             const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
             const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-            if constexpr (MODE == kMain && ABM_STAGE_WINDOWS)
+            if (lds.G == 2)
+              hamming_planes_pairs(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+            else if constexpr (MODE == kMain && ABM_STAGE_WINDOWS)
               hamming_planes_staged(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
             else
               hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
@@ -1032,7 +1073,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
           wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
           // 8-byte words fetched per window: the read's words on the nibble array; on the bit planes a group of four
           // lanes fetches four 16-byte blocks, a group of eight the blocks its window has (at most L / 64 + 2)
-          const u32 fetched = COOP ? (lds.G == 4 ? 8u : 2u * ((L + kPlaneBlock - 1) / kPlaneBlock + 1)) : nwords;
+          const u32 fetched = COOP ? (lds.G == 2 ? 6u : (lds.G == 4 ? 8u : 2u * ((L + kPlaneBlock - 1) / kPlaneBlock + 1))) : nwords;
           wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * fetched;
           wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
         }

@@ -456,13 +456,14 @@ def run_e2e(args, idx, fasta, L):
         t_sim = time.time() - t0
         fq = os.path.join(wd, "reads_1.fq")
         sam, tj = os.path.join(wd, "out.sam"), os.path.join(wd, "timing.json")
-        best = None
-        for rep in range(2):  # the second run has the page cache and the GPU clocks of a run in progress
+        best, all_seconds = None, []
+        for rep in range(3):  # best of three: the later runs have the page cache and the GPU clocks of a run in progress
             r = subprocess.run([cli, "map", "-i", idx, "-o", sam, "-s", os.path.join(wd, "out.stats"), "-timing", tj, fq],
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if r.returncode != 0:
                 return {"error": r.stderr[-2000:]}
             t = json.load(open(tj))
+            all_seconds.append(round(t["seconds"], 3))
             if best is None or t["seconds"] < best["seconds"]:
                 best = t
         # the same pipeline on a longer input (the FASTQ four times over): a 10 M-read run is two batches long, so
@@ -486,7 +487,8 @@ def run_e2e(args, idx, fasta, L):
                     os.remove(f)
         out = {"value": round(best["reads"] / best["seconds"], 1), "unit": "reads/s", "sustained": sustained,
                "window": "first batch submitted -> last SAM byte written (abismal-amd map, plain FASTQ in, SAM text out, tmpfs)",
-               "reads": best["reads"], "seconds": round(best["seconds"], 3), "index_load_s": round(best["index_load_s"], 2),
+               "reads": best["reads"], "seconds": round(best["seconds"], 3), "seconds_of_each_run": all_seconds,
+               "index_load_s": round(best["index_load_s"], 2),
                "fastq_bytes": os.path.getsize(fq), "sam_bytes": os.path.getsize(sam), "sim_s": round(t_sim, 1),
                "cli": {k: best[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "batch_reads")},
                "busy_s": {k: round(v, 3) for k, v in best["busy_s"].items()}}

@@ -761,6 +761,8 @@ int cmd_map(int argc, char **argv) {
   // fixtures cross many slice, chunk and mark boundaries)
   auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
   const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 16));
+  // size of the run's very first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
+  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", 1u << 20));
   const bool plain_input = [&] {
     for (const std::string &path : opt.reads) {
       const int fd = ::open(path.c_str(), O_RDONLY);
@@ -1070,7 +1072,7 @@ int cmd_map(int argc, char **argv) {
           auto target = [&]() -> size_t {
             // (the very first batch is small: the device starts on the first million reads while the rest of the
             // input is still being cut and parsed, instead of idling until a full batch or the input's extent is there)
-            if (n_batches == 0) return std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, 1u << 20));
+            if (n_batches == 0 && first_batch_reads) return std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, first_batch_reads));
             if (!cut_done) return batch_reads;
             const size_t left = static_cast<size_t>(n_slices - next_to_map) * slice_reads;
             size_t k = (left + batch_reads - 1) / batch_reads;

@@ -76,7 +76,8 @@ template <class T> struct HostBuf {
     if (n <= cap) return;
     if (p) HIPCHK(hipHostFree(p));
     p = nullptr; cap = 0;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault));
+    // (portable + mapped: kernels of whichever device the context lives on write results straight into these buffers)
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocPortable | hipHostMallocMapped));
     cap = n;
   }
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }

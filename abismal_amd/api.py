@@ -250,10 +250,9 @@ class Context:
         keys = ["seed_offsets", "search_probes", "candidates", "read_words", "set_updates", "alignments"]
         d = dict(zip(keys, [int(x) for x in out[:6]]))
         d["window_cache_hits"] = int(out[11])
-        if out[12]:  # tail help (single-end): jobs published, chunks, chunks done by their owner / by helpers
-            d["help"] = {"jobs": int(out[12]), "chunks": int(out[13]), "by_owner": int(out[14]), "by_helpers": int(out[15])}
-        if out[10] and not out[12]:
-            d["fifo_updates"], d["filter_steps"] = int(out[14]), int(out[15])
+        d["single_job_reads"] = int(out[12])  # single-end reads whose set held one alignable entry (scored by the traceback run)
+        if out[10]:  # diagnostic (stamped) kernel only
+            d["light_filter_steps"], d["fifo_updates"], d["filter_steps"] = int(out[13]), int(out[14]), int(out[15])
         if out[10]:
             d["phase_cycles"] = dict(zip(["probe_narrow", "gather_hamming", "replay", "align", "total"],
                                          [int(x) for x in out[6:11]]))

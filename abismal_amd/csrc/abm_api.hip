@@ -55,6 +55,13 @@ struct HostTrace {
   }
 };
 
+// Experiment switches (ABM_COOP_WINDOWS, ABM_GRID_WAVES, ABM_PLANES_COPIES, ABM_EXT_LETTERS) are honoured only when
+// ABM_EXPERIMENTS=1 is set as well: a stray variable in a production environment changes nothing.
+const char *experiment_env(const char *name) {
+  static const bool on = [] { const char *e = std::getenv("ABM_EXPERIMENTS"); return e && e[0] == '1'; }();
+  return on ? std::getenv(name) : nullptr;
+}
+
 template <class T> struct DevBuf {  // grow-only device allocation
   T *p = nullptr;
   size_t cap = 0;
@@ -90,6 +97,8 @@ struct DeviceReplica {
   void *arena = nullptr;  // one allocation holding the seven index arrays
   abm::DevIndex dix{};
   int refs = 0;
+  void *ext_mem[3] = {nullptr, nullptr, nullptr};  // seed-extension tables (abm_ext.hip), built for dix.ext_maxc candidates
+  double ext_build_s = 0;
   // The single-end host-buffer entry points of the contexts on one device take turns for the mapping
   // kernel (their transfers overlap freely): the kernels are bound by random line fetches, and two of them
   // resident together only evict each other's lines (see kSeWavesPerCu).
@@ -98,6 +107,7 @@ struct DeviceReplica {
 
 struct abm_index {
   abm::HostIndex h;
+  int want_e2 = -1, want_e3 = -1;  // letters of the seed-extension tables; -1 = chosen from the index's size
   mutable std::mutex mu;
   mutable std::map<int, DeviceReplica> replicas;  // by device ordinal
 };
@@ -105,7 +115,8 @@ struct abm_index {
 struct abm_ctx {
   int device = 0;
   const abm_index *ix = nullptr;
-  abm::DevIndex dix{};
+  abm::DevIndex dix{};            // as of creation (arrays, planes); the seed-extension tables are read from the replica per call
+  DeviceReplica *rep = nullptr;
   bool holds_replica = false;
   hipStream_t stream = nullptr;  // the host-buffer entry points run on the context's own stream
   std::mutex *kernel_turn = nullptr;
@@ -135,7 +146,6 @@ struct abm_ctx {
   DevBuf<abm::u32> finished;
   bool host_results = false;        // set by abm_map_se_batch around its launches: arena and summary words in pinned memory
   HostBuf<abm_hit> h_res;           // hits on their way out (a pinned target keeps the copy on the DMA engines)
-  DevBuf<char> help_ws;  // tail-help workspace of the single-end kernel (see HelpArgs)
   unsigned launch_seq = 0;
   // every device entry point reuses this context's workspaces: a call first makes its stream wait for
   // the previous call's work (whatever stream that ran on), so consecutive calls never overlap
@@ -156,6 +166,68 @@ struct abm_ctx {
 };
 
 namespace {
+
+// Seed-extension tables of one device replica for `maxc` candidates (see abm_ext.hip).  Letters per table: asked
+// for through abm_index_set_seed_extension, else the fewest that give every index entry a key of its own on
+// average -- none for small genomes, 7 and 4 at hg38 scale (34 + 2 x 28 GB) -- and never more than fit half of the
+// device's free memory.  Genomes with IUPAC letters get none (their base-3 digits are not the sort's symbols).
+void free_ext(DeviceReplica &rep) {
+  for (auto &m : rep.ext_mem) { if (m) (void)hipFree(m); m = nullptr; }
+  rep.dix.ext2 = rep.dix.ext3t = rep.dix.ext3a = nullptr;
+  rep.dix.e2 = rep.dix.e3 = rep.dix.ext_maxc = 0;
+}
+void build_ext(DeviceReplica &rep, const abm_index &ix, abm::u32 maxc) {
+  free_ext(rep);
+  const abm::HostIndex &h = ix.h;
+  if (h.multibit_genome || maxc == 0) return;
+  const uint64_t n2 = h.index.size(), n3 = std::max(h.index_t.size(), h.index_a.size());
+  int e2 = ix.want_e2, e3 = ix.want_e3;
+  if (const char *e = experiment_env("ABM_EXT_LETTERS")) { int a = 0, b = 0; if (std::sscanf(e, "%d,%d", &a, &b) == 2) { e2 = a; e3 = b; } }
+  if (e2 < 0) { e2 = 0; while (e2 < 7 && abm::ext_keys(0, e2) < n2) ++e2; }
+  if (e3 < 0) { e3 = 0; while (e3 < 4 && abm::ext_keys(1, e3) < n3) ++e3; }
+  e2 = std::min(e2, 7); e3 = std::min(e3, 4);
+  if (e2 <= 0 || e3 <= 0) return;
+  auto need = [&](int a, int b) {
+    return 8 * (abm::ext_keys(0, a) + 2 * abm::ext_keys(1, b)) + std::max(abm::ext_scratch_bytes(0, a), abm::ext_scratch_bytes(1, b));
+  };
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  while ((e2 > 1 || e3 > 1) && need(e2, e3) > free_b / 2) { if (e2 > 1) --e2; if (e3 > 1) --e3; }
+  if (need(e2, e3) > free_b / 2) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  void *scratch = nullptr;
+  abm::u32 *d_fail = nullptr;
+  try {
+    HIPCHK(hipMalloc(&scratch, std::max(abm::ext_scratch_bytes(0, e2), abm::ext_scratch_bytes(1, e3))));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_fail), 64));
+    HIPCHK(hipMemset(d_fail, 0, 64));
+    const uint64_t n_idx[3] = {h.index.size(), h.index_t.size(), h.index_a.size()};
+    for (int mode = 0; mode < 3; ++mode) {
+      const abm::u32 extra = mode == 0 ? e2 : e3;
+      HIPCHK(hipMalloc(&rep.ext_mem[mode], abm::ext_keys(mode, extra) * 8));
+      HIPCHK(abm::build_ext_table(rep.dix, mode, extra, maxc, n_idx[mode], static_cast<uint2 *>(rep.ext_mem[mode]), scratch, d_fail, nullptr));
+      HIPCHK(hipDeviceSynchronize());
+    }
+    abm::u32 fail = 0;
+    HIPCHK(hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(scratch); scratch = nullptr;
+    (void)hipFree(d_fail); d_fail = nullptr;
+    if (fail) { free_ext(rep); return; }  // (an index whose hashed letters do not name its buckets: bisection only)
+  }
+  catch (...) { if (scratch) (void)hipFree(scratch); if (d_fail) (void)hipFree(d_fail); free_ext(rep); throw; }
+  rep.dix.ext2 = static_cast<const uint2 *>(rep.ext_mem[0]);
+  rep.dix.ext3t = static_cast<const uint2 *>(rep.ext_mem[1]);
+  rep.dix.ext3a = static_cast<const uint2 *>(rep.ext_mem[2]);
+  rep.dix.e2 = static_cast<abm::u32>(e2);
+  rep.dix.e3 = static_cast<abm::u32>(e3);
+  rep.dix.ext_maxc = maxc;
+  rep.ext_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// the index as a launch sees it: the context's arrays plus the replica's seed-extension tables.  Tables built for
+// another max_candidates are rebuilt if this context is the device's only one (its previous launches are waited
+// for); beside other contexts the call goes without tables (the kernels then bisect from the counters).
+abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc);
 
 abm::u32 words_for(abm::u32 max_len) { return std::max(1u, (max_len + 15) / 16); }
 abm::u32 bitwords_for(abm::u32 max_len) { return (max_len + 63) / 64 + 1; }
@@ -197,8 +269,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(abm::launch_pack_reads(d_blob, reinterpret_cast<const abm::u64 *>(d_off), n, W, ctx->packed.p,
                                 ctx->lens.p, st));
   abm::SeArgs a{};
-  a.ix = ctx->dix;
-  if (params->max_candidates) a.ix.max_candidates = params->max_candidates;
+  a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates);
   if (n < (1ull << 32)) {
     ctx->order.reserve(n);
     ctx->cls.reserve(n);
@@ -223,7 +294,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   // planes; their admission rule needs full_compare's word-by-word running sums) nor for reads beyond 448 bases; ABM_COOP_WINDOWS=0 switches them off (experiments)
   // (G lanes x 64 bases cover a window of eff_len + 63 bases)
   a.G = a.ix.planes[0] == nullptr ? 0u : (eff_len <= 2 * abm::kPlaneBlock ? 2u : (eff_len <= 4 * abm::kPlaneBlock - 64 ? 4u : (eff_len <= 8 * abm::kPlaneBlock - 64 ? 8u : 0u)));
-  if (const char *e = std::getenv("ABM_COOP_WINDOWS")) { if (e[0] == '0') a.G = 0; else if (e[0] == '4' && a.G == 2) a.G = 4; }
+  if (const char *e = experiment_env("ABM_COOP_WINDOWS")) { if (e[0] == '0') a.G = 0; else if (e[0] == '4' && a.G == 2) a.G = 4; }
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.res = reinterpret_cast<abm::Hit *>(d_res);
@@ -271,37 +342,12 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   else { waves = abm::se_resident_waves(W, WB, a.ctmp_cap, eff_len, size_frac); ctx->se_waves[shape] = waves; }
   if (waves <= 0) throw HipFail("map_se_kernel does not fit on this device (LDS/occupancy)");
   abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
-  if (const char *e = std::getenv("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));  // experiments only
+  if (const char *e = experiment_env("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));
 
-  // In-block help (HelpWave): the cooperative-filter kernel can run se_block_waves() waves per workgroup whose idle
-  // waves take filter chunks of their block-mates' heaviest reads.  Bit-exact and tested.  It shortens only launches
-  // that are as long as their costliest reads -- measured at hg38 scale with the round-2 kernels
-  // (scripts/r02_help_sizes.sh, profiles/r02_exp_inblock_help_by_size.log): 1 M reads 137 vs 148 ms (the helpers
-  // compute 71 % of the shared chunks), 2 M reads 223 vs 223 ms, 4 M reads 412 vs 358 ms (the four-wave kernel's
-  // extra spills cost every read).  Eleven milliseconds on small launches only: OFF by default, ABM_SE_HELP=1 switches it on.
-  abm::u32 block_waves = 1u;
-  if (const char *e = std::getenv("ABM_SE_HELP")) if (e[0] == '1' && a.G != 0) block_waves = abm::se_block_waves();
-  if (ctx->phase_stamps) block_waves = 1;  // (the stamped diagnostic build measures the plain per-read phases)
-  if (block_waves > 1) {
-    const uint64_t shape2 = shape ^ (0xB10Cull << 32);
-    auto it2 = ctx->se_waves.find(shape2);
-    if (it2 != ctx->se_waves.end()) waves = it2->second;
-    else { waves = abm::se_resident_waves(W, WB, a.ctmp_cap, eff_len, size_frac, block_waves); ctx->se_waves[shape2] = waves; }
-    if (waves <= 0) block_waves = 1, waves = ctx->se_waves[shape];
-    else grid = static_cast<abm::u32>(waves);
-  }
-  if (block_waves > 1) {
-    const abm::u32 cap = 16384;
-    size_t zeroed = 0, total = 0;
-    abm::se_help_bytes(grid, cap, zeroed, total);
-    ctx->help_ws.reserve(total);
-    abm::se_help_carve(ctx->help_ws.p, grid, cap, a.help);
-    HIPCHK(hipMemsetAsync(ctx->help_ws.p, 0, zeroed, st));
-  }
   const hipEvent_t e1 = begin_timed(ctx, st);
   a.next_read = fresh_counter(st);
   a.drained = ctx->signal_drained ? ctx->drained : nullptr;
-  HIPCHK(abm::launch_map_se(a, eff_len, grid, block_waves, ctx->phase_stamps, st));
+  HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipEventRecord(ctx->last_done, st));
 }
@@ -403,8 +449,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(abm::launch_pack_reads(d_blob1, reinterpret_cast<const abm::u64 *>(d_off1), n, W, ctx->packed.p, ctx->lens.p, st));
   HIPCHK(abm::launch_pack_reads(d_blob2, reinterpret_cast<const abm::u64 *>(d_off2), n, W, ctx->packed2.p, ctx->lens2.p, st));
   abm::PeArgs a{};
-  a.ix = ctx->dix;
-  if (params->max_candidates) a.ix.max_candidates = params->max_candidates;
+  a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates);
   HIPCHK(abm::launch_order_reads(a.ix, ctx->packed.p, ctx->lens.p, n, W, mode == 1 ? 1 : 0, ctx->cls.p, ctx->class33.p,
                                  ctx->order.p, st));
   a.packed1 = ctx->packed.p; a.packed2 = ctx->packed2.p;
@@ -417,7 +462,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.tb_extra = abm::tb_extra_bytes(a.GW, eff_len, size_frac);
   // cooperative window loads from the bit planes, as in the single-end path (see there)
   a.G = a.ix.planes[0] == nullptr ? 0u : (eff_len <= 4 * abm::kPlaneBlock - 64 ? 4u : (eff_len <= 8 * abm::kPlaneBlock - 64 ? 8u : 0u));
-  if (const char *e = std::getenv("ABM_COOP_WINDOWS")) if (e[0] == '0') a.G = 0;
+  if (const char *e = experiment_env("ABM_COOP_WINDOWS")) if (e[0] == '0') a.G = 0;
   a.mode = mode;
   a.valid_frac = params->valid_frac;
   a.min_frag = params->min_frag; a.max_frag = params->max_frag;
@@ -484,6 +529,25 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
 
 }  // namespace
 
+namespace {
+abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
+  abm::DevIndex d = ctx->dix;
+  d.max_candidates = maxc;
+  std::lock_guard<std::mutex> lk(ctx->ix->mu);
+  DeviceReplica &rep = *ctx->rep;
+  if (rep.dix.ext_maxc != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
+    HIPCHK(hipDeviceSynchronize());
+    build_ext(rep, *ctx->ix, maxc);
+  }
+  if (rep.dix.ext2 != nullptr && rep.dix.ext_maxc == maxc) {
+    d.ext2 = rep.dix.ext2; d.ext3t = rep.dix.ext3t; d.ext3a = rep.dix.ext3a;
+    d.e2 = rep.dix.e2; d.e3 = rep.dix.e3; d.ext_maxc = maxc;
+  }
+  else { d.ext2 = d.ext3t = d.ext3a = nullptr; d.e2 = d.e3 = d.ext_maxc = 0; }
+  return d;
+}
+}  // namespace
+
 extern "C" {
 
 const char *abm_last_error(void) { return g_error.c_str(); }
@@ -528,6 +592,29 @@ int abm_index_build_targets(const char *fasta_path, const char *targets_path, co
 }
 
 uint32_t abm_index_window(const abm_index *ix) { return ix->h.window; }
+
+int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3) {
+  return guarded([&] {
+    if (!ix) throw std::invalid_argument("index is null");
+    if (letters2 > 7 || letters3 > 4) throw std::invalid_argument("at most 7 and 4 letters");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->replicas.empty()) throw std::invalid_argument("set the seed extension before the first context is created");
+    ix->want_e2 = letters2;
+    ix->want_e3 = letters3;
+  });
+}
+
+int abm_ctx_seed_extension(const abm_ctx *ctx, uint32_t *letters2, uint32_t *letters3, uint64_t *bytes) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->ix->mu);
+    const abm::DevIndex &d = ctx->rep->dix;
+    const bool on = d.ext2 != nullptr;
+    if (letters2) *letters2 = on ? d.e2 : 0;
+    if (letters3) *letters3 = on ? d.e3 : 0;
+    if (bytes) *bytes = on ? 8 * (abm::ext_keys(0, d.e2) + 2 * abm::ext_keys(1, d.e3)) : 0;
+  });
+}
 
 int abm_index_build_opts(const char *fasta_path, const char *targets_path, uint32_t window, const char *out_path,
                          uint32_t n_threads) {
@@ -603,14 +690,19 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
               abm::u32 bad = 0;
               HIPCHK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
               if (!bad) { rep.dix.planes[0] = p0; rep.dix.planes[1] = p1; rep.dix.nmap = nmap; }
-              if (const char *e = std::getenv("ABM_PLANES_COPIES")) if (e[0] == '1') rep.dix.planes[1] = p0;  // experiments only
+              if (const char *e = experiment_env("ABM_PLANES_COPIES")) if (e[0] == '1') rep.dix.planes[1] = p0;
             }
           }
           catch (...) { (void)hipFree(arena); throw; }
           rep.arena = arena;
+          rep.dix.ext2 = rep.dix.ext3t = rep.dix.ext3a = nullptr;
+          rep.dix.e2 = rep.dix.e3 = rep.dix.ext_maxc = 0;
+          try { build_ext(rep, *ix, h.max_candidates); }
+          catch (...) { (void)hipFree(arena); rep.arena = nullptr; throw; }
         }
         ++rep.refs;
         c->holds_replica = true;
+        c->rep = &rep;
         c->dix = rep.dix;
         c->kernel_turn = &rep.kernel_turn;
       }
@@ -636,11 +728,12 @@ void abm_ctx_destroy(abm_ctx *c) {
     std::lock_guard<std::mutex> lk(c->ix->mu);
     auto it = c->ix->replicas.find(c->device);
     if (it != c->ix->replicas.end() && --it->second.refs == 0) {
+      free_ext(it->second);
       (void)hipFree(it->second.arena);
       c->ix->replicas.erase(it);
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->help_ws.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;

@@ -47,6 +47,13 @@ struct DevIndex {
   // starting in the chunk could reach a blank; the filter redoes such candidates (rare: they lie within a read
   // length of an N run) on the nibble array.
   const u32 *nmap;
+  // Seed-extension tables (abm_ext.hip), all three or none: for every key of the hashed letters plus the next e2
+  // (2-letter table) / e3 (3-letter tables) one entry {x = lo, y = size | len << 27 | state << 30} saying where the
+  // narrowing loop of find_candidates / find_candidates_three stands after those letters, for ext_maxc candidates:
+  // state 0 = finished with [lo, lo + size) after key weight + len letters, 1 = still open there (len = e), 2 = not
+  // tabulated (bisect from the bucket's counters).
+  const uint2 *ext2, *ext3t, *ext3a;
+  u32 e2, e3, ext_maxc;
 };
 constexpr u32 kPlaneBlock = 64;       // bases per bit-plane block
 constexpr u32 kPlaneLineBlocks = 8;   // blocks per 128-byte line
@@ -86,25 +93,38 @@ __device__ __forceinline__ u64 rdlane(u64 v, int l) {
 __device__ __forceinline__ void wrlane(int &v, int l, int x) { v = (lane_id() == l) ? x : v; }
 __device__ __forceinline__ void wrlane(u32 &v, int l, u32 x) { v = (lane_id() == l) ? x : v; }
 
+// Wave-wide scans in six DPP steps (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 and 2 to
+// rows 1 and 3, then lane 31 to rows 2 and 3): one v_add / v_max with a DPP operand each, against a ds_bpermute, a
+// compare and a select per step of the shuffle form.  Lanes a step does not reach keep `old`, the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_from(u32 identity, u32 v) {
+  return static_cast<u32>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ u32 wave_incl_sum(u32 x) {
+  x += dpp_from<0x111, 0xf>(0u, x);
+  x += dpp_from<0x112, 0xf>(0u, x);
+  x += dpp_from<0x114, 0xf>(0u, x);
+  x += dpp_from<0x118, 0xf>(0u, x);
+  x += dpp_from<0x142, 0xa>(0u, x);  // row_bcast:15
+  x += dpp_from<0x143, 0xc>(0u, x);  // row_bcast:31
+  return x;
+}
 __device__ __forceinline__ u32 wave_excl_sum(u32 x, u32 &total) {
-  u32 inc = x;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const u32 y = __shfl_up(inc, d);
-    if (lane_id() >= d) inc += y;
-  }
+  const u32 inc = wave_incl_sum(x);
   total = rdlane(inc, 63);
   return inc - x;
 }
-
-__device__ __forceinline__ int wave_incl_max(int x) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(x, d);
-    if (lane_id() >= d) x = max(x, y);
-  }
+// inclusive running maximum of unsigned values (identity 0)
+__device__ __forceinline__ u32 wave_incl_max(u32 x) {
+  x = max(x, dpp_from<0x111, 0xf>(0u, x));
+  x = max(x, dpp_from<0x112, 0xf>(0u, x));
+  x = max(x, dpp_from<0x114, 0xf>(0u, x));
+  x = max(x, dpp_from<0x118, 0xf>(0u, x));
+  x = max(x, dpp_from<0x142, 0xa>(0u, x));
+  x = max(x, dpp_from<0x143, 0xc>(0u, x));
   return x;
 }
+__device__ __forceinline__ int wave_incl_max(int x) { return static_cast<int>(wave_incl_max(static_cast<u32>(x))); }
 
 __device__ __forceinline__ u64 wave_max_u64(u64 x) {
 #pragma unroll

@@ -104,46 +104,24 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict_
   }
 }
 
-// bytes of LDS the staging area of the filter needs beyond the regions it lies over (see map_se_body)
-__host__ __device__ inline u32 se_stage_extra(u32 ctmp_cap, u32 GW) {
-  const u32 cap2 = (ctmp_cap + 1) & ~1u;
-  const u32 over = cap2 * 4 + 2 * kSeCap * 4 + kMaxJobs * GW * 8;
-  return (ABM_STAGE_WINDOWS && over < kStageBytes) ? ((kStageBytes - over + 15) & ~15u) : 0u;
-}
-
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
-template <bool TIMED, bool COOP, u32 NW>
+template <bool TIMED, bool COOP>
 __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  // NW waves per workgroup, each with its own LDS region behind the workgroup's control block (NW > 1);
-  // after the start-up barrier the waves never meet at a barrier again
-  const u32 wave = NW > 1 ? static_cast<u32>(uni(static_cast<int>(threadIdx.x >> 6))) : 0u;
-  BlockCtl<NW> *bc = reinterpret_cast<BlockCtl<NW> *>(smem);
-  constexpr u32 kCtlBytes = NW > 1 ? static_cast<u32>((sizeof(BlockCtl<NW>) + 15) & ~15ul) : 0u;
-  unsigned char *wave_lds0 = smem + kCtlBytes;
-  unsigned char *mine = wave_lds0 + static_cast<size_t>(wave) * a.lds_per_wave;
-  if constexpr (NW > 1) {
-    for (u32 k = threadIdx.x; k < sizeof(BlockCtl<NW>) / 4; k += 64 * NW) reinterpret_cast<u32 *>(smem)[k] = 0;
-    __syncthreads();
-  }
   WaveLds lds;
   lds.W = a.W;
   lds.WB = a.WB;
-  lds.qpk = reinterpret_cast<u64 *>(mine);
+  lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
   lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
   lds.qmask = lds.qbits + 4 * a.WB;
-  // [stage extra | CIGAR scratch | alignment job lists | alignment windows] are contiguous and idle during the seed
-  // passes: the filter's LDS-DMA staging area (ABM_STAGE_WINDOWS) lies over them
   {
     unsigned char *p = reinterpret_cast<unsigned char *>(lds.qmask + 4 * lds.MB * 4);
     const u32 cap2 = (a.ctmp_cap + 1) & ~1u;
-    lds.stage = ABM_STAGE_WINDOWS ? p : nullptr;
-    p += se_stage_extra(a.ctmp_cap, a.GW);
     lds.ctmp = reinterpret_cast<u32 *>(p); p += cap2 * 4;
     lds.jpos = reinterpret_cast<u32 *>(p); p += kSeCap * 4;
     lds.jdf = reinterpret_cast<u32 *>(p); p += kSeCap * 4;
@@ -151,11 +129,15 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     lds.pcache = reinterpret_cast<u64 *>(p); p += (8u << kPosCacheBits) + a.tb_extra;
     // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
     lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
-    lds.lbest = reinterpret_cast<int *>(p);
+    lds.lbest = reinterpret_cast<int *>(p); p += 64 * 4;
+    lds.smark = reinterpret_cast<u32 *>(p); p += 128 * 4;
+    lds.sdelta = reinterpret_cast<u32 *>(p); p += 128 * 4;
+    lds.mark = reinterpret_cast<u16 *>(p);
   }
-  lds.mark = reinterpret_cast<u16 *>(lds.lbest + 64);
   lds.hres = reinterpret_cast<u16 *>(lds.lbest);  // 128 x u16 = the 64 ints of lbest, idle during the seed passes
   lds.G = a.G;
+  lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
+  u32 seg_epoch = 0;
 
   // (rc, a_rich) calls per mode, in the reference's order
   // T-rich :1556-1572 | A-rich (-A/-P) | random PBAT :1649-1676
@@ -163,47 +145,32 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   const u32 call_rc = a.mode == 2 ? 0xCu /*0,0,1,1*/ : 0x2u /*0,1*/;
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
-  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  constexpr int MODE = kMain;
-  HelpWave hw;
-  hw.h = a.help;
-  if constexpr (NW == 1) hw.h.seg = nullptr;
-  hw.span = &bc->span[wave]; hw.epoch_w = &bc->epoch[wave]; hw.done_w = &bc->done[wave]; hw.info_w = &bc->info[wave][0];
-  hw.retired = &bc->retired;
-  hw.slot = blockIdx.x * NW + wave;
-  hw.epoch = 0;
-  hw.failed = hw.mismatch = false;
-  hw.st_jobs = hw.st_chunks = hw.st_taken = hw.st_helped = 0;
+  WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const CigarSink sink = {a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap};
-  PassCtl pc;
-  pc.hw = NW > 1 ? &hw : nullptr;
-  const u64 first = 0, n_items = a.n_reads;
+  const u64 n_items = a.n_reads;
   long long t_begin = 0, t_a = 0, t_b = 0;
   ABM_STAMP(t_begin);
-  u32 n_aln = 0;
+  u32 n_aln = 0, n_single = 0;
   bool overflow = false, too_long = false;
 
-  // reads are handed out by one device-wide counter (zeroed before every launch):
-  // work per read spans four orders of magnitude, so a static split would leave
-  // the launch waiting on whichever wave drew the heaviest reads
-  // A wave's FIRST read is dealt statically -- wave w of workgroup b takes position w * (workgroups) + b of the
-  // heaviest-first order, so the heaviest reads of a batch land in different workgroups (a workgroup's idle
-  // waves can only help their own block-mates) -- the rest come from the counter.
-  const u64 dealt = static_cast<u64>(gridDim.x) * NW;
+  // Reads are handed out by one device-wide counter (zeroed before every launch): work per read spans four orders
+  // of magnitude, so a static split would leave the launch waiting on whichever wave drew the heaviest reads.  A
+  // wave's FIRST read is dealt statically (its own number in the heaviest-first order), the rest come from the
+  // counter: the wave that draws n_items or more first signals `drained` -- from here on only reads already in
+  // flight are left, and the host may let the next batch's kernel in.
+  const u64 dealt = gridDim.x;
   auto next_read = [&]() -> u64 {
     unsigned long long v = 0;
     if (lane == 0) {
       v = atomicAdd(a.next_read, 1ull) + dealt;
-      // exactly one wave draws the first index past the end: from here on only reads already in
-      // flight are left, and the host may let the next batch's kernel in
-      if (v == n_items && a.drained) __hip_atomic_store(a.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (v >= n_items && a.drained) __hip_atomic_store(a.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(v >> 32)))) << 32) |
            static_cast<u32>(uni(static_cast<int>(v)));
   };
-  u64 r_next = static_cast<u64>(wave) * gridDim.x + blockIdx.x;
+  u64 r_next = blockIdx.x;
   while (r_next < n_items) {
-    const u64 r = a.order ? static_cast<u64>(a.order[first + r_next]) : r_next;
+    const u64 r = a.order ? static_cast<u64>(a.order[r_next]) : r_next;
     r_next = next_read();  // fetched early; its latency hides under this read's work
     long long t_read = 0;
     if (TIMED) t_read = clock64();
@@ -238,15 +205,15 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        seed_pass<true, TIMED, COOP, MODE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, &pc);
+        seed_pass<true, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         // should_do_sensitive, :367-370
         if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
           S.cutoff = S.top_d();  // set_sensitive
-          seed_pass<false, TIMED, COOP, MODE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, &pc);
+          seed_pass<false, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         }
       }
       ABM_STAMP(t_a);
-      choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln);
+      choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln, n_single);
       ABM_STAMP(t_b);
       if (TIMED) wt.t_align += t_b - t_a;
     }
@@ -256,10 +223,6 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       if (TIMED && a.read_cycles) a.read_cycles[r] = static_cast<u32>((clock64() - t_read) >> 10);
     }
   }
-  // no reads left: this wave's slot takes no more jobs, and it works for the waves still busy
-  // no reads left: stay and work for the block-mates that are still busy
-  if constexpr (NW > 1 && COOP) help_block_mates<NW>(a.ix, lds, bc, wave_lds0, a.lds_per_wave, wave, hw, wt);
-  else if constexpr (NW > 1) { if (lane == 0) __hip_atomic_fetch_add(&bc->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   if (a.work) {  // exact per-launch work tallies for the roofline model
     auto wsum = [&](u32 v) { u32 t; (void)wave_excl_sum(v, t); return t; };
     const u32 s0 = wsum(wt.seed_iters), s1 = wsum(wt.probes), s2 = wsum(wt.cands), s3 = wsum(wt.words);
@@ -272,31 +235,25 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       atomicAdd(&a.work[4], static_cast<unsigned long long>(wt.updates));
       atomicAdd(&a.work[5], static_cast<unsigned long long>(n_aln));
       atomicAdd(&a.work[11], static_cast<unsigned long long>(wsum_hits));
-      if (NW > 1 && hw.st_jobs + hw.st_helped) {
-        atomicAdd(&a.work[12], static_cast<unsigned long long>(hw.st_jobs));
-        atomicAdd(&a.work[13], static_cast<unsigned long long>(hw.st_chunks));
-        atomicAdd(&a.work[14], static_cast<unsigned long long>(hw.st_chunks - hw.st_taken));
-        atomicAdd(&a.work[15], static_cast<unsigned long long>(hw.st_helped));
-      }
+      atomicAdd(&a.work[12], static_cast<unsigned long long>(n_single));  // reads whose set held one alignable entry
       if (TIMED) {
         atomicAdd(&a.work[6], static_cast<unsigned long long>(wt.t_probe));
         atomicAdd(&a.work[7], static_cast<unsigned long long>(wt.t_stream));
         atomicAdd(&a.work[8], static_cast<unsigned long long>(wt.t_replay));
         atomicAdd(&a.work[9], static_cast<unsigned long long>(wt.t_align));
         atomicAdd(&a.work[10], static_cast<unsigned long long>(phase_stamp() - t_begin));
-        if (NW == 1) {  // (the in-block help slots are free in a one-wave workgroup)
-          atomicAdd(&a.work[14], static_cast<unsigned long long>(wt.fifo_updates));
-          atomicAdd(&a.work[15], static_cast<unsigned long long>(wt.steps));
-        }
+        atomicAdd(&a.work[13], static_cast<unsigned long long>(wt.light_steps));  // filter steps of at most 64 candidates
+        atomicAdd(&a.work[14], static_cast<unsigned long long>(wt.fifo_updates));
+        atomicAdd(&a.work[15], static_cast<unsigned long long>(wt.steps));
       }
     }
   }
-  if (lane == 0 && (overflow || too_long || hw.failed || hw.mismatch))
-    atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u) | (hw.failed ? 8u : 0u) | (hw.mismatch ? 16u : 0u));
+  if (lane == 0 && (overflow || too_long))
+    atomicOr(a.status, (overflow ? 1u : 0u) | (too_long ? 2u : 0u));
   if (a.host_tail != nullptr && lane == 0) {  // the last wave to get here publishes the launch's two summary words
     __threadfence();
     const u32 before = atomicAdd(a.finished, 1u);
-    if (before + 1u == gridDim.x * NW) {
+    if (before + 1u == gridDim.x) {
       __threadfence();
       a.host_tail[0] = __hip_atomic_load(a.cig_arena_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       a.host_tail[1] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -304,13 +261,9 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   }
 }
 
-#ifndef ABM_SE_BLOCK_WAVES
-#define ABM_SE_BLOCK_WAVES 4  // waves per workgroup of the cooperative-filter kernel (see HelpWave); 20 waves per CU = 5 workgroups
-#endif
-constexpr u32 kBlockWaves = ABM_SE_BLOCK_WAVES;
-// (the launch bound's second argument is waves per SIMD: 5 x 4 SIMDs = 20 waves per CU whatever the workgroup shape)
-template <bool TIMED, bool COOP, u32 NW>
-__global__ __launch_bounds__(64 * NW, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, NW>(a); }
+// (the launch bound's second argument is waves per SIMD: 5 x 4 SIMDs = 20 one-wave workgroups per CU)
+template <bool TIMED, bool COOP>
+__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP>(a); }
 
 // =============================================================================
 // Heaviest-first ordering.  Work per read spans four orders of magnitude and is
@@ -435,19 +388,6 @@ hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned lon
   return hipGetLastError();
 }
 
-// ---- in-block help workspace -----------------------------------------------------
-void se_help_bytes(u32 n_waves, u32 cap, size_t &zeroed, size_t &total) {
-  zeroed = static_cast<size_t>(kHelpFlagWords) * n_waves * 4;
-  total = zeroed + (static_cast<size_t>(kHelpSegWords) + cap / 2 + cap) * n_waves * 4;
-}
-void se_help_carve(char *base, u32 n_waves, u32 cap, HelpArgs &h) {
-  h.flags = reinterpret_cast<u32 *>(base);
-  h.seg = h.flags + static_cast<size_t>(kHelpFlagWords) * n_waves;
-  h.res = h.seg + static_cast<size_t>(kHelpSegWords) * n_waves;
-  h.cap = cap;
-}
-u32 se_block_waves() { return kBlockWaves; }
-
 // ---- launchers ----------------------------------------------------------------
 u32 se_window_words(u32 max_len, double valid_frac) {
   const int md = static_cast<i16>(valid_frac * max_len);
@@ -471,33 +411,24 @@ size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_fra
   const u32 MB = (max_len + kPlaneBlock - 1) / kPlaneBlock;
   size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + static_cast<size_t>(4) * MB * 4 * 8 +
              (static_cast<size_t>(8) << kPosCacheBits) +
-             static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>((cig_stride + 1) & ~1u) * 4 + se_stage_extra(cig_stride, GW) +
-             2 * kSeCap * 4 + 64 * 4 + 64 * 2;
+             static_cast<size_t>(kMaxJobs) * GW * 8 + static_cast<size_t>((cig_stride + 1) & ~1u) * 4 +
+             2 * kSeCap * 4 + 64 * 4 + 2 * 128 * 4 + 64 * 2;
   b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);
 }
 
-static size_t se_block_lds(size_t per_wave, u32 block_waves) {
-  return block_waves > 1 ? ((sizeof(BlockCtl<kBlockWaves>) + 15) & ~static_cast<size_t>(15)) + per_wave * block_waves : per_wave;
-}
-
-int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac, u32 block_waves) {
+int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac) {
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  const size_t lds = se_block_lds(se_lds_bytes(W, WB, cig_stride, max_len, valid_frac), block_waves);
-  const hipError_t e = block_waves > 1
-      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true, kBlockWaves>, 64 * kBlockWaves, lds)
-      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true, 1>, 64, lds);
-  if (e != hipSuccess) return 0;
-  // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): the kernel is bound by
-  // the random line requests a CU can keep outstanding, and what matters is waves without register
-  // spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
+  const size_t lds = se_lds_bytes(W, WB, cig_stride, max_len, valid_frac);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true>, 64, lds) != hipSuccess) return 0;
+  // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): what matters is waves without
+  // register spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
   // window loads with 8 rounds in flight, 16 waves at 128 registers 1029 ms (20 waves at 96 with spills:
   // 1386); with 2 rounds in flight 20 waves fit almost without spills: 923 ms (24 waves: 999).
   constexpr int kSeWavesPerCu = 4 * ABM_SE_WAVES_PER_SIMD;
-  return min(per_cu * static_cast<int>(block_waves), kSeWavesPerCu) / static_cast<int>(block_waves) * static_cast<int>(block_waves) *
-         prop.multiProcessorCount;
+  return min(per_cu, kSeWavesPerCu) * prop.multiProcessorCount;
 }
 
 hipError_t launch_make_planes(const u64 *d_genome, u64 n_words, u64 n_bases, u64 n_blocks, u64 *d_planes0,
@@ -517,26 +448,18 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
   return hipGetLastError();
 }
 
-hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, u32 block_waves, bool timed, hipStream_t st) {
+hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, bool timed, hipStream_t st) {
   if (a.n_reads == 0) return hipSuccess;
-  const size_t per_wave = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
-  a.lds_per_wave = static_cast<u32>(per_wave);
-  if (a.G == 0 || block_waves != kBlockWaves) block_waves = 1;  // in-block help needs the cooperative filter
-  const size_t lds = se_block_lds(per_wave, block_waves);
-  const u32 waves = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
-  const u32 blocks = (waves + block_waves - 1) / block_waves;
-  // COOP: G lanes share a candidate's window (a.G != 0); otherwise one lane per window
-  if (a.G != 0 && block_waves > 1) {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, kBlockWaves>), dim3(blocks), dim3(64 * kBlockWaves), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, true, kBlockWaves>), dim3(blocks), dim3(64 * kBlockWaves), lds, st, a);
-  }
-  else if (a.G != 0) {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, 1>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, true, 1>), dim3(blocks), dim3(64), lds, st, a);
+  const size_t lds = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
+  const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
+  // COOP: lanes share a candidate's window on the bit planes (a.G != 0); otherwise one lane per window
+  if (a.G != 0) {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
   }
   else {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false, 1>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, false, 1>), dim3(blocks), dim3(64), lds, st, a);
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, false>), dim3(blocks), dim3(64), lds, st, a);
   }
   return hipGetLastError();
 }

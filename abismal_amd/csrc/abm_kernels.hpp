@@ -5,24 +5,12 @@
 
 namespace abm {
 
-// workspace of the single-end kernel's in-block help (HelpWave in abm_kernels_core.hpp), one slot per wave of the
-// grid; all null = off.  `flags` is zeroed before every launch.
-//   seg:   kHelpSegWords words: the open job's segment table
-//   flags: kHelpFlagWords words: per chunk, the job number whose results the buffer holds
-//   res:   cap/2 words of distances (two u16) + cap words of positions
-struct HelpArgs {
-  u32 *seg, *flags, *res;
-  u32 cap;  // candidates per job (multiple of 128, at most 128 * kHelpFlagWords)
-};
-
 struct SeArgs {
   DevIndex ix;
-  HelpArgs help;
   const u64 *packed;  // [n][4][W]
   const u32 *lens;    // [n]
   const u32 *order;   // [n] processing order (heaviest first), or null
   u64 n_reads;
-  u32 lds_per_wave;   // bytes of LDS per wave (se_lds_bytes)
   u32 W, WB, GW;      // words per packed encoding / 2-letter bit string / genome window
   u32 max_len;        // longest read of the batch
   u32 tb_extra;       // tb_extra_bytes()
@@ -99,6 +87,14 @@ constexpr u32 kPeTier1Cap = ABM_PE_TIER1_CAP;
 
 u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
+// seed-extension tables (abm_ext.hip): keys of table `mode` (0: 2-letter, 1 / 2: 3-letter C->T / G->A) with `extra`
+// letters beyond the hashed ones; bytes of scratch a build needs; the build itself (out[ext_keys] entries, n_idx =
+// entries of the table's index array)
+constexpr u32 kExtGapCap = 1u << 20;
+u64 ext_keys(int mode, u32 extra);
+size_t ext_scratch_bytes(int mode, u32 extra);
+hipError_t build_ext_table(const DevIndex &ix, int mode, u32 extra, u32 maxc, u64 n_idx, uint2 *out, void *scratch, u32 *d_fail,
+                           hipStream_t st);
 // bit-plane copies of the genome for the Hamming filter (DevIndex::planes): n_blocks blocks of 64 bases each,
 // from the first n_words words of nibbles; blank nibbles (N) mark their surroundings in nmap (DevIndex::nmap,
 // zeroed by the caller); *bad is set if a nibble below n_bases has two or more bits
@@ -112,12 +108,8 @@ hipError_t launch_compact_cigars(const Hit *d_res, const u32 *d_cig, const u32 *
                                  unsigned long long *d_off, u32 *d_blob, void *tmp, size_t *tmp_bytes, hipStream_t st);
 hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned long long *d_off, u64 n, u32 *d_blob,
                                 hipStream_t st);
-// n_waves = waves of the grid; block_waves = waves per workgroup (1, or se_block_waves() with in-block help)
-hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, u32 block_waves, bool timed, hipStream_t st);
-u32 se_block_waves();
-// bytes of the help workspace for a grid of n_waves: {zeroed part (the flags, at its start), total}
-void se_help_bytes(u32 n_waves, u32 cap, size_t &zeroed, size_t &total);
-void se_help_carve(char *base, u32 n_waves, u32 cap, HelpArgs &h);
-int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac, u32 block_waves = 1);
+// n_waves = one-wave workgroups of the (persistent) grid
+hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, bool timed, hipStream_t st);
+int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 
 }  // namespace abm

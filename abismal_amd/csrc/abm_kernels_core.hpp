@@ -212,8 +212,9 @@ struct WaveLds {
   u64 *qpk;    // [4][W] packed encodings
   u64 *qbits;  // [4][WB] 2-letter bit strings, bit j = bit2(nibble j), 1 past the end
   u64 *qmask;  // [4][MB][4] per block of 64 read bases: which of them admit genome code 0, 1, 2, 3 (cooperative filter)
-  u8 *stage;   // kStageRounds x 1 KiB (+ 32 bytes): window blocks land here straight from memory (single-end kernel; null: registers)
-  u16 *mark;   // [64]
+  u16 *mark;   // [64] (paired-end mating)
+  u32 *smark;  // [128] seed pass: where the segments of a flattened block begin inside the current 128-candidate step (locate128)
+  u32 *sdelta; // [128] seed pass: per segment, index-array position minus candidate number of its first entry
   u32 *ctmp;   // [ctmp_cap] reversed CIGAR scratch
   u8 *tb;      // traceback bytes
   u64 *gwin;   // [kMaxJobs][GW] genome windows of the alignments in flight
@@ -242,127 +243,48 @@ __device__ __forceinline__ u64 q_window16(const u64 *qpk, u32 W, u32 i, u32 L) {
   return x;
 }
 
-// std::lower_bound's exact probe sequence (see oracle first_not)
-template <class Below>
-__device__ __forceinline__ u32 first_not(u32 lo, u32 hi, u32 &probes, Below below) {
-  int n = static_cast<int>(hi - lo);
-  while (n > 0) {
-    const int half = n >> 1;
-    ++probes;
-    if (below(lo + half)) { lo += half + 1; n -= half + 1; }
-    else n = half;
-  }
-  return lo;
-}
+// The genome letter at position q as the narrowing loops need it: its 2-letter bit / its 3-letter sort symbol
+// (from the nibble array: a probe can land on an N, which the bit planes cannot express).
+__device__ __forceinline__ u32 genome_bit2(const DevIndex &ix, u64 q) { return bit2(gnib(ix.genome, q)); }
+__device__ __forceinline__ u32 genome_sortsym3(const DevIndex &ix, u64 q, bool g_to_a) { return sortsym3(gnib(ix.genome, q), g_to_a); }
 
-// find_candidates, src/abismal.cpp:1163-1194 (range as indices into tbl[]).  The read's letters come
-// from its 2-letter bit string qb (n_bits of it; 1 beyond): the loop ends at p == limit, and for reads
-// of 44-46 bases limit = L - i is BELOW the starting length for the last offsets, so the reference
-// keeps extending past the end of the read, through whatever its reused buffer holds there (the
-// ghost bits the kernel puts into qb: ghost_bits).
-// The genome letter at position q as the narrowing loops need it: its 2-letter bit / its 3-letter sort symbol.
-// PLANES: from the bit planes (the cooperative filter's copy of the genome, so the narrowing probes and the
-// windows share one array and its cache lines; the nibble array is then only read by the alignments).
-template <bool PLANES>
-__device__ __forceinline__ u32 genome_bit2(const DevIndex &ix, u64 q) {
-  if constexpr (PLANES) return static_cast<u32>(ix.planes[0][2 * (q / kPlaneBlock)] >> (q % kPlaneBlock)) & 1u;  // codes 1 (C), 3 (T)
-  else return bit2(gnib(ix.genome, q));
-}
-template <bool PLANES>
-__device__ __forceinline__ u32 genome_sortsym3(const DevIndex &ix, u64 q, bool g_to_a) {
-  if constexpr (PLANES) {
-    const u64 *b = ix.planes[0] + 2 * (q / kPlaneBlock);
-    const u32 code = (static_cast<u32>(b[0] >> (q % kPlaneBlock)) & 1u) | ((static_cast<u32>(b[1] >> (q % kPlaneBlock)) & 1u) << 1);
-    return sortsym3(1u << code, g_to_a);
-  }
-  else return sortsym3(gnib(ix.genome, q), g_to_a);
-}
-
-template <bool PLANES>
-__device__ __forceinline__ u32 narrow2(const DevIndex &ix, const u32 *__restrict__ tbl,
-                                       const u64 *qb, u32 n_bits, u32 qbase, u32 limit, u32 maxc, u32 &lo,
-                                       u32 &hi, u32 &probes) {
-  u32 p = kKeyWeight, plo = lo, phi = hi;
-  for (; p != limit && (hi - lo) > maxc && qbase + p < n_bits + 4096u; ++p) {
-    plo = lo; phi = hi;
-    const u32 ones = first_not(lo, hi, probes, [&](u32 k) {
-      return genome_bit2<PLANES>(ix, static_cast<u64>(tbl[k]) + p) < 1u;
-    });
-    const u32 at = qbase + p;
-    const bool one = at < n_bits ? ((qb[at >> 6] >> (at & 63u)) & 1ull) != 0 : true;
-    lo = one ? ones : lo;  // (selects on values: written as stores to one of two references, lo and hi end up in scratch memory)
-    hi = one ? hi : ones;
-  }
-  if (lo == hi) { --p; lo = plo; hi = phi; }
-  return p;
-}
-
-// find_candidates_three, src/abismal.cpp:1214-1259.  The reference runs two std::lower_bound
-// bisections (first symbol >= mid, first symbol >= top) over the same range; they start at the
-// same midpoint and share probes until their paths part, so both advance in lockstep here and a
-// probe whose index coincides is loaded once.  Each bisection still sees exactly its own probe
-// sequence, so the boundaries are the reference's even where the bucket tail is unsorted.
-template <bool PLANES>
-__device__ __forceinline__ u32 narrow3(const DevIndex &ix, const u32 *__restrict__ tbl,
-                                       bool g_to_a, const u64 *qpk, u32 qbase, u32 limit, u32 maxc,
-                                       u32 &lo, u32 &hi, u32 &probes) {
-  const u32 mid_sym = g_to_a ? 2u : 1u, top_sym = g_to_a ? 8u : 4u;
-  u32 p = kKeyWeight3, plo = lo, phi = hi;
-  for (; p != limit && (hi - lo) > maxc; ++p) {
-    plo = lo; phi = hi;
-    u32 l1 = lo, l2 = lo;
-    int n1 = static_cast<int>(hi - lo), n2 = n1;
-    while (n1 > 0 || n2 > 0) {
-      const int h1 = n1 >> 1, h2 = n2 >> 1;
-      const u32 m1 = l1 + static_cast<u32>(h1), m2 = l2 + static_cast<u32>(h2);
-      u32 s1 = 0, s2 = 0;
-      if (n1 > 0) { s1 = genome_sortsym3<PLANES>(ix, static_cast<u64>(tbl[m1]) + p, g_to_a); ++probes; }
-      if (n2 > 0) {
-        if (n1 > 0 && m2 == m1) s2 = s1;
-        else { s2 = genome_sortsym3<PLANES>(ix, static_cast<u64>(tbl[m2]) + p, g_to_a); ++probes; }
-      }
-      if (n1 > 0) { if (s1 < mid_sym) { l1 = m1 + 1; n1 -= h1 + 1; } else n1 = h1; }
-      if (n2 > 0) { if (s2 < top_sym) { l2 = m2 + 1; n2 -= h2 + 1; } else n2 = h2; }
-    }
-    const u32 b1 = l1, b2 = l2;
-    const u32 sym = sortsym3(q_nibble(qpk, qbase + p), g_to_a);
-    const u32 nlo = sym == 0 ? lo : (sym == mid_sym ? b1 : b2), nhi = sym == 0 ? b1 : (sym == mid_sym ? b2 : hi);
-    lo = nlo;
-    hi = nhi;
-  }
-  if (lo == hi) { --p; lo = plo; hi = phi; }
-  return p;
-}
-
-// narrow2 and narrow3 of one seed offset advanced TOGETHER: every round issues the next probe of the 2-letter
-// bisection and of both 3-letter bisections before any of them is waited for (three dependent chains of
-// index-entry -> genome-letter loads in flight per lane instead of one after the other).  Each chain sees exactly
-// the probe sequence and the updates it has in narrow2 / narrow3; a chain with nothing to probe in a round reads
-// entry 0 of its table and ignores it.
-template <bool PLANES>
+// find_candidates (src/abismal.cpp:1163-1194) and find_candidates_three (:1214-1259) of one seed offset, advanced
+// TOGETHER.  Both narrow a bucket letter by letter with std::lower_bound bisections (one per letter on the 2-letter
+// table; two per letter -- first symbol >= mid, first symbol >= top -- on a 3-letter table, which start at the same
+// midpoint and share probes until their paths part).  Every round issues the next probe of the 2-letter bisection
+// and of both 3-letter bisections before any of them is waited for (three dependent chains of index-entry ->
+// genome-letter loads in flight per lane instead of one after the other); each bisection sees exactly
+// std::lower_bound's probe sequence, so the boundaries are the reference's even where a bucket's tail is unsorted.
+// A chain with nothing to probe in a round reads entry 0 of its table and ignores it.  The read's letters of the
+// 2-letter chain come from its bit string qb (n_bits of it; 1 beyond): the loop ends at p == limit, and for reads
+// of 44-46 bases limit = L - i is BELOW the starting length for the last offsets, so the reference keeps extending
+// past the end of the read, through whatever its reused buffer holds there (the ghost bits put into qb: ghost_bits).
 __device__ __forceinline__ void narrow_both(const DevIndex &ix, const u32 *__restrict__ tbl3, bool g_to_a, const u64 *qb,
-                                            u32 n_bits, const u64 *qpk, u32 qbase, u32 limit, u32 maxc, u32 &lo2, u32 &hi2,
-                                            u32 &len2, u32 &lo3, u32 &hi3, u32 &len3, u32 &probes) {
+                                            u32 n_bits, const u64 *qpk, u32 qbase, u32 limit, u32 maxc, bool run2, u32 &lo2,
+                                            u32 &hi2, u32 &len2, bool run3, u32 &lo3, u32 &hi3, u32 &len3, u32 &probes) {
+  // (len2 / len3 on entry: the letters each range has been narrowed by already -- the key weights, or more where the
+  // seed-extension tables have taken the first steps; run2 / run3 false: the table has finished that chain, nothing
+  // is done to its range)
   const u32 *__restrict__ tbl2 = ix.index;
   const u32 mid_sym = g_to_a ? 2u : 1u, top_sym = g_to_a ? 8u : 4u;
-  u32 pA = kKeyWeight, ploA = lo2, phiA = hi2, blA = 0;
+  u32 pA = len2, ploA = lo2, phiA = hi2, blA = 0;
   int bnA = 0;
   auto goA = [&]() { return pA != limit && (hi2 - lo2) > maxc && qbase + pA < n_bits + 4096u; };
-  bool actA = goA();
+  bool actA = run2 && goA();
   if (actA) { blA = lo2; bnA = static_cast<int>(hi2 - lo2); }
-  u32 pB = kKeyWeight3, ploB = lo3, phiB = hi3, l1 = 0, l2 = 0;
+  u32 pB = len3, ploB = lo3, phiB = hi3, l1 = 0, l2 = 0;
   int n1 = 0, n2 = 0;
   auto goB = [&]() { return pB != limit && (hi3 - lo3) > maxc; };
-  bool actB = goB();
+  bool actB = run3 && goB();
   if (actB) { l1 = l2 = lo3; n1 = n2 = static_cast<int>(hi3 - lo3); }
   while (actA || actB) {
     const int hA = bnA >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     const u32 kA = blA + static_cast<u32>(hA), m1 = l1 + static_cast<u32>(h1), m2 = l2 + static_cast<u32>(h2);
     const bool dA = actA, d1 = actB && n1 > 0, d2 = actB && n2 > 0 && !(d1 && m2 == m1);
     const u32 eA = tbl2[dA ? kA : 0u], e1 = tbl3[d1 ? m1 : 0u], e2 = tbl3[d2 ? m2 : 0u];
-    const u32 sA = genome_bit2<PLANES>(ix, static_cast<u64>(eA) + pA);
-    const u32 s1 = genome_sortsym3<PLANES>(ix, static_cast<u64>(e1) + pB, g_to_a);
-    u32 s2 = genome_sortsym3<PLANES>(ix, static_cast<u64>(e2) + pB, g_to_a);
+    const u32 sA = genome_bit2(ix, static_cast<u64>(eA) + pA);
+    const u32 s1 = genome_sortsym3(ix, static_cast<u64>(e1) + pB, g_to_a);
+    u32 s2 = genome_sortsym3(ix, static_cast<u64>(e2) + pB, g_to_a);
     probes += (dA ? 1u : 0u) + (d1 ? 1u : 0u) + (d2 ? 1u : 0u);
     if (actA) {  // one step of first_not (std::lower_bound's probe sequence), then find_candidates' update
       if (sA < 1u) { blA = kA + 1; bnA -= hA + 1; } else bnA = hA;
@@ -391,8 +313,8 @@ __device__ __forceinline__ void narrow_both(const DevIndex &ix, const u32 *__res
       }
     }
   }
-  if (lo2 == hi2) { --pA; lo2 = ploA; hi2 = phiA; }
-  if (lo3 == hi3) { --pB; lo3 = ploB; hi3 = phiB; }
+  if (run2 && lo2 == hi2) { --pA; lo2 = ploA; hi2 = phiA; }
+  if (run3 && lo3 == hi3) { --pB; lo3 = ploB; hi3 = phiB; }
   len2 = pA;
   len3 = pB;
 }
@@ -482,15 +404,6 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
   if (G == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false);
   return v;
 }
-#ifndef ABM_STAGE_WINDOWS
-#define ABM_STAGE_WINDOWS false  // single-end kernel: window blocks through LDS-DMA loads (hamming_planes_staged)
-#endif
-#ifndef ABM_NARROW_PLANES
-#define ABM_NARROW_PLANES false  // true (experiments only): narrowing reads the bit planes -- not exact where a probe lands on an N
-#endif
-#ifndef ABM_NARROW_TOGETHER
-#define ABM_NARROW_TOGETHER true  // the two tables' narrowing loops of a seed offset run in lockstep (narrow_both)
-#endif
 #ifndef ABM_COOP_ROUNDS
 #define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (scripts/se_variant.sh): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
 #endif
@@ -530,6 +443,12 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
   u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
   if (counts) { const u64 *q = qm + sub * 4; m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; }
   for (u32 pass = 0; pass * kRounds * per_round < 128; ++pass) {
+    {  // a pass none of whose slots is wanted (most steps of an ordinary read hold a few candidates) costs nothing
+      const u32 slot0 = pass * kRounds * per_round;
+      const u64 w = (slot0 >= 64 ? wb : wa) >> (slot0 & 63u);
+      if (kRounds * per_round < 64 && (w & ((1ull << (kRounds * per_round)) - 1)) == 0) continue;
+      if (kRounds * per_round >= 64 && w == 0) continue;
+    }
     u64 xl[kRounds], xh[kRounds];
     u64 shifts = 0;  // (pos & 63) of the rounds' candidates, eight bits each (up to eight rounds)
 #pragma unroll
@@ -591,6 +510,8 @@ __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const W
   for (u32 pass = 0; pass < 4; ++pass) {
     const u32 slot = pass * 32 + grp;  // < 128; passes 0-1 are the lanes' first candidates, 2-3 their second
     const bool second = pass >= 2;
+    // (a pass none of whose 32 slots is wanted costs nothing: most steps of an ordinary read hold a few candidates)
+    if (static_cast<u32>((second ? wb : wa) >> ((pass & 1u) * 32u)) == 0u) continue;
     const u32 c = slot & 63u;
     const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
     const u32 sh = cp & 63u;
@@ -612,161 +533,52 @@ __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const W
   wave_sync();
 }
 
-// The same through LDS: the 16-byte window blocks of kStageRounds rounds (16 candidates each for groups of four)
-// are fetched by LDS-DMA loads (global_load_lds_dwordx4: no destination registers, the wave's 64 x 16 bytes land
-// lane-linear in a 1 KiB piece of lds.stage), so twice as many windows are in flight per lane as the register
-// version affords at 96 VGPRs; a lane then reads its own block and the next lane's (the bits past its block) back
-// with two ds_read_b128.  Same arithmetic, same results.
-constexpr u32 kStageRounds = 4;
-constexpr u32 kStageBytes = kStageRounds * 1024 + 32;
-__device__ __forceinline__ void hamming_planes_staged(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
-                                                      u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
-  const int lane = lane_id();
-  const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
-  const u64 wa = __ballot(want_a), wb = __ballot(want_b);
-  const bool counts = sub * kPlaneBlock < L;
-  u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-  if (counts) { const u64 *q = qm + sub * 4; m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; }
-  typedef __attribute__((address_space(3))) void lds_void;
-  for (u32 pass = 0; pass * kStageRounds * per_round < 128; ++pass) {
-    u32 shifts = 0;  // (pos & 63) of the rounds' candidates, eight bits each
-#pragma unroll
-    for (u32 r = 0; r < kStageRounds; ++r) {
-      const u32 slot = (pass * kStageRounds + r) * per_round + grp;
-      const bool second = (pass * kStageRounds + r) * per_round >= 64;
-      const u32 c = slot & 63u;
-      const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
-      shifts |= (cp & 63u) << (8 * r);
-      const u32 b0 = cp / kPlaneBlock, b1 = G == 4 ? b0 + 3 : (cp + L - 1) / kPlaneBlock;
-      const bool act = (((second ? wb : wa) >> c) & 1ull) && b0 + sub <= b1;
-      const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
-                         : ix.planes[0];
-      __builtin_amdgcn_global_load_lds(g, (lds_void *)(lds.stage + r * 1024), 16, 0, 0);  // (generic -> LDS address space)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (u32 r = 0; r < kStageRounds; ++r) {
-      const u32 slot = (pass * kStageRounds + r) * per_round + grp;
-      const u32 sh = (shifts >> (8 * r)) & 63u;
-      const u64 *blk = reinterpret_cast<const u64 *>(lds.stage + r * 1024 + lane * 16);
-      const u64 xl = blk[0], xh = blk[1], nl = blk[2], nh = blk[3];
-      const u64 gl = (xl >> sh) | ((nl << (63 - sh)) << 1), gh = (xh >> sh) | ((nh << (63 - sh)) << 1);
-      const u64 match = (~gh & ((~gl & m0) | (gl & m1))) | (gh & ((~gl & m2) | (gl & m3)));
-      int d = counts ? 64 - __popcll(match) : 0;
-      d = group_sum(d, G);
-      if (sub == 0) lds.hres[slot] = static_cast<u16>(d);
-    }
-    wave_sync();  // the next pass's loads overwrite the pieces
-  }
-  d_a = static_cast<i16>(lds.hres[lane]);
-  d_b = static_cast<i16>(lds.hres[64 + lane]);
-  wave_sync();
-}
-
 // ---- flattened candidates of one 64-offset block ---------------------------------------
 // Per lane (= seed offset g0 + lane): its checked 2-letter bucket [lo2, lo2 + na) and 3-letter bucket
 // [lo3, lo3 + nb), laid end to end in the reference's visiting order (offset ascending, 2-letter
 // before 3-letter, index order): candidate c of the block is entry start_a + ... of whichever
-// segment contains c.
+// segment contains c.  Segment number = 2 * lane + (1 for the 3-letter table).
 struct Segs {
   u32 start_a, na, lo2, nb, lo3;
   __device__ __forceinline__ u32 start_b() const { return start_a + na; }
 };
-// the segment (2 * lane + is_three) that holds candidate c0 - 1, i.e. the one still open when the
-// 64-candidate window starting at c0 begins (needed when a window is not reached sequentially)
-__device__ __forceinline__ int seg_before(const Segs &sg, u32 c0) {
-  const int lane = lane_id();
-  int m = 0;
-  if (sg.na && sg.start_a < c0) m = 2 * lane + 1;
-  if (sg.nb && sg.start_b() < c0) m = 2 * lane + 2;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-  return m ? m - 1 : 0;
+constexpr u32 kSegEpochLimit = (1u << 24) - 4;
+// once per block: where each segment's entries lie relative to their candidate numbers
+__device__ __forceinline__ void publish_segs(const WaveLds &lds, const Segs &sg) {
+  typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = {sg.lo2 - sg.start_a, sg.lo3 - sg.start_b()};
+  *reinterpret_cast<u32x2 *>(lds.sdelta + 2 * lane_id()) = v;
 }
-// which (offset, table) segment each of the 64 candidates from c0 on belongs to, and where its index
-// entry is.  `carry` = the segment open at c0 (0 at c0 == 0; seg_before otherwise; updated for c0 + 64)
-__device__ __forceinline__ void locate(const WaveLds &lds, const Segs &sg, u32 c0, u32 total, int &carry,
-                                       bool &valid, int &owner, u32 &entry_at, bool &three) {
+// Which segment each of the 128 candidates c0 + lane (a) and c0 + 64 + lane (b) belongs to, and where its index
+// entry is.  Every segment that begins inside the step leaves a mark at its first candidate, a running maximum
+// spreads it over the candidates that follow, and candidates before the first mark belong to `carry`, the segment
+// open at c0 (0 at c0 == 0; updated for c0 + 128).  Marks are tagged with the call's epoch (seg_epoch: one counter
+// per wave, owned by the kernel) and never cleared: a stale mark is smaller than any mark of this call and loses
+// the maximum.
+__device__ __forceinline__ void locate128(const WaveLds &lds, u32 &seg_epoch, const Segs &sg, u32 c0, u32 total, u32 &carry, bool &va,
+                                          bool &vb, u32 &seg_a, u32 &seg_b, u32 &ea_at, u32 &eb_at) {
   const int lane = lane_id();
-  lds.mark[lane] = 0;
+  const u32 epoch = ++seg_epoch, tag = epoch << 8;
+  const u32 da = sg.start_a - c0, db = sg.start_b() - c0;
+  if (sg.na && da < 128u) lds.smark[da] = tag | static_cast<u32>(2 * lane + 1);
+  if (sg.nb && db < 128u) lds.smark[db] = tag | static_cast<u32>(2 * lane + 2);
   wave_sync();
-  if (sg.na && sg.start_a - c0 < 64u) lds.mark[sg.start_a - c0] = static_cast<u16>(2 * lane + 1);
-  if (sg.nb && sg.start_b() - c0 < 64u) lds.mark[sg.start_b() - c0] = static_cast<u16>(2 * lane + 2);
-  wave_sync();
-  const int m = wave_incl_max(static_cast<int>(lds.mark[lane]));
-  const int seg = m ? m - 1 : carry;
-  carry = rdlane(seg, 63);
-  owner = seg >> 1;
-  three = seg & 1;
-  const u32 c = c0 + lane;
-  valid = c < total;
-  // (all four exchanges are made by every lane: a shuffle inside a divergent branch would not
-  // see the lanes on the other side)
-  const u32 sa = __shfl(sg.start_a, owner), sb = __shfl(sg.start_b(), owner);
-  const u32 ba = __shfl(sg.lo2, owner), bb = __shfl(sg.lo3, owner);
-  entry_at = three ? bb + (c - sb) : ba + (c - sa);
-}
-
-// ---- in-block help: idle waves of a workgroup take filter chunks of a block-mate's heavy read -------------
-// Reads differ in cost by four orders of magnitude: a homopolymer or satellite read puts one to two
-// million candidates through the filter, 128 per dependent memory round trip, and keeps its wave busy
-// for 0.2-0.3 s -- long after a small batch's other reads are done.  The single-end kernel therefore
-// runs kBlockWaves waves per workgroup, each mapping its own reads exactly as a one-wave workgroup would
-// (own LDS region, no workgroup barrier after start-up).  A wave that has run out of reads does not exit:
-// it watches its block-mates.  A mate ("owner") that meets a block with many candidates while some wave
-// of its workgroup is idle opens a JOB: its segment table goes to its slot in global memory, the chunks
-// [0, n) of 128 candidates become claimable from BOTH ends through one LDS word -- the owner takes them
-// from the front in order, exactly as it would alone; helpers take them from the back, run the same
-// filter against the owner's read (which they read straight from the owner's LDS) and put distance +
-// position per candidate into the owner's result buffer.  Where the two meet, the owner stops computing
-// and replays the helpers' results from the buffer, still in the reference's order.  Distances are a
-// pure function of (read, position), so which wave computed them cannot show in the output.
-//
-// Everything stays inside one CU: owner and helpers share its LDS and its vector L1, so workgroup-scope
-// ordering suffices (no agent-scope fence, no cross-XCD visibility protocol); results reach the owner
-// through global memory only because 16 K candidates x 6 bytes per wave would not fit LDS.
-constexpr u32 kHelpMin = 1024;        // candidates in a block from which its owner opens a job
-constexpr u32 kHelpChunk = 128;       // candidates per chunk (one filter step)
-constexpr u32 kHelpFlagWords = 128;   // chunks per job at most = cap / 128
-constexpr u32 kHelpSegWords = 5 * 64;  // a job's segment table: five words per lane
-constexpr u32 kHelpSpinLimit = 1u << 24;  // polls before a wait gives up and flags the launch
-#ifndef ABM_HELP_ROUNDS
-#define ABM_HELP_ROUNDS 8  // rounds of window loads in flight per lane in a helper's chunk (it has nothing else to hold)
-#endif
-
-#define ABM_WG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define ABM_WG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-__device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-
-// per-workgroup control block at the start of dynamic LDS (only when kBlockWaves > 1)
-template <u32 NW> struct BlockCtl {
-  u32 retired;        // waves that have no reads left
-  u32 span[NW];       // wave w's open job: hi << 16 | lo, unclaimed chunks = [lo, hi); 0 = none
-  u32 epoch[NW];      // job number of wave w (tags the per-chunk flags)
-  u32 done[NW];       // chunks of the current job its helpers have finished
-  u32 info[NW][6];    // enc | g_to_a << 8, g0, total, c_base, L, unused
-};
-
-struct HelpWave {  // one wave's view of the help machinery
-  HelpArgs h;       // global workspace (null = help off)
-  u32 *span, *epoch_w, *done_w, *info_w;  // this wave's words in the control block
-  const u32 *retired;
-  u32 slot;         // global wave number: its slot in the workspace
-  u32 epoch;        // jobs this wave has opened
-  bool failed;      // a bounded wait gave up
-  bool mismatch;    // ABM_HELP_SELFCHECK build only
-  u32 st_jobs, st_chunks, st_taken, st_helped;  // diagnostics: jobs opened, their chunks, chunks its helpers took; chunks this wave computed for others
-
-  __device__ __forceinline__ u32 *seg(u32 s) const { return h.seg + static_cast<u64>(kHelpSegWords) * s; }
-  __device__ __forceinline__ u32 *flags(u32 s) const { return h.flags + static_cast<u64>(kHelpFlagWords) * s; }
-  __device__ __forceinline__ u32 *res_d(u32 s) const { return h.res + static_cast<u64>(s) * (h.cap / 2 + h.cap); }
-  __device__ __forceinline__ u32 *res_p(u32 s) const { return res_d(s) + h.cap / 2; }
-  __device__ __forceinline__ bool wanted() const {  // some wave of this workgroup is idle
-    return h.seg != nullptr && uni(static_cast<int>(ABM_WG_LOAD(retired))) != 0;
+  const bool two = c0 + 64 < total;  // (uniform)
+  u32 ma = lds.smark[lane], mb = two ? lds.smark[64 + lane] : 0u;
+  ma = wave_incl_max(ma);
+  seg_a = (ma >> 8) == epoch ? (ma & 255u) - 1u : carry;
+  carry = rdlane(seg_a, 63);
+  va = c0 + lane < total;
+  ea_at = c0 + lane + lds.sdelta[seg_a];
+  vb = false; seg_b = 0; eb_at = 0;
+  if (two) {
+    mb = wave_incl_max(mb);
+    seg_b = (mb >> 8) == epoch ? (mb & 255u) - 1u : carry;
+    carry = rdlane(seg_b, 63);
+    vb = c0 + 64 + lane < total;
+    eb_at = c0 + 64 + lane + lds.sdelta[seg_b];
   }
-};
+}
 
 // Ghost bits.  The reference hashes a read's first max(20, L/2) seed offsets and extends the last
 // ones while their buckets are too big; for reads of 44-46 bases that reaches PAST the end of the read,
@@ -804,40 +616,13 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
   wave_sync();
 }
 
-// distances and positions of candidates [c0, c0 + 128) of a flattened block (two per lane: c0 + lane
-// and c0 + 64 + lane), reached out of sequence -- what a claimed chunk of a job computes
-__device__ __forceinline__ void filter_chunk(const DevIndex &ix, const WaveLds &lds, const u64 *qm, const u64 *qpk, const u32 *idx3,
-                                             u32 L, const Segs &sg, u32 g0, u32 total, u32 c0, int &ha, int &hb,
-                                             u32 &pa, u32 &pb) {
-  int carry = seg_before(sg, c0);
-  bool va, vb = false, ta3, tb3 = false;
-  int oa, ob = 0;
-  u32 ea_at, eb_at = 0, ea = 0, eb = 0;
-  locate(lds, sg, c0, total, carry, va, oa, ea_at, ta3);
-  if (c0 + 64 < total) locate(lds, sg, c0 + 64, total, carry, vb, ob, eb_at, tb3);
-  if (va) ea = ta3 ? idx3[ea_at] : ix.index[ea_at];
-  if (vb) eb = tb3 ? idx3[eb_at] : ix.index[eb_at];
-  pa = ea - (g0 + static_cast<u32>(oa));
-  pb = eb - (g0 + static_cast<u32>(ob));
-  const u32 na = va ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
-  const u32 nb = vb ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-  if (lds.G == 2) hamming_planes_pairs(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
-  else hamming_planes<ABM_HELP_ROUNDS>(ix, lds, qm, L, pa, va, pb, vb, ha, hb);
-  if (__any((na | nb) & 1u)) {
-    if (na & 1u) ha = hamming(ix.genome, qpk, (L + 15) >> 4, pa);
-    if (nb & 1u) hb = hamming(ix.genome, qpk, (L + 15) >> 4, pb);
-  }
-  if (!va) ha = 0x7fff;
-  if (!vb) hb = 0x7fff;
-}
-
 // One (strand, alphabet) call of process_seeds (src/abismal.cpp:1269-1375) for
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
 // candidates (all checked buckets of 64 offsets flattened in reference order)
 // for the Hamming filter; survivors are replayed in order into the set.
 struct WorkTally {
   u32 seed_iters, probes, cands, words, updates, cache_hits;
-  u32 fifo_updates, steps;  // diagnostic build only
+  u32 fifo_updates, steps, light_steps;  // diagnostic build only
   // diagnostic build only (TIMED): shader cycles per phase, from s_memtime
   long long t_probe, t_stream, t_replay, t_align, t_total;
 };
@@ -852,17 +637,9 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-// How a seed pass is run: kPlain (paired-end kernels), kMain (single-end kernel: a heavy block's filter
-// work can be shared with idle waves of the workgroup, see HelpWave)
-enum PassMode { kPlain = 0, kMain = 1 };
-struct PassCtl {
-  HelpWave *hw;  // kMain with in-block help; null otherwise
-};
-template <bool SPECIFIC, bool TIMED, bool COOP, int MODE, class Set>
+template <bool SPECIFIC, bool TIMED, bool COOP, class Set>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
-                                          u32 flags, u32 L, Set &S, WorkTally &wt, PassCtl *pc = nullptr) {
-  constexpr bool HELP = MODE == kMain && COOP;
-  HelpWave *hw = (HELP && pc != nullptr) ? pc->hw : nullptr;
+                                          u32 flags, u32 L, Set &S, WorkTally &wt, u32 &seg_epoch) {
   const int lane = lane_id();
   const u64 *qpk = lds.qpk + enc * lds.W;
   const u64 *qb = lds.qbits + enc * lds.WB;
@@ -872,6 +649,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   const u32 nwords = (L + 15) >> 4;
   const u32 spec_len = min(L - ix.window, L >> 1);
   const u32 n_off = SPECIFIC ? max(ix.window, L >> 1) : L - kKeyWeight + 1;
+  // the tables answer for offsets whose seed can be extended by all their letters inside the read (L - i >= depth for
+  // every offset of the pass) and for the max_candidates they were built with; otherwise the loops start at the counters
+  const bool use_ext = SPECIFIC && ix.ext2 != nullptr && ix.ext_maxc == maxc &&
+                       L - n_off + 1 >= max(kKeyWeight + ix.e2, kKeyWeight3 + ix.e3);
 
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
   if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
@@ -901,22 +682,37 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       // (likewise keeping the specific pass's distances, one byte per candidate, so that the sensitive pass fetches no
       // window for a bucket entry it has seen: 290 of 2,850 candidates per read found there, -7 % lines, and 2.3 KB more LDS
       // per wave cost 15 % of the time -- profiles/r02_exp_distance_memo.log)
-      lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
-      lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
       if (SPECIFIC) {
         u32 probes = 0;
-        u32 len2, len3;
-        if constexpr (ABM_NARROW_TOGETHER)
-          narrow_both<COOP && ABM_NARROW_PLANES>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, lo2, hi2, len2, lo3, hi3, len3, probes);
-        else {
-          len2 = narrow2<COOP>(ix, ix.index, qb, 64u * lds.WB, i, L - i, maxc, lo2, hi2, probes);
-          len3 = narrow3<COOP>(ix, idx3, g_to_a, qpk, i, L - i, maxc, lo3, hi3, probes);
+        u32 len2 = kKeyWeight, len3 = kKeyWeight3;
+        bool run2 = true, run3 = true;
+        if (use_ext) {
+          // seed-extension tables (abm_ext.hip): one independent 8-byte load per table says where the narrowing
+          // loops stand after the next e2 / e3 letters -- for most offsets, finished
+          const u32 D2 = kKeyWeight + ix.e2;
+          const u32 K2 = __brev(static_cast<u32>(bits) & (D2 >= 32 ? 0xFFFFFFFFu : (1u << D2) - 1u)) >> (32 - D2);
+          const u64 more = q_window16(qpk, lds.W, i + 16, L);
+          u32 K3 = k3;
+          for (u32 j = 0; j < ix.e3; ++j) K3 = K3 * 3u + trit(static_cast<u32>(more >> (j << 2)) & 15u, g_to_a);
+          const uint2 x2 = ix.ext2[K2], x3 = (g_to_a ? ix.ext3a : ix.ext3t)[K3];
+          const u32 st2 = x2.y >> 30, st3 = x3.y >> 30;
+          lo2 = x2.x; hi2 = x2.x + (x2.y & 0x7FFFFFFu); len2 = kKeyWeight + ((x2.y >> 27) & 7u); run2 = st2 != 0;
+          lo3 = x3.x; hi3 = x3.x + (x3.y & 0x7FFFFFFu); len3 = kKeyWeight3 + ((x3.y >> 27) & 7u); run3 = st3 != 0;
+          if (st2 == 2) { lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1]; len2 = kKeyWeight; }  // (not tabulated)
+          if (st3 == 2) { lo3 = cnt3[k3]; hi3 = cnt3[k3 + 1]; len3 = kKeyWeight3; }
         }
+        else {
+          lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
+          lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
+        }
+        narrow_both(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, run2, lo2, hi2, len2, run3, lo3, hi3, len3, probes);
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
         chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;
         wt.probes += probes;
       }
       else {
+        lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
+        lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
         const u32 d2 = hi2 - lo2, d3 = hi3 - lo3;
         chk2 = d2 != 0 && d2 <= maxc && (d3 == 0 || d2 <= 10u * d3);
         chk3 = d3 != 0 && d3 <= maxc;
@@ -932,6 +728,12 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     sg.start_a = wave_excl_sum(sg.na + sg.nb, total);
     ABM_STAMP(tb_);
     if (TIMED) wt.t_probe += tb_ - ta;
+    if (total == 0) continue;
+    if (seg_epoch >= kSegEpochLimit) {  // (sixteen million steps on: start the mark tags over)
+      lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
+      seg_epoch = 0;
+    }
+    publish_segs(lds, sg);
 
     // ordered replay of one 64-candidate sub-chunk (check_hits + update, :1133-1149, :394-404)
     auto replay = [&](bool valid, int h, int hmax, u32 pos) {
@@ -961,237 +763,80 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       }
     };
 
-    int carry = 0;
-    // Candidates are taken 128 at a time, two per lane (c0+lane and c0+64+lane): both index entries,
+    // Candidates are taken 128 at a time, two per lane (a: c0+lane, b: c0+64+lane): both index entries,
     // then both genome windows, are in flight together, which halves the dependent round trips of a
     // read with very many candidates.  The set still sees them strictly in the reference's order.
     // The index entries of the NEXT 128 candidates are requested before this step's windows, so a
     // step costs one dependent memory round trip instead of two (what a read with millions of
     // candidates -- one wave, no other latency hiding at the end of a launch -- is made of).
+    // A step with at most 64 candidates (most steps of an ordinary read) does nothing for its b half.
+    u32 carry = 0;
     bool nva = false, nvb = false;
-    int noa = 0, nob = 0;
-    u32 nea = 0, neb = 0;
+    u32 nsa = 0, nsb = 0, nea = 0, neb = 0;
     auto fetch_entries = [&](u32 c0) {
-      bool ta3, tb3 = false;
-      u32 ea_at, eb_at = 0;
-      nvb = false; nob = 0; nea = 0; neb = 0;
-      locate(lds, sg, c0, total, carry, nva, noa, ea_at, ta3);
-      if (c0 + 64 < total) locate(lds, sg, c0 + 64, total, carry, nvb, nob, eb_at, tb3);
-      if (nva) nea = ta3 ? idx3[ea_at] : ix.index[ea_at];
-      if (nvb) neb = tb3 ? idx3[eb_at] : ix.index[eb_at];
+      u32 ea_at, eb_at;
+      locate128(lds, seg_epoch, sg, c0, total, carry, nva, nvb, nsa, nsb, ea_at, eb_at);
+      nea = 0; neb = 0;
+      if (nva) nea = (nsa & 1u) ? idx3[ea_at] : ix.index[ea_at];
+      if (nvb) neb = (nsb & 1u) ? idx3[eb_at] : ix.index[eb_at];
     };
-    // A block with very many candidates while a wave of this workgroup is idle becomes a series of jobs (at
-    // most the result buffer's capacity each) whose chunks helpers claim from the back (HelpWave); otherwise
-    // -- always, in a one-wave workgroup -- the loop below is the plain sequential one.
-    // (whether a job is shared is decided job by job: a block of a heavy read lasts for many jobs, and waves
-    // retire while it runs)
-    bool may_share = false;
-    if constexpr (HELP) may_share = hw != nullptr && total >= kHelpMin;
-    const u32 per_job = may_share ? hw->h.cap : total;
-    u32 primed_for = 0xFFFFFFFFu;  // candidate index the prefetched index entries belong to
-    if (total && !may_share) { fetch_entries(0); primed_for = 0; }
-    for (u32 c_base = 0; c_base < total && !S.sure_ambig; c_base += per_job) {
-      const u32 n_chunks = (min(per_job, total - c_base) + kHelpChunk - 1) / kHelpChunk;
-      bool computing = true;  // false once the helpers own the rest of this job's chunks
-      bool shared = false;
-      if constexpr (HELP) if (may_share) {
-        shared = hw->wanted();
-        if (shared) {
-          // open the job: segment table to this wave's slot, then the claim word (release order)
-          u32 *sv = hw->seg(hw->slot) + lane;
-          sv[0] = sg.start_a; sv[64] = sg.na; sv[128] = sg.lo2; sv[192] = sg.nb; sv[256] = sg.lo3;
-          if (lane == 0) {
-            hw->info_w[0] = enc | (g_to_a ? 256u : 0u); hw->info_w[1] = g0; hw->info_w[2] = total; hw->info_w[3] = c_base; hw->info_w[4] = L;
-            ABM_WG_STORE(hw->done_w, 0u);
-          }
-          ++hw->epoch;
-          ++hw->st_jobs;
-          hw->st_chunks += n_chunks;
-          wg_release();
-          if (lane == 0) {
-            ABM_WG_STORE(hw->epoch_w, hw->epoch);
-            ABM_WG_STORE(hw->span, n_chunks << 16);
-          }
+    fetch_entries(0);
+    for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
+      ABM_STAMP(tc);
+      if (TIMED) { ++wt.steps; if (total - c0 <= 64) ++wt.light_steps; }
+      const bool two = c0 + 64 < total;  // (uniform: this step has a b half)
+      const bool va = nva, vb = nvb;
+      const u32 pa = nea - (g0 + (nsa >> 1)), pb = neb - (g0 + (nsb >> 1));
+      if (c0 + 128 < total) fetch_entries(c0 + 128);
+      // the same genome position is proposed again and again (neighbouring seeds of one hit, the
+      // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
+      // saves the 1-2 HBM lines of a window.  Distances are a pure function of (pos, encoding),
+      // so a cache hit is exact by construction.  (Without it: 7 % more windows fetched, 18 instead of 25 spilled
+      // VGPRs, 10 M reads 1.1 % faster and 1 M reads 2.4 % slower -- profiles/r02_exp_position_cache.log; kept.)
+      u64 *slot_a = lds.pcache + ((pa * 2654435761u) >> (32 - kPosCacheBits));
+      u64 *slot_b = lds.pcache + ((pb * 2654435761u) >> (32 - kPosCacheBits));
+      const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
+      const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
+      int ha, hma, hb = 0x7fff, hmb = 0x7fff;
+      if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
+        // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
+        const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
+        const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
+        if (lds.G == 2)
+          hamming_planes_pairs(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+        else
+          hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
+        if (__any((na | nb) & 1u)) {  // rare: redone on the nibble array, where an N is an N
+          if (na & 1u) ha = hamming(ix.genome, qpk, nwords, pa);
+          if (nb & 1u) hb = hamming(ix.genome, qpk, nwords, pb);
         }
-        if (primed_for != c_base) { carry = seg_before(sg, c_base); fetch_entries(c_base); primed_for = c_base; }
+        hma = ha; hmb = hb;
       }
-      for (u32 k = 0; k < n_chunks && !S.sure_ambig; ++k) {
-        const u32 c0 = c_base + k * kHelpChunk;
-        ABM_STAMP(tc);
-        if (TIMED) ++wt.steps;
-        if constexpr (HELP) if (shared && computing) {  // take chunk k from the front, if the helpers have left it
-          u32 old = 0;
-          if (lane == 0) old = __hip_atomic_fetch_add(hw->span, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          old = static_cast<u32>(uni(static_cast<int>(old)));
-          computing = (old & 0xFFFFu) < (old >> 16);
-        }
-        int ha, hma, hb, hmb;
-        u32 pa, pb;
-        bool va, vb;
-        if (computing) {
-          va = nva; vb = nvb;
-          const int oa = noa, ob = nob;
-          const u32 ea = nea, eb = neb;
-          if (c0 + 128 < total) { fetch_entries(c0 + 128); primed_for = c0 + 128; }
-          pa = ea - (g0 + static_cast<u32>(oa));
-          pb = eb - (g0 + static_cast<u32>(ob));
-          // the same genome position is proposed again and again (neighbouring seeds of one hit, the
-          // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
-          // saves the 1-2 HBM lines of a window.  Distances are a pure function of (pos, encoding),
-          // so a cache hit is exact by construction.  (Without it: 7 % more windows fetched, 18 instead of 25 spilled
-          // VGPRs, 10 M reads 1.1 % faster and 1 M reads 2.4 % slower -- profiles/r02_exp_position_cache.log; kept.)
-          u64 *slot_a = lds.pcache + ((pa * 2654435761u) >> (32 - kPosCacheBits));
-          u64 *slot_b = lds.pcache + ((pb * 2654435761u) >> (32 - kPosCacheBits));
-          const u64 ca = va ? *slot_a : 0ull, cb = vb ? *slot_b : 0ull;
-          const bool hit_a = va && static_cast<u32>(ca) == pa, hit_b = vb && static_cast<u32>(cb) == pb;
-          if constexpr (COOP) {  // (distances are complete sums: no genome letter here makes a word's share negative)
-            // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
-            const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
-            const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-            if (lds.G == 2)
-              hamming_planes_pairs(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
-            else if constexpr (MODE == kMain && ABM_STAGE_WINDOWS)
-              hamming_planes_staged(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
-            else
-              hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
-            if (__any((na | nb) & 1u)) {  // rare: redone on the nibble array, where an N is an N
-              if (na & 1u) ha = hamming(ix.genome, qpk, nwords, pa);
-              if (nb & 1u) hb = hamming(ix.genome, qpk, nwords, pb);
-            }
-            hma = ha; hmb = hb;
-          }
-          else
-            hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
-          if (hit_a) { ha = static_cast<i16>(static_cast<u16>(ca >> 32)); hma = static_cast<i16>(static_cast<u16>(ca >> 48)); }
-          if (hit_b) { hb = static_cast<i16>(static_cast<u16>(cb >> 32)); hmb = static_cast<i16>(static_cast<u16>(cb >> 48)); }
-          if (va && !hit_a)
-            *slot_a = static_cast<u64>(pa) | (static_cast<u64>(static_cast<u16>(ha)) << 32) | (static_cast<u64>(static_cast<u16>(hma)) << 48);
-          if (vb && !hit_b)
-            *slot_b = static_cast<u64>(pb) | (static_cast<u64>(static_cast<u16>(hb)) << 32) | (static_cast<u64>(static_cast<u16>(hmb)) << 48);
-          if (!va) { ha = hma = 0x7fff; }
-          if (!vb) { hb = hmb = 0x7fff; }
-          wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
-          // 8-byte words fetched per window: the read's words on the nibble array; on the bit planes a group of four
-          // lanes fetches four 16-byte blocks, a group of eight the blocks its window has (at most L / 64 + 2)
-          const u32 fetched = COOP ? (lds.G == 2 ? 6u : (lds.G == 4 ? 8u : 2u * ((L + kPlaneBlock - 1) / kPlaneBlock + 1))) : nwords;
-          wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * fetched;
-          wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
-        }
-        else {
-          // a helper computed this chunk: wait for its flag, then take distance + position from the buffer
-          if constexpr (HELP) {
-            const u32 *fl = hw->flags(hw->slot) + k;
-            for (u32 spins = 0; static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(fl)))) != hw->epoch; ++spins) {
-              if (spins > kHelpSpinLimit) { hw->failed = true; break; }
-              __builtin_amdgcn_s_sleep(4);
-            }
-            wg_acquire();
-            const u32 dd = ABM_WG_LOAD(hw->res_d(hw->slot) + k * 64u + lane);
-            pa = ABM_WG_LOAD(hw->res_p(hw->slot) + k * 128u + lane);
-            pb = ABM_WG_LOAD(hw->res_p(hw->slot) + k * 128u + 64u + lane);
-            ha = hma = static_cast<int>(dd & 0xFFFFu);
-            hb = hmb = static_cast<int>(dd >> 16);
-            va = ha != 0x7fff; vb = hb != 0x7fff;
-#ifdef ABM_HELP_SELFCHECK  // test build: the owner recomputes every chunk it takes from the buffer
-            {
-              int xa, xb;
-              u32 ya, yb;
-              filter_chunk(ix, lds, lds.qmask + enc * lds.MB * 4, qpk, idx3, L, sg, g0, total, c0, xa, xb, ya, yb);
-              if (__any(xa != ha || xb != hb || (xa != 0x7fff && ya != pa) || (xb != 0x7fff && yb != pb))) hw->mismatch = true;
-            }
-#endif
-          }
-          else { va = vb = false; ha = hma = hb = hmb = 0x7fff; pa = pb = 0; }
-        }
-        ABM_STAMP(td);
-        if (TIMED) wt.t_stream += td - tc;
-        replay(va, ha, hma, pa);
-        if (!S.sure_ambig) replay(vb, hb, hmb, pb);
-        ABM_STAMP(tc);
-        if (TIMED) wt.t_replay += tc - td;
+      else
+        hamming2(ix.genome, qpk, nwords, pa, va && !hit_a, pb, vb && !hit_b, ha, hma, hb, hmb);
+      if (hit_a) { ha = static_cast<i16>(static_cast<u16>(ca >> 32)); hma = static_cast<i16>(static_cast<u16>(ca >> 48)); }
+      if (va && !hit_a)
+        *slot_a = static_cast<u64>(pa) | (static_cast<u64>(static_cast<u16>(ha)) << 32) | (static_cast<u64>(static_cast<u16>(hma)) << 48);
+      if (!va) { ha = hma = 0x7fff; }
+      if (two) {
+        if (hit_b) { hb = static_cast<i16>(static_cast<u16>(cb >> 32)); hmb = static_cast<i16>(static_cast<u16>(cb >> 48)); }
+        if (vb && !hit_b)
+          *slot_b = static_cast<u64>(pb) | (static_cast<u64>(static_cast<u16>(hb)) << 32) | (static_cast<u64>(static_cast<u16>(hmb)) << 48);
+        if (!vb) { hb = hmb = 0x7fff; }
       }
-      if constexpr (HELP) if (shared) {
-        // close the job: no more claims, then wait for the chunks helpers still have in hand (their stores
-        // must not land in the next job's buffer)
-        u32 old = 0;
-        if (lane == 0) old = __hip_atomic_exchange(hw->span, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = static_cast<u32>(uni(static_cast<int>(old)));
-        const u32 theirs = n_chunks - min(n_chunks, old >> 16);
-        hw->st_taken += theirs;
-        for (u32 spins = 0; static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(hw->done_w)))) < theirs; ++spins) {
-          if (spins > kHelpSpinLimit) { hw->failed = true; break; }
-          __builtin_amdgcn_s_sleep(4);
-        }
-      }
+      wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
+      // 8-byte words fetched per window: the read's words on the nibble array; on the bit planes a group of four
+      // lanes fetches four 16-byte blocks, a group of eight the blocks its window has (at most L / 64 + 2)
+      const u32 fetched = COOP ? (lds.G == 2 ? 6u : (lds.G == 4 ? 8u : 2u * ((L + kPlaneBlock - 1) / kPlaneBlock + 1))) : nwords;
+      wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * fetched;
+      wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
+      ABM_STAMP(td);
+      if (TIMED) wt.t_stream += td - tc;
+      replay(va, ha, hma, pa);
+      if (two && !S.sure_ambig) replay(vb, hb, hmb, pb);
+      ABM_STAMP(tc);
+      if (TIMED) wt.t_replay += tc - td;
     }
-  }
-}
-
-// A wave with no reads left stays and works for its block-mates until all of them are done: it scans
-// their claim words, takes a chunk from the back of an open job, and computes it against the owner's
-// read -- in place in the owner's LDS -- with more window loads in flight than the mapping loop affords.
-template <u32 NW>
-__device__ __forceinline__ void help_block_mates(const DevIndex &ix, const WaveLds &lds, BlockCtl<NW> *bc, unsigned char *wave_lds0,
-                                                 u32 per_wave_bytes, u32 my_wave, HelpWave &hw, WorkTally &wt) {
-  const int lane = lane_id();
-  if (lane == 0) __hip_atomic_fetch_add(&bc->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if (hw.h.seg == nullptr) return;
-  u32 cur_mate = 0xFFFFFFFFu, cur_epoch = 0;
-  Segs sg = {0, 0, 0, 0, 0};
-  u32 j_enc = 0, j_g0 = 0, j_total = 0, j_cbase = 0, j_L = 0;
-  bool j_g2a = false;
-  for (u32 spins = 0; spins < kHelpSpinLimit; ++spins) {
-    if (static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(&bc->retired)))) >= NW) break;
-    bool worked = false;
-    for (u32 m = 0; m < NW; ++m) {
-      if (m == my_wave) continue;
-      u32 got = 0xFFFFFFFFu;
-      if (lane == 0) {
-        u32 old = ABM_WG_LOAD(&bc->span[m]);
-        if ((old & 0xFFFFu) < (old >> 16) &&
-            __hip_atomic_compare_exchange_strong(&bc->span[m], &old, old - 0x10000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-          got = (old >> 16) - 1;
-      }
-      got = static_cast<u32>(uni(static_cast<int>(got)));
-      if (got == 0xFFFFFFFFu) continue;
-      wg_acquire();
-      const u32 e = static_cast<u32>(uni(static_cast<int>(ABM_WG_LOAD(&bc->epoch[m]))));
-      const u32 mate_slot = hw.slot - my_wave + m;
-      if (m != cur_mate || e != cur_epoch) {  // a job not seen yet: its header (LDS) and segment table (the mate's slot)
-        const u32 i0 = ABM_WG_LOAD(&bc->info[m][0]);
-        j_enc = i0 & 255u; j_g2a = (i0 & 256u) != 0;
-        j_g0 = ABM_WG_LOAD(&bc->info[m][1]); j_total = ABM_WG_LOAD(&bc->info[m][2]);
-        j_cbase = ABM_WG_LOAD(&bc->info[m][3]); j_L = ABM_WG_LOAD(&bc->info[m][4]);
-        const u32 *sv = hw.seg(mate_slot) + lane;
-        sg.start_a = ABM_WG_LOAD(sv);
-        sg.na = ABM_WG_LOAD(sv + 64);
-        sg.lo2 = ABM_WG_LOAD(sv + 128);
-        sg.nb = ABM_WG_LOAD(sv + 192);
-        sg.lo3 = ABM_WG_LOAD(sv + 256);
-        cur_mate = m; cur_epoch = e;
-      }
-      // the owner's read masks, where they lie: packed encodings, bit strings, then the masks open every wave's LDS region
-      const u64 *mate_qm = reinterpret_cast<const u64 *>(wave_lds0 + static_cast<size_t>(m) * per_wave_bytes) + 4 * lds.W + 4 * lds.WB +
-                           j_enc * lds.MB * 4;
-      int ha, hb;
-      u32 pa, pb;
-      const u64 *mate_qpk = reinterpret_cast<const u64 *>(wave_lds0 + static_cast<size_t>(m) * per_wave_bytes) + j_enc * lds.W;
-      filter_chunk(ix, lds, mate_qm, mate_qpk, j_g2a ? ix.index_a : ix.index_t, j_L, sg, j_g0, j_total,
-                   j_cbase + got * kHelpChunk, ha, hb, pa, pb);
-      ABM_WG_STORE(hw.res_d(mate_slot) + got * 64u + lane, (static_cast<u32>(ha) & 0xFFFFu) | (static_cast<u32>(hb) << 16));
-      ABM_WG_STORE(hw.res_p(mate_slot) + got * 128u + lane, pa);
-      ABM_WG_STORE(hw.res_p(mate_slot) + got * 128u + 64u + lane, pb);
-      wg_release();
-      if (lane == 0) ABM_WG_STORE(hw.flags(mate_slot) + got, e);
-      wg_release();
-      if (lane == 0) __hip_atomic_fetch_add(&bc->done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      wt.cands += (ha != 0x7fff ? 1u : 0u) + (hb != 0x7fff ? 1u : 0u);
-      wt.words += ((ha != 0x7fff ? 1u : 0u) + (hb != 0x7fff ? 1u : 0u)) * ((j_L + 15) >> 4);
-      ++hw.st_helped;
-      worked = true;
-      spins = 0;
-    }
-    if (!worked) __builtin_amdgcn_s_sleep(32);
   }
 }
 
@@ -1555,7 +1200,7 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
 // align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
 __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
                                           SeSet &S, Hit &best, u32 *cig_out, const CigarSink &sink,
-                                          u32 &n_ops, bool &overflow, u32 &n_aln) {
+                                          u32 &n_ops, bool &overflow, u32 &n_aln, u32 &n_single) {
   const int lane = lane_id();
   const int Ls = static_cast<i16>(L);
   const int md = static_cast<i16>(frac * static_cast<u32>(Ls));  // valid_diffs_cutoff
@@ -1598,7 +1243,17 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   int top = 0;
   u32 top_pos = 0, b_pos = 0, b_flags = 0;
   int b_diffs = 0x7fff;
-  for (int s = 0; s < n_jobs;) {
+  // A set with ONE alignable entry (most reads that map uniquely with a mismatch or two): the reference scores it
+  // (align<false>) and then aligns it again with traceback (align<true>) -- the same table twice, so the traceback
+  // run's score is the scoring run's, and the scoring run is skipped.
+  const bool single = n_jobs == 1;
+  if (single) {
+    const u32 df = lds.jdf[0];
+    b_diffs = static_cast<int>(df) >> 16; b_flags = df & 0xFFFFu; b_pos = lds.jpos[0];
+    ++n_aln;
+    ++n_single;
+  }
+  for (int s = 0; s < n_jobs && !single;) {
     const int first = s;
     s = score_round(ix, lds, first, n_jobs, static_cast<int>(L), md, 0);
     // apply the reference's selection in job order
@@ -1644,6 +1299,10 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   const int bc = static_cast<int>(0xFFu - static_cast<u32>(topk & 0xFFu));
   const int sc = static_cast<i16>(static_cast<int>(topk >> 32));
   wave_sync();
+  if (single) {  // what the scoring run would have found
+    top = sc;
+    if (sc <= 0) { best.flags = static_cast<u16>(kFlagAmbig); return; }  // (a zero score ties with "nothing yet" at position 0)
+  }
   u32 alen = 0, pos = b_pos;
   int n_ins = 0, n_del = 0;
   wave_cigar(lds.tb, lds.ctmp, static_cast<int>(L), b_diffs, md, sc, br, bc, cig_out, sink, n_ops,

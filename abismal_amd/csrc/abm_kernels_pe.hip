@@ -54,6 +54,7 @@ template <bool BIG, bool COOP> struct PeWave {
   PeLds pl;
   WorkTally wt;
   u32 n_aln;
+  u32 seg_epoch;    // tags the seed passes' segment marks (locate128)
   bool overflow, need_big;
   u32 L[2];
   SeSet se[2];
@@ -91,10 +92,10 @@ template <bool BIG, bool COOP> struct PeWave {
     P.begin_read(L[end]);
     if (L[end] >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+      seed_pass<true, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt, seg_epoch);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, COOP, kPlain>(a.ix, w, enc, g_to_a, flags, L[end], P, wt);
+        seed_pass<false, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt, seg_epoch);
       }
     }
     need_big |= P.overflow;
@@ -568,7 +569,6 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   lds.qbits = lds.qpk + 8 * a.W;
   lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
   lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
-  lds.stage = nullptr;  // (LDS-DMA staging of window blocks: single-end kernel only)
   lds.gwin = lds.qmask + 8 * lds.MB * 4;
   lds.pcache = lds.gwin + kMaxJobs * a.GW;
   // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
@@ -596,9 +596,13 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     w.pl.ld[0] = h; w.pl.ld[1] = h + a.cap; w.pl.lsc[0] = h + 2 * a.cap; w.pl.lsc[1] = h + 3 * a.cap;
     after_heap = reinterpret_cast<u32 *>(h + 4 * a.cap);
   }
-  lds.mark = reinterpret_cast<u16 *>(after_heap);
+  lds.smark = after_heap;
+  lds.sdelta = after_heap + 128;
+  lds.mark = reinterpret_cast<u16 *>(after_heap + 256);
   lds.hres = reinterpret_cast<u16 *>(lds.lbest);
   lds.G = a.G;
+  lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
+  w.seg_epoch = 0;
 
   w.P.heap = w.pl.heap;
   w.log_base = BIG ? a.log_ws + static_cast<u64>(blockIdx.x) * (32ull + 12ull * a.cap) : nullptr;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   static_assert(kPeTier1Cap * 4 <= (8u << kPosCacheBits), "tier-1 scratch table must fit the window cache");
   w.pl.tmp = BIG ? a.payload_ws + static_cast<u64>(blockIdx.x) * a.cap : reinterpret_cast<u32 *>(lds.pcache);
   w.P.cap_avail = a.cap;
-  w.wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  w.wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   w.n_aln = 0;
   w.overflow = false;
   w.t_sort = w.t_score = w.t_mate = w.t_single = 0;
@@ -703,8 +707,9 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
         const WaveLds we = w.lds_of(e);
         u32 nops = 0;
         Hit &h = e ? h2 : h1;
+        u32 n_single = 0;
         choose_se(a.ix, we, w.L[e], a.valid_frac / 2, w.se[e], h, w.cig_of(e, r), w.sink(), nops,
-                  w.overflow, w.n_aln);
+                  w.overflow, w.n_aln, n_single);
         if (nops != 0) w.n_ops[e] = nops;  // whatever traceback ran last owns the slot (A.10)
       }
       ABM_STAMP(tf1);
@@ -796,7 +801,7 @@ size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double v
   const u32 MB = (max_len + kPlaneBlock - 1) / kPlaneBlock;
   size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + static_cast<size_t>(8) * MB * 4 * 8 +
              (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
-             static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + 64 * 2;
+             static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + 2 * 128 * 4 + 64 * 2;
   if (!big) b += static_cast<size_t>(cap) * (4 + 2 * 4 + 4 * 2);
   b += tb_extra_bytes(GW, max_len, valid_frac);
   return (b + 15) & ~static_cast<size_t>(15);

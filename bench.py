@@ -951,7 +951,6 @@ def main():
         "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                     "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])},
         "work_per_read": {k: round(v / n, 2) for k, v in per_launch.items()},
-        "tail_help_per_launch": {k: round(v / max(1, launches), 1) for k, v in work["help"].items()} if "help" in work else None,
         "phase_shares_diagnostic": phases,
         "kernel_status": st_host,
         "filter_genome": filter_genome,

@@ -70,6 +70,18 @@ int abm_index_build_opts(const char *fasta_path, const char *targets_path, uint3
                          uint32_t n_threads);
 uint32_t abm_index_window(const abm_index *ix);
 
+/* Seed-extension tables (no reference counterpart; results are unaffected).  The first context on a device also
+ * derives, in HBM, three tables that answer the first steps of the bucket-narrowing loops of find_candidates /
+ * find_candidates_three (src/abismal.cpp:1163-1259) with one load per seed offset: one entry per key of the hashed
+ * letters plus letters2 more (2-letter table, at most 7) / letters3 more (3-letter tables, at most 4).  By default
+ * the letters are chosen from the index's size (none for small genomes; 7 and 4 = 90 GB at hg38 scale, fewer if that
+ * exceeds half of the free device memory); this call fixes them (0, 0 = no tables) and must precede the first
+ * abm_ctx_create on the index.  The tables are built for the index's max_candidates; a call with another value
+ * rebuilds them when its context is the only one on the device and otherwise runs without them. */
+int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3);
+/* what the context's device holds: letters per table (0 = no tables) and their bytes */
+int abm_ctx_seed_extension(const abm_ctx *ctx, uint32_t *letters2, uint32_t *letters3, uint64_t *bytes);
+
 /* A context = one host thread's workspaces and stream on `device` (hipSetDevice
  * ordinal).  The first context on a device replicates the index into its HBM;
  * later ones share that replica (freed with the last of them).  Calls on one
@@ -146,9 +158,7 @@ int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint
 enum {
   ABM_STATUS_CIGAR_OVERFLOW = 1u, /* the arena for CIGARs longer than a slot ran out */
   ABM_STATUS_READ_TOO_LONG = 2u,  /* a read exceeded the kernel's length cap */
-  ABM_STATUS_SET_OVERFLOW = 4u,   /* PE candidate set outgrew its workspace */
-  ABM_STATUS_HELP_TIMEOUT = 8u,   /* a wave waited too long for chunks handed to idle waves (results invalid) */
-  ABM_STATUS_HELP_MISMATCH = 16u  /* self-check build only: a handed-off result differed from the owner's own */
+  ABM_STATUS_SET_OVERFLOW = 4u    /* PE candidate set outgrew its workspace */
 };
 uint32_t abm_max_read_length(void); /* longest read the kernels map (the reference: below 32767 bases) */
 /* Reads (pairs) longer than that handed to this context's host entry points so far: they come back without a hit,

@@ -1,0 +1,111 @@
+// GPU test program (built and run by tests/test_gpu_se_set.py): the wave-wide DPP scans of abm_device.hpp
+// (wave_incl_sum / wave_excl_sum / wave_incl_max) and the seed passes' segment location (locate128) against
+// serial host code, on random inputs.  Prints "OK <cases>" or the first mismatch.
+#include "../../abismal_amd/csrc/abm_kernels.hip"
+#include <cstdio>
+#include <vector>
+using namespace abm;
+
+__global__ __launch_bounds__(64) void scans(const u32 *in, u32 *sum_out, u32 *max_out, u32 *tot_out) {
+  const u32 x = in[blockIdx.x * 64 + threadIdx.x];
+  u32 total;
+  sum_out[blockIdx.x * 64 + threadIdx.x] = wave_excl_sum(x, total);
+  max_out[blockIdx.x * 64 + threadIdx.x] = wave_incl_max(x);
+  if (threadIdx.x == 0) tot_out[blockIdx.x] = total;
+}
+
+// one flattened block per workgroup: na / nb per lane; every candidate's (segment, entry index) through locate128
+__global__ __launch_bounds__(64) void locate(const u32 *na, const u32 *nb, const u32 *lo2, const u32 *lo3, u32 *seg_out,
+                                             u32 *entry_out, u32 cap, u32 rounds) {
+  __shared__ u32 smark[128], sdelta[128];
+  WaveLds lds{};
+  lds.smark = smark; lds.sdelta = sdelta;
+  const int lane = threadIdx.x;
+  smark[lane] = 0; smark[64 + lane] = 0;
+  u32 epoch = 0;
+  for (u32 rep = 0; rep < rounds; ++rep) {  // (repeated: stale marks of earlier calls must lose)
+    const u32 b = (blockIdx.x * rounds + rep);
+    Segs sg;
+    sg.na = na[b * 64 + lane]; sg.nb = nb[b * 64 + lane]; sg.lo2 = lo2[b * 64 + lane]; sg.lo3 = lo3[b * 64 + lane];
+    u32 total;
+    sg.start_a = wave_excl_sum(sg.na + sg.nb, total);
+    publish_segs(lds, sg);
+    u32 carry = 0;
+    for (u32 c0 = 0; c0 < total; c0 += 128) {
+      bool va, vb;
+      u32 sa, sb, ea, eb;
+      locate128(lds, epoch, sg, c0, total, carry, va, vb, sa, sb, ea, eb);
+      if (va && c0 + lane < cap) { seg_out[b * cap + c0 + lane] = sa; entry_out[b * cap + c0 + lane] = ea; }
+      if (vb && c0 + 64 + lane < cap) { seg_out[b * cap + c0 + 64 + lane] = sb; entry_out[b * cap + c0 + 64 + lane] = eb; }
+    }
+  }
+}
+
+static u32 rnd(u32 &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+
+int main() {
+  const int B = 512;
+  std::vector<u32> in(B * 64), es(B * 64), em(B * 64), et(B);
+  u32 seed = 12345;
+  for (int b = 0; b < B; ++b) {
+    u32 run = 0, mx = 0;
+    for (int l = 0; l < 64; ++l) {
+      const u32 r = rnd(seed);
+      const u32 v = (b % 4 == 0) ? (r % 3 == 0 ? r >> 8 : 0) : (b % 4 == 1 ? r % 5 : (b % 4 == 2 ? r : (l == (b % 64) ? 7u : 0u)));
+      in[b * 64 + l] = v;
+      es[b * 64 + l] = run; run += v;
+      mx = v > mx ? v : mx; em[b * 64 + l] = mx;
+    }
+    et[b] = run;
+  }
+  u32 *d_in, *d_s, *d_m, *d_t;
+  hipMalloc(&d_in, in.size() * 4); hipMalloc(&d_s, in.size() * 4); hipMalloc(&d_m, in.size() * 4); hipMalloc(&d_t, B * 4);
+  hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(scans, dim3(B), dim3(64), 0, 0, d_in, d_s, d_m, d_t);
+  std::vector<u32> gs(B * 64), gm(B * 64), gt(B);
+  hipMemcpy(gs.data(), d_s, gs.size() * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(gm.data(), d_m, gm.size() * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(gt.data(), d_t, gt.size() * 4, hipMemcpyDeviceToHost);
+  for (int k = 0; k < B * 64; ++k)
+    if (gs[k] != es[k] || gm[k] != em[k]) { std::printf("scan mismatch block %d lane %d: sum %u/%u max %u/%u\n", k / 64, k % 64, gs[k], es[k], gm[k], em[k]); return 1; }
+  for (int b = 0; b < B; ++b) if (gt[b] != et[b]) { std::printf("total mismatch block %d\n", b); return 1; }
+
+  // locate128
+  const u32 rounds = 8, NB = 64 * rounds, cap = 8192;
+  std::vector<u32> na(NB * 64), nb(NB * 64), l2(NB * 64), l3(NB * 64), eseg(static_cast<size_t>(NB) * cap, 0xFFFFFFFFu), eent(static_cast<size_t>(NB) * cap, 0xFFFFFFFFu);
+  for (u32 b = 0; b < NB; ++b) {
+    u32 c = 0;
+    for (int l = 0; l < 64; ++l) {
+      const u32 r = rnd(seed), shape = b % 5;
+      u32 a = 0, bb = 0;
+      if (shape == 0) { a = r % 4 == 0 ? (r >> 8) % 101 : 0; bb = (r >> 4) % 7 == 0 ? (r >> 16) % 101 : 0; }
+      else if (shape == 1) { a = (r >> 3) % 101; bb = (r >> 12) % 101; }
+      else if (shape == 2) { a = l == 5 ? 100 : 0; bb = l == 60 ? 3 : 0; }
+      else if (shape == 3) { a = (r & 1); bb = (r >> 1) & 1; }
+      else { a = l < 3 ? 1 : 0; bb = 0; }
+      if (c + a + bb > cap) { a = 0; bb = 0; }
+      na[b * 64 + l] = a; nb[b * 64 + l] = bb;
+      l2[b * 64 + l] = rnd(seed) >> 4; l3[b * 64 + l] = rnd(seed) >> 4;
+      for (u32 k = 0; k < a; ++k) { eseg[static_cast<size_t>(b) * cap + c] = 2 * l; eent[static_cast<size_t>(b) * cap + c] = l2[b * 64 + l] + k; ++c; }
+      for (u32 k = 0; k < bb; ++k) { eseg[static_cast<size_t>(b) * cap + c] = 2 * l + 1; eent[static_cast<size_t>(b) * cap + c] = l3[b * 64 + l] + k; ++c; }
+    }
+  }
+  u32 *d_na, *d_nb, *d_l2, *d_l3, *d_seg, *d_ent;
+  hipMalloc(&d_na, na.size() * 4); hipMalloc(&d_nb, na.size() * 4); hipMalloc(&d_l2, na.size() * 4); hipMalloc(&d_l3, na.size() * 4);
+  hipMalloc(&d_seg, eseg.size() * 4); hipMalloc(&d_ent, eseg.size() * 4);
+  hipMemcpy(d_na, na.data(), na.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_nb, nb.data(), na.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_l2, l2.data(), na.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_l3, l3.data(), na.size() * 4, hipMemcpyHostToDevice);
+  hipMemset(d_seg, 0xFF, eseg.size() * 4); hipMemset(d_ent, 0xFF, eseg.size() * 4);
+  hipLaunchKernelGGL(locate, dim3(NB / rounds), dim3(64), 0, 0, d_na, d_nb, d_l2, d_l3, d_seg, d_ent, cap, rounds);
+  std::vector<u32> gseg(eseg.size()), gent(eseg.size());
+  hipMemcpy(gseg.data(), d_seg, gseg.size() * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(gent.data(), d_ent, gent.size() * 4, hipMemcpyDeviceToHost);
+  if (hipDeviceSynchronize() != hipSuccess) { std::printf("kernel failed\n"); return 1; }
+  for (size_t k = 0; k < eseg.size(); ++k)
+    if (gseg[k] != eseg[k] || gent[k] != eent[k]) {
+      std::printf("locate mismatch block %zu candidate %zu: segment %u/%u entry %u/%u\n", k / cap, k % cap, gseg[k], eseg[k], gent[k], eent[k]);
+      return 1;
+    }
+  std::printf("OK %d scan blocks, %u flattened blocks\n", B, NB);
+  return 0;
+}

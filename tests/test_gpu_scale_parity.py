@@ -1,7 +1,6 @@
 """GPU vs oracle at scale, inside the test suite: a 400 Mbp hg38-shaped genome (the bench's generator:
 repeat families, satellites, microsatellites, N gaps), full comparison of hits AND CIGARs.
- * BASELINE config 2/4 shape: 200 k x 100 bp single-end T-rich (large enough that idle waves help
-   the heaviest reads: the tail-help path runs);
+ * BASELINE config 2/4 shape: 200 k x 100 bp single-end T-rich;
  * BASELINE config 5: 100 k x 150 bp single-end random-PBAT (-R: both conversions);
  * BASELINE config 3: 50 k pairs 2 x 150 bp."""
 import os
@@ -72,16 +71,3 @@ def test_scale_pe_150(oracle, big):
     orc = oracle.map_pe(big["oix"], r1, r2, mode=0, threads=os.cpu_count() or 8)
     compare_pe(gpu, orc, "scale PE 2x150")
     assert (gpu[0]["r1"]["pos"] != 0).mean() > 0.8
-
-
-def test_scale_se_with_in_block_help(oracle, big, monkeypatch):
-    """The optional in-block help of the single-end kernel (ABM_SE_HELP=1: four waves per workgroup, idle waves
-    compute filter chunks of their block-mates' heavy reads) must not change a single result."""
-    from tests.test_gpu_se_parity import compare_se
-    n, L = 150_000, 100
-    reads = host_reads(big["bench"].sample_reads(big["gw"], big["starts"], n, L, 1234, big["dev"])[0], L)
-    o_res, o_cig, o_n, _ = oracle.map_se(big["oix"], reads, mode=0, threads=os.cpu_count() or 8)
-    monkeypatch.setenv("ABM_SE_HELP", "1")
-    res, cig, off = big["ctx"].map_se(reads, mode=0)
-    lib = __import__("abismal_amd").load_library()
-    compare_se(res, cig, off, o_res, o_cig, o_n, reads, "scale SE with in-block help")

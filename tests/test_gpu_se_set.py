@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog", ["se_set_check", "pe_set_check"])
+@pytest.mark.parametrize("prog", ["se_set_check", "pe_set_check", "wave_prims_check"])
 def test_candidate_set_equals_libstdcxx_heap(tmp_path, prog):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = tmp_path / prog

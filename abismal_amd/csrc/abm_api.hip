@@ -99,6 +99,7 @@ struct DeviceReplica {
   int refs = 0;
   void *ext_mem[3] = {nullptr, nullptr, nullptr};  // seed-extension tables (abm_ext.hip), built for dix.ext_maxc candidates
   double ext_build_s = 0;
+  std::mutex mu;  // guards arena / refs / tables: the replicas of different devices are set up side by side
   // The single-end host-buffer entry points of the contexts on one device take turns for the mapping
   // kernel (their transfers overlap freely): the kernels are bound by random line fetches, and two of them
   // resident together only evict each other's lines (see kSeWavesPerCu).
@@ -108,8 +109,9 @@ struct DeviceReplica {
 struct abm_index {
   abm::HostIndex h;
   int want_e2 = -1, want_e3 = -1;  // letters of the seed-extension tables; -1 = chosen from the index's size
-  mutable std::mutex mu;
-  mutable std::map<int, DeviceReplica> replicas;  // by device ordinal
+  mutable std::mutex mu;  // guards the map itself and the wishes below (a replica's contents: DeviceReplica::mu)
+  mutable std::map<int, DeviceReplica> replicas;  // by device ordinal; nodes stay for the index's lifetime
+  uint32_t want_maxc = 0;  // max_candidates the tables are built for; 0 = the index file's
 };
 
 struct abm_ctx {
@@ -533,8 +535,8 @@ namespace {
 abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
   abm::DevIndex d = ctx->dix;
   d.max_candidates = maxc;
-  std::lock_guard<std::mutex> lk(ctx->ix->mu);
   DeviceReplica &rep = *ctx->rep;
+  std::lock_guard<std::mutex> lk(rep.mu);
   if (rep.dix.ext_maxc != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
     HIPCHK(hipDeviceSynchronize());
     build_ext(rep, *ctx->ix, maxc);
@@ -561,6 +563,10 @@ void abm_default_params(abm_params *p) {
   p->allow_ambig = 0;
 }
 
+int abm_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx) { return ctx ? ctx->too_long : 0; }
 int abm_ctx_filter_on_planes(const abm_ctx *ctx) { return ctx && ctx->dix.planes[0] != nullptr ? 1 : 0; }
@@ -598,16 +604,24 @@ int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3) {
     if (!ix) throw std::invalid_argument("index is null");
     if (letters2 > 7 || letters3 > 4) throw std::invalid_argument("at most 7 and 4 letters");
     std::lock_guard<std::mutex> lk(ix->mu);
-    if (!ix->replicas.empty()) throw std::invalid_argument("set the seed extension before the first context is created");
+    for (auto &r : ix->replicas) if (r.second.refs) throw std::invalid_argument("set the seed extension before the first context is created");
     ix->want_e2 = letters2;
     ix->want_e3 = letters3;
+  });
+}
+
+int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates) {
+  return guarded([&] {
+    if (!ix) throw std::invalid_argument("index is null");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->want_maxc = max_candidates;
   });
 }
 
 int abm_ctx_seed_extension(const abm_ctx *ctx, uint32_t *letters2, uint32_t *letters3, uint64_t *bytes) {
   return guarded([&] {
     if (!ctx) throw std::invalid_argument("ctx is null");
-    std::lock_guard<std::mutex> lk(ctx->ix->mu);
+    std::lock_guard<std::mutex> lk(ctx->rep->mu);
     const abm::DevIndex &d = ctx->rep->dix;
     const bool on = d.ext2 != nullptr;
     if (letters2) *letters2 = on ? d.e2 : 0;
@@ -644,8 +658,11 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
       c->device = device;
       c->ix = ix;
       {
-        std::lock_guard<std::mutex> lk(ix->mu);
-        DeviceReplica &rep = ix->replicas[device];
+        DeviceReplica *rep_p;
+        abm::u32 tables_maxc;
+        { std::lock_guard<std::mutex> lk(ix->mu); rep_p = &ix->replicas[device]; tables_maxc = ix->want_maxc ? ix->want_maxc : ix->h.max_candidates; }
+        DeviceReplica &rep = *rep_p;
+        std::lock_guard<std::mutex> lk(rep.mu);
         if (rep.refs == 0) {
           const abm::HostIndex &h = ix->h;
           // one arena, 256-byte aligned sub-arrays: genome first (u64), then the u32 tables
@@ -697,7 +714,7 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
           rep.arena = arena;
           rep.dix.ext2 = rep.dix.ext3t = rep.dix.ext3a = nullptr;
           rep.dix.e2 = rep.dix.e3 = rep.dix.ext_maxc = 0;
-          try { build_ext(rep, *ix, h.max_candidates); }
+          try { build_ext(rep, *ix, tables_maxc); }
           catch (...) { (void)hipFree(arena); rep.arena = nullptr; throw; }
         }
         ++rep.refs;
@@ -724,13 +741,12 @@ void abm_ctx_destroy(abm_ctx *c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->last_done) (void)hipEventDestroy(c->last_done);
   if (c->drained) (void)hipHostFree(c->drained);
-  if (c->holds_replica && c->ix) {
-    std::lock_guard<std::mutex> lk(c->ix->mu);
-    auto it = c->ix->replicas.find(c->device);
-    if (it != c->ix->replicas.end() && --it->second.refs == 0) {
-      free_ext(it->second);
-      (void)hipFree(it->second.arena);
-      c->ix->replicas.erase(it);
+  if (c->holds_replica && c->rep) {
+    std::lock_guard<std::mutex> lk(c->rep->mu);
+    if (--c->rep->refs == 0) {
+      free_ext(*c->rep);
+      (void)hipFree(c->rep->arena);
+      c->rep->arena = nullptr;
     }
   }
   c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
@@ -1083,38 +1099,52 @@ int abm_stats_allreduce(abm_ctx *const *ctxs, int n_ctx, uint64_t *const *counte
   return guarded([&] {
     if (!ctxs || !counters || n_ctx <= 0) throw std::invalid_argument("bad arguments");
     if (n_ctx == 1) return;  // a single GPU already holds the total
-    // one communicator per participating GPU of this process; the payload is 18 x u64
+    // One communicator, stream and 18 x u64 buffer per participating GPU of this process, created on the first call
+    // for a set of devices and kept for the process's lifetime (ncclCommInitAll costs hundreds of milliseconds; a
+    // service that maps run after run pays it once).
+    struct Group { std::vector<ncclComm_t> comms; std::vector<hipStream_t> streams; std::vector<unsigned long long *> bufs; };
+    static std::mutex gmu;
+    static std::map<std::vector<int>, Group> groups;
     std::vector<int> devs(n_ctx);
-    for (int k = 0; k < n_ctx; ++k) devs[k] = ctxs[k]->device;
-    std::vector<ncclComm_t> comms(n_ctx);
+    for (int k = 0; k < n_ctx; ++k) { if (!ctxs[k]) throw std::invalid_argument("null context"); devs[k] = ctxs[k]->device; }
     auto nccl_check = [](ncclResult_t r, const char *what) {
       if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
     };
-    nccl_check(ncclCommInitAll(comms.data(), n_ctx, devs.data()), "ncclCommInitAll");
-    std::vector<unsigned long long *> bufs(n_ctx, nullptr);
-    std::vector<hipStream_t> streams(n_ctx, nullptr);
-    try {
-      for (int k = 0; k < n_ctx; ++k) {
-        HIPCHK(hipSetDevice(devs[k]));
-        HIPCHK(hipStreamCreate(&streams[k]));
-        HIPCHK(hipMalloc(&bufs[k], 18 * sizeof(unsigned long long)));
-        HIPCHK(hipMemcpy(bufs[k], counters[k], 18 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lk(gmu);
+    auto it = groups.find(devs);
+    if (it == groups.end()) {
+      Group g;
+      g.comms.resize(n_ctx);
+      nccl_check(ncclCommInitAll(g.comms.data(), n_ctx, devs.data()), "ncclCommInitAll");
+      g.streams.assign(n_ctx, nullptr);
+      g.bufs.assign(n_ctx, nullptr);
+      try {
+        for (int k = 0; k < n_ctx; ++k) {
+          HIPCHK(hipSetDevice(devs[k]));
+          HIPCHK(hipStreamCreate(&g.streams[k]));
+          HIPCHK(hipMalloc(&g.bufs[k], 18 * sizeof(unsigned long long)));
+        }
       }
-      nccl_check(ncclGroupStart(), "ncclGroupStart");
-      for (int k = 0; k < n_ctx; ++k)
-        nccl_check(ncclAllReduce(bufs[k], bufs[k], 18, ncclUint64, ncclSum, comms[k], streams[k]), "ncclAllReduce");
-      nccl_check(ncclGroupEnd(), "ncclGroupEnd");
-      for (int k = 0; k < n_ctx; ++k) {
-        HIPCHK(hipSetDevice(devs[k]));
-        HIPCHK(hipStreamSynchronize(streams[k]));
-        HIPCHK(hipMemcpy(counters[k], bufs[k], 18 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      catch (...) {
+        for (int k = 0; k < n_ctx; ++k) { if (g.bufs[k]) (void)hipFree(g.bufs[k]); if (g.streams[k]) (void)hipStreamDestroy(g.streams[k]); ncclCommDestroy(g.comms[k]); }
+        throw;
       }
+      it = groups.emplace(devs, std::move(g)).first;
     }
-    catch (...) {
-      for (int k = 0; k < n_ctx; ++k) { if (bufs[k]) (void)hipFree(bufs[k]); if (streams[k]) (void)hipStreamDestroy(streams[k]); ncclCommDestroy(comms[k]); }
-      throw;
+    Group &g = it->second;
+    for (int k = 0; k < n_ctx; ++k) {
+      HIPCHK(hipSetDevice(devs[k]));
+      HIPCHK(hipMemcpyAsync(g.bufs[k], counters[k], 18 * sizeof(unsigned long long), hipMemcpyHostToDevice, g.streams[k]));
     }
-    for (int k = 0; k < n_ctx; ++k) { (void)hipSetDevice(devs[k]); (void)hipFree(bufs[k]); (void)hipStreamDestroy(streams[k]); ncclCommDestroy(comms[k]); }
+    nccl_check(ncclGroupStart(), "ncclGroupStart");
+    for (int k = 0; k < n_ctx; ++k)
+      nccl_check(ncclAllReduce(g.bufs[k], g.bufs[k], 18, ncclUint64, ncclSum, g.comms[k], g.streams[k]), "ncclAllReduce");
+    nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+    for (int k = 0; k < n_ctx; ++k) {
+      HIPCHK(hipSetDevice(devs[k]));
+      HIPCHK(hipMemcpyAsync(counters[k], g.bufs[k], 18 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.streams[k]));
+      HIPCHK(hipStreamSynchronize(g.streams[k]));
+    }
   });
 }
 

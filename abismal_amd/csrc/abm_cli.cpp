@@ -570,10 +570,13 @@ struct Options {
   std::string index, genome, out, stats, timing;
   bool bam = false, json = false, ambig = false, pbat = false, rpbat = false, arich = false, verbose = false;
   uint32_t max_candidates = 0, min_frag = 32, max_frag = 3000;
-  uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));  // host parse/format threads
+  uint32_t threads = 0;  // host parse/format threads (-t); 0 = chosen from the GPU count (see cmd_map)
   int gpus = 0;
   size_t batch = 0;  // reads (pairs) per batch; 0 = default for the input type
   int mappers = 0;  // mapper threads (contexts) per GPU; 0 = 2 for single-end, 3 for paired-end input
+  int ext2 = -1, ext3 = -1;  // -seed-ext a,b: letters of the seed-extension tables (default: chosen from the index's size)
+  bool host_ceiling = false;  // -host-ceiling (diagnostic): no mapping call; every read gets a made-up hit, so that cut ->
+                              // parse -> format -> write run at the rate the host can carry (single-end input)
   double max_distance = 0.1;
   std::vector<std::string> reads;
 };
@@ -604,6 +607,8 @@ Options parse_map(int argc, char **argv) {
     else if (k == "gpus") o.gpus = std::stoi(need(i));
     else if (k == "batch") o.batch = std::stoul(need(i));
     else if (k == "mappers") o.mappers = std::stoi(need(i));
+    else if (k == "host-ceiling") o.host_ceiling = true;
+    else if (k == "seed-ext") { const std::string v = need(i); if (std::sscanf(v.c_str(), "%d,%d", &o.ext2, &o.ext3) != 2) throw std::runtime_error("-seed-ext wants two numbers: a,b"); }
     else if (k == "timing") o.timing = need(i);  // JSON: reads, seconds (first batch submitted -> last byte written), stage busy times
     else if (k == "z" || k == "bam-level") g_bgzf_level = std::max(0, std::min(9, std::stoi(need(i))));
     else throw std::runtime_error("unknown option " + a);
@@ -656,17 +661,32 @@ int cmd_map(int argc, char **argv) {
   // thread's batch is in transit over PCIe
   int n_gpus = opt.gpus;
   const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 3 : 2);
+  if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
+  if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
   std::vector<abm_ctx *> ctxs;
-  for (int d = 0; n_gpus <= 0 || d < n_gpus; ++d) {
-    abm_ctx *c = nullptr;
-    if (abm_ctx_create(ix, d, &c) != 0) { if (n_gpus <= 0 && d > 0) break; die_abm("creating GPU context"); }
-    ctxs.push_back(c);
-    for (int k = 1; k < per_gpu; ++k) {
-      if (abm_ctx_create(ix, d, &c) != 0) die_abm("creating GPU context");
-      ctxs.push_back(c);
+  {
+    // the first context on a GPU uploads the index and derives its tables there: every GPU's at the same time
+    if (n_gpus <= 0) n_gpus = abm_device_count();  // all that are visible
+    if (n_gpus <= 0) { std::cerr << "creating GPU context: no HIP device present (the mapping path has no CPU fallback)\n"; return EXIT_FAILURE; }
+    std::vector<abm_ctx *> first(n_gpus, nullptr);
+    std::vector<std::thread> th;
+    std::mutex emu;
+    std::string err;
+    for (int d = 0; d < n_gpus; ++d)
+      if (!first[d]) th.emplace_back([&, d] {
+        if (abm_ctx_create(ix, d, &first[d]) != 0) { std::lock_guard<std::mutex> lk(emu); err = abm_last_error(); }
+      });
+    for (auto &t : th) t.join();
+    if (!err.empty()) { std::cerr << "creating GPU context: " << err << "\n"; return EXIT_FAILURE; }
+    for (int d = 0; d < n_gpus; ++d) {
+      ctxs.push_back(first[d]);
+      for (int k = 1; k < per_gpu; ++k) {
+        abm_ctx *c = nullptr;
+        if (abm_ctx_create(ix, d, &c) != 0) die_abm("creating GPU context");
+        ctxs.push_back(c);
+      }
     }
   }
-  n_gpus = static_cast<int>(ctxs.size()) / per_gpu;
   {
     // set-up, like the index upload: workspaces for full batches of reads as long as the input's first one, and the
     // kernels' code loaded, before the clock of the run starts (a longer read later only makes the buffers grow)
@@ -780,7 +800,10 @@ int cmd_map(int argc, char **argv) {
   // by its costliest reads (a quarter of a second, whatever the batch), so small batches waste the GPU;
   // cutting and parsing run far ahead of it, so a full batch is ready within a fraction of a kernel's time.
   const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
-  const unsigned n_host = std::max(1u, opt.threads);
+  // host threads: -t, else 64 for one GPU and 24 more per further GPU (what 10 M reads/s per GPU of cutting, parsing and
+  // formatting take on the measured busy times), never more than the box has
+  const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned n_host = opt.threads ? std::max(1u, opt.threads) : std::min(hw_threads, std::max(64u, 40u + 24u * static_cast<unsigned>(n_gpus)));
   const size_t max_reads_in_flight = (static_cast<size_t>(n_gpus) * per_gpu + 2) * batch_reads + 4 * slice_reads * n_host;
   std::deque<std::unique_ptr<Slice>> q_parse;               // cut, waiting for a parser
   std::map<uint64_t, std::unique_ptr<Slice>> parsed;        // parsed, waiting for a mapper (by slice number)
@@ -801,6 +824,7 @@ int cmd_map(int argc, char **argv) {
   int parsers_live = 0, mappers_live = 0;
   std::exception_ptr failure;
   std::vector<Stats3> gpu_stats(n_gpus);
+  std::vector<uint64_t> gpu_batches(n_gpus, 0), gpu_reads(n_gpus, 0);  // what each GPU was handed
   uint64_t total_records = 0;
   const auto t_start = std::chrono::steady_clock::now();
 
@@ -1093,6 +1117,8 @@ int cmd_map(int argc, char **argv) {
           }
           b->seq = n_batches++;
           b->gpu = g;
+          ++gpu_batches[g];
+          gpu_reads[g] += b->n;
           b->slices_left = static_cast<int>(b->slices.size());
           // Reads of 44-46 bases see what earlier reads left in the reference's reused buffers:
           // the mapper looks for that among the reads handed over in the same call, so a batch is led by the
@@ -1112,12 +1138,12 @@ int cmd_map(int argc, char **argv) {
                   next[e].emplace_back(sl.blob[e].data() + sl.off[e][k], len);
                   all_long &= len > 46;
                 }
-                closed = all_long || next[0].size() >= 256;
+                closed = all_long;  // (no cap on the records: a heavily trimmed library has long runs of short ones)
               }
             }
-            if (!closed && next[0].size() < 256)  // the whole batch had no such record: keep the older tail too
+            if (!closed)  // the whole batch had no such record: keep the older tail too
               for (int e = 0; e < (paired ? 2 : 1); ++e)
-                for (size_t k = carry[e].size(); k-- > 0 && next[e].size() < 256;) next[e].push_back(carry[e][k]);
+                for (size_t k = carry[e].size(); k-- > 0;) next[e].push_back(carry[e][k]);
             for (int e = 0; e < (paired ? 2 : 1); ++e) { std::reverse(next[e].begin(), next[e].end()); carry[e].swap(next[e]); }
           }
           live_batches.push_back(std::move(owned));
@@ -1185,7 +1211,30 @@ int cmd_map(int argc, char **argv) {
           uint64_t cap = std::min<uint64_t>(worst, 4 * n + 1024);
           for (;;) {
             int rc;
-            if (!paired) {
+            if (!paired && opt.host_ceiling) {
+              // diagnostic: what the pipeline around the mapper can carry.  Every read "maps" somewhere inside the first
+              // chromosome with one mismatch and a single-op CIGAR; nothing is sent to the GPU.
+              cap = std::max<uint64_t>(cap, n);
+              b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
+              const uint32_t c0 = ch.starts.size() > 2 ? ch.starts[1] : 0, c1 = ch.starts.size() > 2 ? ch.starts[2] : 0;
+              const uint32_t span = c1 > c0 + 70000 ? c1 - c0 - 66000 : 1;
+              std::vector<std::thread> fill;
+              for (unsigned t = 0; t < 8; ++t)
+                fill.emplace_back([&, t] {
+                  for (size_t i = n * t / 8; i < n * (t + 1) / 8; ++i) {
+                    const uint32_t len = static_cast<uint32_t>(off_p[0][i + 1] - off_p[0][i]);
+                    abm_hit h;
+                    h.diffs = 1; h.flags = (i & 1) ? 0x10 : 0; h.pos = len ? c0 + static_cast<uint32_t>((i * 7919u) % span) : 0;
+                    b->se[0][i] = h;
+                    b->cig[0][i] = len << 4;
+                    b->cig_off[0][i] = i;
+                  }
+                });
+              for (auto &t : fill) t.join();
+              b->cig_off[0][n] = n;
+              rc = 0;
+            }
+            else if (!paired) {
               b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
               rc = abm_map_se_batch(ctx, se_mode, &par, n, blob_p[0], off_p[0], b->se[0].data(),
                                     b->cig[0].data(), cap, b->cig_off[0].data());
@@ -1409,7 +1458,12 @@ int cmd_map(int argc, char **argv) {
     std::ofstream tj(opt.timing);
     tj << "{\"records\": " << total_records << ", \"reads\": " << (paired ? 2 : 1) * total_records << ", \"seconds\": " << secs
        << ", \"index_load_s\": " << index_load_s << ", \"gpus\": " << n_gpus << ", \"mappers_per_gpu\": " << per_gpu
-       << ", \"host_threads\": " << n_host << ", \"batch_reads\": " << batch_reads << ", \"busy_s\": {\"split\": " << busy_split
+       << ", \"host_threads\": " << n_host << ", \"batch_reads\": " << batch_reads << ", \"host_ceiling\": " << (opt.host_ceiling ? "true" : "false")
+       << ", \"batches_per_gpu\": [";
+    for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_batches[g];
+    tj << "], \"reads_per_gpu\": [";
+    for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_reads[g];
+    tj << "], \"busy_s\": {\"split\": " << busy_split
        << ", \"parse\": " << busy_parse << ", \"map\": " << busy_map << ", \"format\": " << busy_format << ", \"write\": "
        << busy_write << "}}\n";
   }
@@ -1419,6 +1473,9 @@ int cmd_map(int argc, char **argv) {
               << "[abismal-amd] busy seconds: split " << busy_split << ", parse " << busy_parse << " (" << n_host
               << " threads), map " << busy_map << " (" << n_gpus * per_gpu << " threads), format " << busy_format << " ("
               << n_host << " threads), write " << busy_write << "\n";
+  if (opt.verbose)
+    for (int g = 0; g < n_gpus; ++g)
+      std::cerr << "[abismal-amd] GPU " << g << ": " << gpu_batches[g] << " batches, " << gpu_reads[g] << (paired ? " pairs\n" : " reads\n");
   {
     uint64_t too_long = 0;
     for (abm_ctx *c : ctxs) too_long += abm_ctx_reads_too_long(c);

@@ -17,6 +17,8 @@
 // send the kernel down the bisection path from the bucket's counters.
 #include "abm_kernels.hpp"
 
+#include <algorithm>
+
 namespace abm {
 
 namespace {
@@ -96,14 +98,14 @@ __global__ __launch_bounds__(256) void ext_gaps_kernel(GapList gaps, u32 *__rest
 __global__ __launch_bounds__(256) void ext_entries_kernel(const u32 *__restrict__ bound, const u32 *__restrict__ counter,
                                                           const u32 *__restrict__ bad, u64 n_keys, u32 extra, int mode, u32 maxc,
                                                           uint2 *__restrict__ out) {
-  const u64 K = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (K >= n_keys) return;
   // span[s] = keys under one prefix that is s letters short of the full depth
   u64 span[8];
   span[0] = 1;
   for (u32 s = 1; s <= extra; ++s) span[s] = span[s - 1] * (mode == 0 ? 2u : 3u);
+  // (grid-stride: a launch cannot have 2^32 threads, which the deepest 2-letter table has keys)
+  for (u64 K = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; K < n_keys; K += static_cast<u64>(gridDim.x) * blockDim.x) {
   const u64 base = K / span[extra];
-  if ((bad[base >> 5] >> (base & 31u)) & 1u) { out[K] = make_uint2(0u, 2u << 30); return; }
+  if ((bad[base >> 5] >> (base & 31u)) & 1u) { out[K] = make_uint2(0u, 2u << 30); continue; }
   // boundaries that coincide with a base bucket's come from the index's own counter array
   auto bnd = [&](u64 x) -> u32 { return x % span[extra] == 0 ? counter[x / span[extra]] : bound[x]; };
   u32 p = 0;  // letters beyond the hashed ones
@@ -122,8 +124,9 @@ __global__ __launch_bounds__(256) void ext_entries_kernel(const u32 *__restrict_
   }
   else if (hi - lo > maxc) state = 1;  // (p == extra) still open
   const u32 size = hi - lo;
-  if (size >= (1u << 27)) { out[K] = make_uint2(0u, 2u << 30); return; }
+  if (size >= (1u << 27)) { out[K] = make_uint2(0u, 2u << 30); continue; }
   out[K] = make_uint2(lo, size | (len << 27) | (state << 30));
+  }
 }
 
 }  // namespace
@@ -168,7 +171,7 @@ hipError_t build_ext_table(const DevIndex &ix, int mode, u32 extra, u32 maxc, u6
   hipLaunchKernelGGL(ext_bounds_kernel, dim3(static_cast<u32>((threads + 255) / 256)), dim3(256), 0, st, ix.genome, index, n_idx,
                      counter, depth, mode, n_keys, shift_or_div, bound, bad, d_fail, gaps);
   hipLaunchKernelGGL(ext_gaps_kernel, dim3(4096), dim3(256), 0, st, gaps, bound);
-  hipLaunchKernelGGL(ext_entries_kernel, dim3(static_cast<u32>((n_keys + 255) / 256)), dim3(256), 0, st, bound, counter, bad, n_keys,
+  hipLaunchKernelGGL(ext_entries_kernel, dim3(static_cast<u32>(std::min<u64>((n_keys + 255) / 256, 1u << 22))), dim3(256), 0, st, bound, counter, bad, n_keys,
                      extra, mode, maxc, out);
   return hipGetLastError();
 }

@@ -194,8 +194,9 @@ def sample_pairs(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, f
     return r1.reshape(-1), r2.reshape(-1)
 
 
-def sample_reads(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, chunk=1_000_000):
-    """simreads-equivalent sampler on the GPU: returns uint8 blob [n*L] of ASCII reads."""
+def sample_reads(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, chunk=1_000_000, pbat_frac=0.0):
+    """simreads-equivalent sampler on the GPU: returns uint8 blob [n*L] of ASCII reads.  pbat_frac of the reads come
+    from the PBAT strand (A-rich: the reverse complement of a T-rich read), as `sim -R` mixes them (src/simreads.cpp)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -237,6 +238,9 @@ def sample_reads(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, c
         reads = torch.where(is_mut & (kind != 2), rnd, reads)
         conv = (reads == ord("C")) & (torch.rand((m, L), generator=g, device=device) < bis)
         reads = torch.where(conv, torch.full_like(reads, ord("T")), reads)
+        if pbat_frac > 0:
+            pbat = torch.rand((m,), generator=g, device=device) < pbat_frac
+            reads = torch.where(pbat[:, None], comp[reads.flip(1).long()], reads)
         out[a:a + m] = reads
     # ReadLoader rules (src/abismal.cpp:187-195): <44 informative bases -> skipped.
     # Such reads (N-gap overlaps) are kept as all-N records of length L so that the
@@ -432,13 +436,17 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
 
 
 # ---------------------------------------------------------------------------------- e2e
-def run_e2e(args, idx, fasta, L):
-    """SURVEY.md section 8(d)'s window: FASTQ on disk -> SAM on disk through the product CLI, timed from the
-    first batch submitted to the last SAM byte written (index load/upload excluded and reported).  The
-    FASTQ comes from the product's own `sim` (md5-pinned restatement of `abismal sim`) on the bench
-    genome; a prefix of it also goes through the oracle's CLI and the SAM bodies must be identical."""
+def run_e2e(args, idx, fasta, L, gpus=1):
+    """SURVEY.md section 8(d)'s window on `gpus` GPUs: FASTQ on disk -> SAM on disk through the product CLI
+    (`abismal-amd map -gpus N`, a fresh child process), timed from the first batch submitted to the last SAM byte
+    written (index load/upload excluded and reported).  The FASTQ comes from the product's own `sim` (md5-pinned
+    restatement of `abismal sim`) on the bench genome -- --e2e-reads reads, N times over for N GPUs; the MEDIAN of
+    three runs is the value.  A prefix of the input also goes through the oracle's CLI and the SAM bodies must be
+    identical.  The same input once more with -host-ceiling (no mapping call: every read gets a made-up hit) says
+    what the host pipeline around the mapper can carry on this box."""
     import hashlib
     import shutil
+    import statistics
     import subprocess
     cli = os.path.join(ROOT, "abismal_amd", "abismal-amd")
     if not os.path.exists(fasta):  # (an earlier run without this leg removed it: the generator is deterministic)
@@ -454,26 +462,49 @@ def run_e2e(args, idx, fasta, L):
         subprocess.run([cli, "sim", "-single", "-seed", "1", "-n", str(n), "-l", str(L), "-m", "0.01", "-b", "0.98",
                         "-o", os.path.join(wd, "reads"), fasta], check=True, stdout=subprocess.DEVNULL)
         t_sim = time.time() - t0
-        fq = os.path.join(wd, "reads_1.fq")
+        fq1 = os.path.join(wd, "reads_1.fq")
+        fq, copies = fq1, 1
+        if gpus > 1:
+            # N GPUs map N times the reads: the same FASTQ N times over (fewer if the tmpfs cannot hold input + SAM)
+            per_copy = os.path.getsize(fq1) * 1.8
+            room = shutil.disk_usage(wd).free * 0.8
+            copies = int(max(1, min(gpus, room // per_copy)))
+            if copies > 1:
+                fq = os.path.join(wd, "reads_n.fq")
+                with open(fq, "wb") as fo:
+                    for _ in range(copies):
+                        with open(fq1, "rb") as fi:
+                            shutil.copyfileobj(fi, fo, 1 << 24)
         sam, tj = os.path.join(wd, "out.sam"), os.path.join(wd, "timing.json")
-        best, all_seconds = None, []
-        for rep in range(3):  # best of three: the later runs have the page cache and the GPU clocks of a run in progress
-            r = subprocess.run([cli, "map", "-i", idx, "-o", sam, "-s", os.path.join(wd, "out.stats"), "-timing", tj, fq],
+        gflag = ["-gpus", str(gpus)]
+        runs = []
+        for rep in range(3):
+            r = subprocess.run([cli, "map"] + gflag + ["-i", idx, "-o", sam, "-s", os.path.join(wd, "out.stats"), "-timing", tj, fq],
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if r.returncode != 0:
                 return {"error": r.stderr[-2000:]}
-            t = json.load(open(tj))
-            all_seconds.append(round(t["seconds"], 3))
-            if best is None or t["seconds"] < best["seconds"]:
-                best = t
-        # the same pipeline on a longer input (the FASTQ four times over): a 10 M-read run is two batches long, so
-        # it mostly measures how well the first batch's start and the last batch's output are hidden
+            runs.append(json.load(open(tj)))
+        secs = sorted(t["seconds"] for t in runs)
+        med = [t for t in runs if t["seconds"] == secs[1]][0]
+        # what the host side alone can carry: the same command without the mapping call, at several thread counts
+        ceiling = []
+        for th in sorted({med["host_threads"], min(os.cpu_count() or 1, 128), os.cpu_count() or 1}):
+            r = subprocess.run([cli, "map"] + gflag + ["-host-ceiling", "-t", str(th), "-i", idx, "-o", os.path.join(wd, "ceil.sam"), "-timing", tj, fq],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if r.returncode == 0:
+                t = json.load(open(tj))
+                ceiling.append({"host_threads": th, "reads_per_s": round(t["reads"] / t["seconds"], 1), "seconds": round(t["seconds"], 3),
+                                "busy_s": {k: round(v, 3) for k, v in t["busy_s"].items()}})
+            if os.path.exists(os.path.join(wd, "ceil.sam")):
+                os.remove(os.path.join(wd, "ceil.sam"))
+        # one GPU: the same pipeline on a longer input (the FASTQ four times over) -- a 10 M-read run is a few batches
+        # long, so it mostly measures how well the first batch's start and the last batch's output are hidden
         sustained = None
-        if args.e2e_copies > 1:
+        if args.e2e_copies > 1 and gpus == 1:
             big = os.path.join(wd, "reads_x.fq")
             with open(big, "wb") as fo:
                 for _ in range(args.e2e_copies):
-                    with open(fq, "rb") as fi:
+                    with open(fq1, "rb") as fi:
                         shutil.copyfileobj(fi, fo, 1 << 24)
             r = subprocess.run([cli, "map", "-i", idx, "-o", os.path.join(wd, "big.sam"), "-timing", tj, big],
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -485,13 +516,19 @@ def run_e2e(args, idx, fasta, L):
             for f in (big, os.path.join(wd, "big.sam")):
                 if os.path.exists(f):
                     os.remove(f)
-        out = {"value": round(best["reads"] / best["seconds"], 1), "unit": "reads/s", "sustained": sustained,
-               "window": "first batch submitted -> last SAM byte written (abismal-amd map, plain FASTQ in, SAM text out, tmpfs)",
-               "reads": best["reads"], "seconds": round(best["seconds"], 3), "seconds_of_each_run": all_seconds,
-               "index_load_s": round(best["index_load_s"], 2),
+        out = {"value": round(med["reads"] / med["seconds"], 1), "unit": "reads/s", "gpus": gpus, "statistic": "median of three runs",
+               "sustained": sustained,
+               "window": "first batch submitted -> last SAM byte written (abismal-amd map -gpus N, plain FASTQ in, SAM text out, tmpfs)",
+               "reads": med["reads"], "input": f"{n} product-sim reads" + (f", {copies} times over" if copies > 1 else ""),
+               "seconds": round(med["seconds"], 3), "seconds_of_each_run": [round(t["seconds"], 3) for t in runs],
+               "index_load_s": round(med["index_load_s"], 2),
                "fastq_bytes": os.path.getsize(fq), "sam_bytes": os.path.getsize(sam), "sim_s": round(t_sim, 1),
-               "cli": {k: best[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "batch_reads")},
-               "busy_s": {k: round(v, 3) for k, v in best["busy_s"].items()}}
+               "cli": {k: med[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "batch_reads", "batches_per_gpu", "reads_per_gpu") if k in med},
+               "busy_s": {k: round(v, 3) for k, v in med["busy_s"].items()},
+               "host_ceiling": ceiling,
+               "host_ceiling_reads_per_s": max([c["reads_per_s"] for c in ceiling], default=None),
+               "host_ceiling_note": "abismal-amd map -host-ceiling on the same input: cut, parse, format and write at full rate, every "
+                                    "read given a made-up hit instead of the mapping call; SAM to the same tmpfs"}
         # parity on a prefix: product CLI vs oracle CLI, SAM body (everything but the @PG line) byte for byte
         nchk = min(n, args.e2e_check)
         if nchk > 0:
@@ -610,6 +647,8 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ABM_BENCH_READS", 10_000_000)),
                     help="reads per step per GPU")
     ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--mode", choices=["trich", "arich", "random"], default="trich",
+                    help="single-end conversion mode: T-rich (default), A-rich (-A) or random PBAT (-R; BASELINE config 5 with --read-len 150)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ABM_BENCH_CPU_SAMPLE", 1_000_000)))
     ap.add_argument("--pe", action="store_true",
                     help="paired-end variant (BASELINE config 3): 2 x --read-len pairs from 150-500 bp fragments; "
@@ -631,6 +670,8 @@ def main():
                     help="also time the CLI on the e2e FASTQ concatenated this many times (0/1 = skip)")
     ap.add_argument("--e2e-check", type=int, default=int(os.environ.get("ABM_BENCH_E2E_CHECK", 1_000_000)),
                     help="reads of the FASTQ prefix mapped by the oracle CLI too (SAM body md5 must agree)")
+    ap.add_argument("--seed-ext", default=os.environ.get("ABM_BENCH_SEED_EXT", ""),
+                    help="letters of the seed-extension tables as 'a,b' (default: the library's choice from the index's size)")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
     args = ap.parse_args()
@@ -695,15 +736,23 @@ def main():
             dist.barrier()
 
     t0 = time.time()
-    index = A.Index(idx)
+    ext_arg = None
+    if args.seed_ext:
+        ext_arg = tuple(int(x) for x in args.seed_ext.split(","))
+    index = A.Index(idx, seed_extension=ext_arg)
     ctx = A.Context(index, local_rank)
     on_planes = ctx.filter_on_planes()
     filter_genome = "bit planes (cooperative window loads)" if on_planes else "nibble array (one lane per window)"
     t_load = time.time() - t0
-    log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident)")
+    ext = ctx.seed_extension()
+    seed_tables = {"letters_2": ext[0], "letters_3": ext[1], "gb": round(ext[2] / 1e9, 2)}
+    log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident; "
+        f"seed-extension tables {ext[0]}+{ext[1]} letters, {ext[2] / 1e9:.1f} GB)")
 
     names, starts, genome_words = read_index_genome(idx)
     n, L = args.reads, args.read_len
+    se_mode = {"trich": A.SE_T_RICH, "arich": A.SE_A_RICH, "random": A.SE_RANDOM}[args.mode]
+    mode_name = {"trich": "T-rich mode", "arich": "A-rich mode (-A)", "random": "random-PBAT mode (-R: both conversions, half the reads from the PBAT strand)"}[args.mode]
     if args.pe:
         return run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     t0 = time.time()
@@ -712,7 +761,7 @@ def main():
     n_batches = max(1, min(args.steps + args.warmup, args.distinct_batches))
     blobs, n_skipped = [], 0
     for k in range(n_batches):
-        bk, sk = sample_reads(genome_words, starts, n, L, 1000 + rank + 7919 * k, dev)
+        bk, sk = sample_reads(genome_words, starts, n, L, 1000 + rank + 7919 * k, dev, pbat_frac=0.5 if se_mode == A.SE_RANDOM else 0.0)
         blobs.append(bk)
         n_skipped = sk if k == 0 else n_skipped
     blob = blobs[0]
@@ -733,7 +782,7 @@ def main():
     def step():
         bk = blobs[issued[0] % n_batches]
         issued[0] += 1
-        ctx.map_se_device(A.SE_T_RICH, params, n, bk.data_ptr(), off.data_ptr(), L, res.data_ptr(),
+        ctx.map_se_device(se_mode, params, n, bk.data_ptr(), off.data_ptr(), L, res.data_ptr(),
                           cig.data_ptr(), stride, cig_n.data_ptr(), status.data_ptr(), stream)
 
     for _ in range(args.warmup):
@@ -838,7 +887,7 @@ def main():
         oix = o.index_load(idx)
         cores = os.cpu_count() or 1
         t0 = time.perf_counter()
-        o_res, o_cig, o_cn, o_work = o.map_se(oix, seqs, mode=0, threads=cores, cig_stride=L + 2)
+        o_res, o_cig, o_cn, o_work = o.map_se(oix, seqs, mode=int(se_mode), threads=cores, cig_stride=L + 2)
         t_cpu = time.perf_counter() - t0
         o.index_free(oix)
         # full comparison on the sample: position, then diffs + flags, then the CIGAR op for op
@@ -886,10 +935,15 @@ def main():
         ctx.set_phase_stamps(True)
         step()
         torch.cuda.synchronize()
-        pc = ctx.take_work().get("phase_cycles")
+        wk = ctx.take_work()
+        pc = wk.get("phase_cycles")
         ctx.set_phase_stamps(False)
         if pc:
             phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
+            # (filter steps of 128 candidates per read, those holding at most 64, set updates applied as runs of ties)
+            phases["filter_steps_per_read"] = round(wk.get("filter_steps", 0) / n, 2)
+            phases["light_filter_steps_per_read"] = round(wk.get("light_filter_steps", 0) / n, 2)
+            phases["tie_run_updates_per_read"] = round(wk.get("fifo_updates", 0) / n, 2)
 
     basis = "strict" if strict else "kernel_tally"
     use_bytes, use_stage = (strict["bytes_per_read"], strict["stage"]) if strict else (k_bytes, k_stage)
@@ -927,24 +981,24 @@ def main():
                                         per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
 
     e2e = None
-    if not args.no_e2e and world == 1:
+    if not args.no_e2e and args.mode == "trich":  # (the other ranks have left by now: the CLI child drives all `world` GPUs itself)
         # free this process's HBM first: the CLI is a process of its own on the same GPU
         del blobs, blob, res, cig, cig_n
         ctx.close()
         index.close()
         torch.cuda.empty_cache()
-        e2e = run_e2e(args, idx, fasta, L)
+        e2e = run_e2e(args, idx, fasta, L, gpus=world)
         log(f"e2e: {e2e}")
 
     line = {
-        "metric": "mapped reads/sec (whole node), 100 bp SE on hg38-scale index",
+        "metric": f"mapped reads/sec (whole node), {L} bp SE on hg38-scale index" + ("" if args.mode == "trich" else f", {mode_name}"),
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
         "per_rank_reads_per_s": rank_rates, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp (hg38 unavailable offline), "
-                               f"{n} sim-like reads x {L} bp SE per GPU per step, T-rich mode",
+                               f"{n} sim-like reads x {L} bp SE per GPU per step, {mode_name}",
                    "reads_per_step_per_gpu": n, "read_len": L, "index_gb": round(index.device_bytes / 1e9, 2),
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated"},
         "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e,
@@ -954,6 +1008,7 @@ def main():
         "phase_shares_diagnostic": phases,
         "kernel_status": st_host,
         "filter_genome": filter_genome,
+        "seed_extension_tables": seed_tables,
         "long_cigars": {"slot_ops": stride, "reads_beyond_slot": n_long_cigars, "returned_through": "per-launch arena (abm_ctx_long_cigars)"},
         "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
     }

@@ -43,6 +43,7 @@ enum { ABM_SE_T_RICH = 0, ABM_SE_A_RICH = 1, ABM_SE_RANDOM = 2 }; /* :1552-1581,
 enum { ABM_PE_NORMAL = 0, ABM_PE_PBAT = 1, ABM_PE_RANDOM = 2 };   /* :1950-2002, -P, :2094-2158 */
 
 const char *abm_last_error(void);
+int abm_device_count(void); /* HIP devices visible to the process (0 = none: every abm_ctx_create will fail) */
 void abm_default_params(abm_params *p);
 
 /* AbismalIndex::read, src/AbismalIndex.cpp:1082-1146 (+ seed::read :988-1024,
@@ -79,6 +80,9 @@ uint32_t abm_index_window(const abm_index *ix);
  * abm_ctx_create on the index.  The tables are built for the index's max_candidates; a call with another value
  * rebuilds them when its context is the only one on the device and otherwise runs without them. */
 int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3);
+/* the max_candidates (-c, src/abismal.cpp:2329) the calls on this index will pass, when it is not the value stored
+ * in the index file: the tables of contexts created afterwards are built for it (0 = the file's value) */
+int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates);
 /* what the context's device holds: letters per table (0 = no tables) and their bytes */
 int abm_ctx_seed_extension(const abm_ctx *ctx, uint32_t *letters2, uint32_t *letters3, uint64_t *bytes);
 

@@ -112,7 +112,7 @@ int abo_map_se(void *mapper, int mode, uint64_t n, const char *blob, const uint6
       Cigar c;
       {  // the reads before this shard, back to one longer than 46 bases, leave their trace in the buffers
         uint64_t from = lo;
-        while (from > 0 && lo - from < 4096) { --from; if (off[from + 1] - off[from] > 46) break; }
+        while (from > 0) { --from; if (off[from + 1] - off[from] > 46) break; }  // (no cap: the reference's buffers never forget)
         for (uint64_t i = from; i < lo; ++i) mp.touch_se(std::string(blob + off[i], blob + off[i + 1]), static_cast<SeMode>(mode));
       }
       for (uint64_t i = lo; i < hi; ++i) {
@@ -157,7 +157,7 @@ int abo_map_pe(void *mapper, int mode, uint64_t n, const char *blob1, const uint
       Cigar c1, c2;
       {  // (see abo_map_se)
         uint64_t from = lo;
-        while (from > 0 && lo - from < 4096) {
+        while (from > 0) {
           --from;
           if (off1[from + 1] - off1[from] > 46 && off2[from + 1] - off2[from] > 46) break;
         }

@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Small test genomes would get no seed-extension tables (the library sizes them from the index): ask for 2 + 1
+    # letters by default so that the GPU parity tests run the table path, as an hg38-scale run does.  Tests of the
+    # bisection-only path pass seed_extension=(0, 0) to Index().
+    import abismal_amd.api as api
+    api.DEFAULT_SEED_EXTENSION = (2, 1)
 
 
 @pytest.fixture(scope="session")

@@ -49,17 +49,30 @@ def test_stats_allreduce_two_contexts(trex_index):
 
 @needs_two
 def test_cli_two_gpus_same_output_as_one(oracle, trex_index, tmp_path):
+    import re
     fa = os.path.join(ROOT, "tests", "golden", "tRex1.fa")
     oracle.simulate(fa, str(tmp_path / "r"), 40000, single_end=True, seed=11)
+    # every fifth read cut to 44-46 bases: what such a read finds past its end comes from the reads before it, which
+    # for the first reads of a batch were mapped by the OTHER GPU (the lead-in a batch carries along)
+    lines = open(tmp_path / "r_1.fq").read().split("\n")
+    for k in range(0, len(lines) - 3, 20):
+        cut = 44 + (k // 20) % 3
+        lines[k + 1], lines[k + 3] = lines[k + 1][:cut], lines[k + 3][:cut]
+    open(tmp_path / "r_1.fq", "w").write("\n".join(lines))
     body = {}
+    # slices and batches of 1024 reads (the units are 64 k reads by default: one slice would be one batch on one GPU)
+    env = dict(os.environ, ABM_CLI_SLICE_READS="1024", ABM_CLI_FIRST_BATCH="1024", ABM_CLI_CHUNK_BYTES="65536",
+               ABM_CLI_MARK_LINES="64")
     for g in (1, 2):
         out, st = tmp_path / f"g{g}.sam", tmp_path / f"g{g}.mstats"
-        # small batches so that both GPUs get several
-        r = subprocess.run([CLI, "map", "-v", "-gpus", str(g), "-batch", "4096", "-s", str(st), "-o", str(out), "-i", trex_index,
-                            str(tmp_path / "r_1.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        r = subprocess.run([CLI, "map", "-v", "-gpus", str(g), "-batch", "1024", "-s", str(st), "-o", str(out), "-i", trex_index,
+                            str(tmp_path / "r_1.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
         assert r.returncode == 0, r.stderr
+        per_gpu = [int(m.group(1)) for m in re.finditer(r"GPU \d+: (\d+) batches", r.stderr)]
+        assert len(per_gpu) == g and sum(per_gpu) >= 30, r.stderr
         if g == 2:
             assert "one RCCL all-reduce" in r.stderr, r.stderr
+            assert min(per_gpu) >= 5, f"both GPUs must have mapped batches: {per_gpu}"
         body[g] = ([ln for ln in open(out) if not ln.startswith("@PG")], open(st).read())
     assert body[1] == body[2] and len(body[1][0]) > 30000
 

@@ -1,0 +1,90 @@
+"""GPU parity of the seed-extension tables (abm_ext.hip): whatever number of letters the tables answer for -- none
+(bisection from the counters, the reference's find_candidates / find_candidates_three, src/abismal.cpp:1163-1259),
+a few, or the hg38-scale maximum of the 2-letter table -- results equal the oracle's, read for read, on the
+repeat-rich genome whose buckets need narrowing; and a call whose max_candidates differs from the one the tables
+were built for rebuilds them (single context) instead of using stale answers."""
+import os
+
+import pytest
+
+from tests.test_gpu_se_parity import compare_se
+from tests.test_gpu_pe_parity import compare_pe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rep(oracle, workdir):
+    import abismal_amd as A
+    from tests import synth
+    fa = os.path.join(workdir, "rep_ext.fa")
+    synth.repeat_rich_genome(fa)
+    idx = os.path.join(workdir, "rep_ext.idx")
+    A.index_build(fa, idx, 8)
+    oix = oracle.index_load(idx)
+    yield fa, idx, oix
+    oracle.index_free(oix)
+
+
+@pytest.mark.parametrize("letters", [(0, 0), (1, 1), (3, 2), (7, 1), (2, 4)])
+def test_se_any_table_depth_equals_the_oracle(oracle, rep, letters):
+    import abismal_amd as A
+    from tests import synth
+    fa, idx, oix = rep
+    ix = A.Index(idx, seed_extension=letters)
+    ctx = A.Context(ix, 0)
+    try:
+        got = ctx.seed_extension()
+        assert got[:2] == letters or letters == (0, 0) and got[:2] == (0, 0), got
+        for mode, L in ((0, 100), (2, 150), (0, 66), (0, 48)):  # (48: reads too short for the tables take the counters)
+            reads = synth.trim_like_readloader(synth.mutated_reads(fa, 4000, L, seed=7 + L, pbat_frac=0.5 if mode == 2 else 0.0))
+            o_res, o_cig, o_n, work = oracle.map_se(oix, reads, mode=mode, threads=8)
+            assert work["search_probes"] > 0
+            res, cig, off = ctx.map_se(reads, mode=mode)
+            compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"tables {letters} mode {mode} L {L}")
+    finally:
+        ctx.close()
+        ix.close()
+
+
+def test_max_candidates_other_than_the_tables(oracle, rep):
+    import abismal_amd as A
+    from tests import synth
+    fa, idx, oix = rep
+    ix = A.Index(idx, seed_extension=(3, 2))
+    ctx = A.Context(ix, 0)
+    try:
+        reads = synth.trim_like_readloader(synth.mutated_reads(fa, 4000, 100, seed=99))
+        for c in (20, 500, 100, 5):
+            p = A.Params(max_candidates=c)
+            o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, mode=0, threads=8, max_candidates=c)
+            res, cig, off = ctx.map_se(reads, mode=0, params=p)
+            compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"tables rebuilt for -c {c}")
+        # a second context on the device: a differing max_candidates now runs without tables (nothing is rebuilt under it)
+        ctx2 = A.Context(ix, 0)
+        try:
+            p = A.Params(max_candidates=33)
+            o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, mode=0, threads=8, max_candidates=33)
+            res, cig, off = ctx2.map_se(reads, mode=0, params=p)
+            compare_se(res, cig, off, o_res, o_cig, o_n, reads, "second context, -c 33, no tables")
+        finally:
+            ctx2.close()
+    finally:
+        ctx.close()
+        ix.close()
+
+
+def test_pe_with_and_without_tables(oracle, rep):
+    import abismal_amd as A
+    from tests import synth
+    fa, idx, oix = rep
+    r1, r2 = synth.mutated_pairs(fa, 3000, 100, seed=3)
+    orc = oracle.map_pe(oix, r1, r2, mode=0, threads=8)
+    for letters in ((0, 0), (3, 2)):
+        ix = A.Index(idx, seed_extension=letters)
+        ctx = A.Context(ix, 0)
+        try:
+            compare_pe(ctx.map_pe(r1, r2, mode=0), orc, f"PE tables {letters}")
+        finally:
+            ctx.close()
+            ix.close()

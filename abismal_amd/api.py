@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_reserve", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
-    "abm_device_count", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_ctx_seed_extension",
+    "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_ctx_seed_extension",
 ]
 
 
@@ -35,7 +35,8 @@ class Params(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libabismal_amd.so")
+    # (ABISMAL_AMD_LIB: another build of the library, for the A/B scripts under scripts/)
+    return os.environ.get("ABISMAL_AMD_LIB") or os.path.join(_HERE, "libabismal_amd.so")
 
 
 _lib = None
@@ -73,8 +74,9 @@ def load_library():
     lib.abm_index_build_targets.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]
     lib.abm_index_build_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
     lib.abm_index_window.argtypes = [C.c_void_p]
-    lib.abm_index_set_seed_extension.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    lib.abm_ctx_seed_extension.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    if hasattr(lib, "abm_index_set_seed_extension"):  # (absent from older builds loaded through ABISMAL_AMD_LIB)
+        lib.abm_index_set_seed_extension.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.abm_ctx_seed_extension.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.abm_index_window.restype = C.c_uint32
     lib.abm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.abm_ctx_destroy.argtypes = [C.c_void_p]

@@ -98,6 +98,7 @@ struct DeviceReplica {
   abm::DevIndex dix{};
   int refs = 0;
   void *ext_mem[3] = {nullptr, nullptr, nullptr};  // seed-extension tables (abm_ext.hip), built for dix.ext_maxc candidates
+  abm::u32 ext_tried = 0;                           // max_candidates of the last build attempt (it may have built nothing)
   double ext_build_s = 0;
   std::mutex mu;  // guards arena / refs / tables: the replicas of different devices are set up side by side
   // The single-end host-buffer entry points of the contexts on one device take turns for the mapping
@@ -170,8 +171,8 @@ struct abm_ctx {
 namespace {
 
 // Seed-extension tables of one device replica for `maxc` candidates (see abm_ext.hip).  Letters per table: asked
-// for through abm_index_set_seed_extension, else the fewest that give every index entry a key of its own on
-// average -- none for small genomes, 7 and 4 at hg38 scale (34 + 2 x 28 GB) -- and never more than fit half of the
+// for through abm_index_set_seed_extension, else the fewest that give the tables as many keys as the genome has
+// bases -- none below 33 Mbp, 7 and 4 at hg38 scale (34 + 2 x 28 GB) -- and never more than fit half of the
 // device's free memory.  Genomes with IUPAC letters get none (their base-3 digits are not the sort's symbols).
 void free_ext(DeviceReplica &rep) {
   for (auto &m : rep.ext_mem) { if (m) (void)hipFree(m); m = nullptr; }
@@ -180,13 +181,16 @@ void free_ext(DeviceReplica &rep) {
 }
 void build_ext(DeviceReplica &rep, const abm_index &ix, abm::u32 maxc) {
   free_ext(rep);
+  rep.ext_tried = maxc;
   const abm::HostIndex &h = ix.h;
   if (h.multibit_genome || maxc == 0) return;
-  const uint64_t n2 = h.index.size(), n3 = std::max(h.index_t.size(), h.index_a.size());
+  // (by the genome's length: the buckets that need narrowing belong to repeats, whose copy numbers grow with it --
+  // measured at 3.1 Gbp, kernel time per 10 M reads: no tables 757-763 ms, 4+2 letters 739-747, 6+3 728-739, 7+4 719-728)
+  const uint64_t n_bases = h.chrom_starts.empty() ? 0 : h.chrom_starts.back();
   int e2 = ix.want_e2, e3 = ix.want_e3;
   if (const char *e = experiment_env("ABM_EXT_LETTERS")) { int a = 0, b = 0; if (std::sscanf(e, "%d,%d", &a, &b) == 2) { e2 = a; e3 = b; } }
-  if (e2 < 0) { e2 = 0; while (e2 < 7 && abm::ext_keys(0, e2) < n2) ++e2; }
-  if (e3 < 0) { e3 = 0; while (e3 < 4 && abm::ext_keys(1, e3) < n3) ++e3; }
+  if (e2 < 0) { e2 = 0; while (e2 < 7 && abm::ext_keys(0, e2) < n_bases) ++e2; }
+  if (e3 < 0) { e3 = 0; while (e3 < 4 && abm::ext_keys(1, e3) < n_bases) ++e3; }
   e2 = std::min(e2, 7); e3 = std::min(e3, 4);
   if (e2 <= 0 || e3 <= 0) return;
   auto need = [&](int a, int b) {
@@ -537,7 +541,7 @@ abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
   d.max_candidates = maxc;
   DeviceReplica &rep = *ctx->rep;
   std::lock_guard<std::mutex> lk(rep.mu);
-  if (rep.dix.ext_maxc != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
+  if (rep.dix.ext_maxc != maxc && rep.ext_tried != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
     HIPCHK(hipDeviceSynchronize());
     build_ext(rep, *ctx->ix, maxc);
   }
@@ -562,6 +566,15 @@ void abm_default_params(abm_params *p) {
   p->max_frag = 3000;
   p->allow_ambig = 0;
 }
+
+int abm_host_alloc(size_t bytes, void **out) {
+  return guarded([&] {
+    if (!out) throw std::invalid_argument("null argument");
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocPortable));
+  });
+}
+void abm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int abm_device_count(void) {
   int n = 0;

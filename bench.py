@@ -488,15 +488,17 @@ def run_e2e(args, idx, fasta, L, gpus=1):
         med = [t for t in runs if t["seconds"] == secs[1]][0]
         # what the host side alone can carry: the same command without the mapping call, at several thread counts
         ceiling = []
-        for th in sorted({med["host_threads"], min(os.cpu_count() or 1, 128), os.cpu_count() or 1}):
-            r = subprocess.run([cli, "map"] + gflag + ["-host-ceiling", "-t", str(th), "-i", idx, "-o", os.path.join(wd, "ceil.sam"), "-timing", tj, fq],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            if r.returncode == 0:
-                t = json.load(open(tj))
-                ceiling.append({"host_threads": th, "reads_per_s": round(t["reads"] / t["seconds"], 1), "seconds": round(t["seconds"], 3),
-                                "busy_s": {k: round(v, 3) for k, v in t["busy_s"].items()}})
-            if os.path.exists(os.path.join(wd, "ceil.sam")):
-                os.remove(os.path.join(wd, "ceil.sam"))
+        for sink in (os.path.join(wd, "ceil.sam"), "/dev/null"):
+            for th in sorted({32, med["host_threads"], min(os.cpu_count() or 1, 128)}):
+                r = subprocess.run([cli, "map"] + gflag + ["-host-ceiling", "-seed-ext", "0,0", "-t", str(th), "-i", idx, "-o", sink, "-timing", tj, fq],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                if r.returncode == 0:
+                    t = json.load(open(tj))
+                    ceiling.append({"sink": "tmpfs file" if sink != "/dev/null" else "/dev/null", "host_threads": th,
+                                    "reads_per_s": round(t["reads"] / t["seconds"], 1), "seconds": round(t["seconds"], 3),
+                                    "busy_s": {k: round(v, 3) for k, v in t["busy_s"].items()}})
+                if sink != "/dev/null" and os.path.exists(sink):
+                    os.remove(sink)
         # one GPU: the same pipeline on a longer input (the FASTQ four times over) -- a 10 M-read run is a few batches
         # long, so it mostly measures how well the first batch's start and the last batch's output are hidden
         sustained = None
@@ -521,14 +523,15 @@ def run_e2e(args, idx, fasta, L, gpus=1):
                "window": "first batch submitted -> last SAM byte written (abismal-amd map -gpus N, plain FASTQ in, SAM text out, tmpfs)",
                "reads": med["reads"], "input": f"{n} product-sim reads" + (f", {copies} times over" if copies > 1 else ""),
                "seconds": round(med["seconds"], 3), "seconds_of_each_run": [round(t["seconds"], 3) for t in runs],
-               "index_load_s": round(med["index_load_s"], 2),
+               "index_load_s": round(med["index_load_s"], 2), "host_prepare_s": round(med.get("host_prepare_s", 0.0), 2),
                "fastq_bytes": os.path.getsize(fq), "sam_bytes": os.path.getsize(sam), "sim_s": round(t_sim, 1),
                "cli": {k: med[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "batch_reads", "batches_per_gpu", "reads_per_gpu") if k in med},
                "busy_s": {k: round(v, 3) for k, v in med["busy_s"].items()},
                "host_ceiling": ceiling,
-               "host_ceiling_reads_per_s": max([c["reads_per_s"] for c in ceiling], default=None),
+               "host_ceiling_reads_per_s": max([c["reads_per_s"] for c in ceiling if c["sink"] == "tmpfs file"], default=None),
+               "host_ceiling_reads_per_s_dev_null": max([c["reads_per_s"] for c in ceiling if c["sink"] == "/dev/null"], default=None),
                "host_ceiling_note": "abismal-amd map -host-ceiling on the same input: cut, parse, format and write at full rate, every "
-                                    "read given a made-up hit instead of the mapping call; SAM to the same tmpfs"}
+                                    "read given a made-up hit instead of the mapping call; SAM to a tmpfs file and to /dev/null, at 32 / default / 128 host threads"}
         # parity on a prefix: product CLI vs oracle CLI, SAM body (everything but the @PG line) byte for byte
         nchk = min(n, args.e2e_check)
         if nchk > 0:
@@ -672,6 +675,8 @@ def main():
                     help="reads of the FASTQ prefix mapped by the oracle CLI too (SAM body md5 must agree)")
     ap.add_argument("--seed-ext", default=os.environ.get("ABM_BENCH_SEED_EXT", ""),
                     help="letters of the seed-extension tables as 'a,b' (default: the library's choice from the index's size)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the embedded runs of BASELINE configs 3 (paired-end 2 x 150) and 5 (150 bp random PBAT) at N=1")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
     args = ap.parse_args()
@@ -744,6 +749,7 @@ def main():
     on_planes = ctx.filter_on_planes()
     filter_genome = "bit planes (cooperative window loads)" if on_planes else "nibble array (one lane per window)"
     t_load = time.time() - t0
+    index_gb = round(index.device_bytes / 1e9, 2)
     ext = ctx.seed_extension()
     seed_tables = {"letters_2": ext[0], "letters_3": ext[1], "gb": round(ext[2] / 1e9, 2)}
     log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident; "
@@ -990,6 +996,33 @@ def main():
         e2e = run_e2e(args, idx, fasta, L, gpus=world)
         log(f"e2e: {e2e}")
 
+    # the other single-GPU configurations of BASELINE.json, each by a fresh child process of this script once this
+    # process has let go of the GPU (their own JSON lines, embedded): config 3 (paired-end 2 x 150) and config 5
+    # (150 bp single-end, random PBAT) -- shortened so that the default run stays within minutes
+    other = None
+    if world == 1 and args.mode == "trich" and not args.no_other_configs:
+        import subprocess
+        if e2e is None:
+            del blobs, blob, res, cig, cig_n
+            ctx.close()
+            index.close()
+            torch.cuda.empty_cache()
+        other = {}
+        common = [sys.executable, os.path.abspath(__file__), "--no-e2e", "--no-other-configs", "--genome-mbp", str(args.genome_mbp),
+                  "--workdir", args.workdir]
+        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "12", "--warmup", "12", "--cpu-sample", "200000"]),
+                           ("config5_random_pbat_150", ["--mode", "random", "--read-len", "150", "--reads", "4000000", "--steps", "3", "--warmup", "1",
+                                                        "--cpu-sample", "200000"])):
+            t0 = time.time()
+            r = subprocess.run(common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and rows:
+                other[key] = json.loads(rows[-1])
+                other[key]["wall_s"] = round(time.time() - t0, 1)
+            else:
+                other[key] = {"error": r.stderr[-1500:]}
+            log(f"{key}: {other[key].get('value')} {other[key].get('unit', '')} in {time.time() - t0:.0f}s")
+
     line = {
         "metric": f"mapped reads/sec (whole node), {L} bp SE on hg38-scale index" + ("" if args.mode == "trich" else f", {mode_name}"),
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -999,9 +1032,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp (hg38 unavailable offline), "
                                f"{n} sim-like reads x {L} bp SE per GPU per step, {mode_name}",
-                   "reads_per_step_per_gpu": n, "read_len": L, "index_gb": round(index.device_bytes / 1e9, 2),
+                   "reads_per_step_per_gpu": n, "read_len": L, "index_gb": index_gb,
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated"},
-        "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e,
+        "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "other_configs": other,
         "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                     "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])},
         "work_per_read": {k: round(v / n, 2) for k, v in per_launch.items()},

@@ -44,6 +44,11 @@ enum { ABM_PE_NORMAL = 0, ABM_PE_PBAT = 1, ABM_PE_RANDOM = 2 };   /* :1950-2002,
 
 const char *abm_last_error(void);
 int abm_device_count(void); /* HIP devices visible to the process (0 = none: every abm_ctx_create will fail) */
+/* Page-locked host memory, usable from every device (hipHostMalloc, portable): batches whose seq_blob / seq_off lie
+ * in it are uploaded by the DMA engines at the link's rate instead of through the runtime's staging buffers (the
+ * reference has no counterpart: its batches never leave the host). */
+int abm_host_alloc(size_t bytes, void **out);
+void abm_host_free(void *p);
 void abm_default_params(abm_params *p);
 
 /* AbismalIndex::read, src/AbismalIndex.cpp:1082-1146 (+ seed::read :988-1024,
@@ -75,7 +80,7 @@ uint32_t abm_index_window(const abm_index *ix);
  * derives, in HBM, three tables that answer the first steps of the bucket-narrowing loops of find_candidates /
  * find_candidates_three (src/abismal.cpp:1163-1259) with one load per seed offset: one entry per key of the hashed
  * letters plus letters2 more (2-letter table, at most 7) / letters3 more (3-letter tables, at most 4).  By default
- * the letters are chosen from the index's size (none for small genomes; 7 and 4 = 90 GB at hg38 scale, fewer if that
+ * the letters are chosen from the genome's length (none below 33 Mbp; 7 and 4 = 90 GB at hg38 scale, fewer if that
  * exceeds half of the free device memory); this call fixes them (0, 0 = no tables) and must precede the first
  * abm_ctx_create on the index.  The tables are built for the index's max_candidates; a call with another value
  * rebuilds them when its context is the only one on the device and otherwise runs without them. */

@@ -5,12 +5,12 @@
 set -u
 export ABM_BENCH_GENOME_MBP=${ABM_BENCH_GENOME_MBP:-3100}
 SAMPLE=${SAMPLE:-200000}
-python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-split --no-e2e > /dev/null 2>&1   # builds the index once
+python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-split --no-e2e --no-other-configs > /dev/null 2>&1   # builds the index once
 for rep in 1 2; do
   for v in ${VARIANTS:-old new}; do
     cp abismal_amd/_ab/libabismal_amd_$v.so abismal_amd/libabismal_amd.so
     if [ $rep = 1 ]; then EXTRA="--cpu-sample $SAMPLE"; else EXTRA="--no-cpu-baseline --no-stage-split"; fi
-    python bench.py --steps 4 --warmup 1 --no-e2e $EXTRA 2>gpurun_out/r03_ab_$v.err | tail -1 > gpurun_out/r03_ab_${v}_$rep.json
+    python bench.py --steps 4 --warmup 1 --no-e2e --no-other-configs $EXTRA 2>gpurun_out/r03_ab_$v.err | tail -1 > gpurun_out/r03_ab_${v}_$rep.json
     python - "$v" "$rep" gpurun_out/r03_ab_${v}_$rep.json <<'PY'
 import json, sys
 v, rep, path = sys.argv[1:4]

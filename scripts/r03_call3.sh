@@ -18,7 +18,7 @@ print("  e2e", {k: e.get(k) for k in ("value", "seconds_of_each_run", "sustained
 PY
 EXTS="6,3 7,4" SAMPLE=100000 bash scripts/r03_ext.sh 2>&1 | tee gpurun_out/r03_call3_ext.log
 # config 5: 150 bp random PBAT
-python bench.py --mode random --read-len 150 --reads 5000000 --steps 3 --warmup 1 --cpu-sample 300000 --no-e2e 2> gpurun_out/r03_call3_cfg5.err | tail -1 > gpurun_out/r03_call3_cfg5.json
+python bench.py --mode random --read-len 150 --reads 5000000 --steps 3 --warmup 1 --cpu-sample 300000 --no-e2e --no-other-configs 2> gpurun_out/r03_call3_cfg5.err | tail -1 > gpurun_out/r03_call3_cfg5.json
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/r03_call3_cfg5.json"))

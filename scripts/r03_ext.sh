@@ -4,11 +4,11 @@
 set -u
 export ABM_BENCH_GENOME_MBP=${ABM_BENCH_GENOME_MBP:-3100}
 SAMPLE=${SAMPLE:-200000}
-python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-split --no-e2e --seed-ext 0,0 > /dev/null 2>&1   # builds the index once
+python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-split --no-e2e --no-other-configs --seed-ext 0,0 > /dev/null 2>&1   # builds the index once
 for rep in 1 2; do
   for x in ${EXTS:-0,0 4,2 7,4}; do
     if [ $rep = 1 ]; then EXTRA="--cpu-sample $SAMPLE"; else EXTRA="--no-cpu-baseline --no-stage-split"; fi
-    python bench.py --steps 4 --warmup 1 --no-e2e --seed-ext $x $EXTRA 2>gpurun_out/r03_ext_$x.err | tail -1 > gpurun_out/r03_ext_${x}_$rep.json
+    python bench.py --steps 4 --warmup 1 --no-e2e --no-other-configs --seed-ext $x $EXTRA 2>gpurun_out/r03_ext_$x.err | tail -1 > gpurun_out/r03_ext_${x}_$rep.json
     grep "index loaded" gpurun_out/r03_ext_$x.err
     python - "$x" "$rep" gpurun_out/r03_ext_${x}_$rep.json <<'PY'
 import json, sys

@@ -26,8 +26,9 @@ def big(oracle, tmp_path_factory):
     A.index_build(fa, idx, os.cpu_count() or 8)
     os.remove(fa)
     _, starts, gw = bench.read_index_genome(idx)
-    ix = A.Index(idx)
+    ix = A.Index(idx, seed_extension=(-1, -1))  # the library's own choice for a genome of this size (4 + 3 letters)
     ctx = A.Context(ix, 0)
+    assert ctx.seed_extension()[0] >= 3
     oix = oracle.index_load(idx)
     yield {"ctx": ctx, "oix": oix, "starts": starts, "gw": gw, "dev": dev, "bench": bench}
     oracle.index_free(oix)

@@ -79,6 +79,7 @@ def test_pe_with_and_without_tables(oracle, rep):
     from tests import synth
     fa, idx, oix = rep
     r1, r2 = synth.mutated_pairs(fa, 3000, 100, seed=3)
+    r1, r2 = synth.trim_like_readloader(r1), synth.trim_like_readloader(r2)  # (the boundary takes reads as ReadLoader hands them over)
     orc = oracle.map_pe(oix, r1, r2, mode=0, threads=8)
     for letters in ((0, 0), (3, 2)):
         ix = A.Index(idx, seed_extension=letters)

@@ -137,6 +137,9 @@ struct abm_ctx {
   DevBuf<abm::u32> cblob;
   DevBuf<abm::u64> off2;
   DevBuf<abm::u32> lens, order, class33;
+  DevBuf<abm::u32> long_list, long_count, long_ctmp;  // the long-read launch (se_long_reads): listed reads, per-wave scratch
+  DevBuf<abm::u64> packed_long;
+  DevBuf<abm::u8> long_tb;
   DevBuf<abm::u8> cls;
   DevBuf<unsigned long long> work;
   DevBuf<unsigned long long> next_read;
@@ -258,6 +261,66 @@ hipEvent_t begin_timed(abm_ctx *ctx, hipStream_t st) {
   return e1;
 }
 
+// The launch for a batch's reads of kLdsReadLen + 1 .. kMaxReadLen bases (map_se_long_kernel): the reads are listed
+// on the device, the list's length is fetched (the one place a device entry point waits for the device -- only when
+// the caller announced such reads through max_len), and the list is mapped in rounds of at most 1024 reads, each
+// packed into encodings of its own and mapped by one wave per CU with per-wave traceback tables in global memory.
+// Results land where the main launch left these reads unmapped.  `a` = the main launch's arguments.
+void se_long_reads(abm_ctx *ctx, const abm::SeArgs &main, uint64_t n, const char *d_blob, const uint64_t *d_off,
+                   abm::u32 max_len, double valid_frac, hipStream_t st) {
+  if (n >= (1ull << 32)) throw std::invalid_argument("batch too large for the long-read launch (>= 2^32 reads)");
+  ctx->long_list.reserve(n);
+  ctx->long_count.reserve(1);
+  HIPCHK(hipMemsetAsync(ctx->long_count.p, 0, 4, st));
+  HIPCHK(abm::launch_collect_long(ctx->lens.p, n, ctx->long_list.p, ctx->long_count.p, st));
+  abm::u32 count = 0;
+  HIPCHK(hipMemcpyAsync(&count, ctx->long_count.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const abm::u32 W = words_for(max_len), WB = bitwords_for(max_len);
+  const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : valid_frac;
+  const abm::u32 GW = abm::se_window_words(max_len, size_frac);
+  const abm::u32 cap2 = (max_len + 2 + 1) & ~1u;
+  int waves = 0;
+  if (count) {
+    waves = abm::se_long_resident_waves(W, WB, GW);
+    if (waves <= 0) throw HipFail("map_se_long_kernel does not fit on this device (LDS)");
+  }
+  const abm::u32 round = 1024;
+  for (abm::u32 at = 0; at < count; at += round) {
+    const abm::u32 m = std::min(round, count - at);
+    const abm::u32 grid = std::min<abm::u32>(m, static_cast<abm::u32>(waves));
+    ctx->packed_long.reserve(static_cast<size_t>(m) * 4 * W);
+    ctx->long_tb.reserve(static_cast<size_t>(grid) * abm::se_long_tb_bytes(max_len));
+    ctx->long_ctmp.reserve(static_cast<size_t>(grid) * cap2);
+    HIPCHK(abm::launch_pack_listed(d_blob, reinterpret_cast<const abm::u64 *>(d_off), ctx->long_list.p + at, m, W, ctx->packed_long.p, st));
+    abm::SeArgs a = main;
+    a.packed = ctx->packed_long.p;
+    a.order = ctx->long_list.p + at;
+    a.n_reads = m;
+    a.W = W; a.WB = WB; a.GW = GW;
+    a.max_len = max_len;
+    a.tb_extra = 0;
+    a.G = 0;
+    a.size_frac = size_frac;
+    a.ctmp_cap = max_len + 2;
+    a.long_tb = ctx->long_tb.p;
+    a.long_ctmp = ctx->long_ctmp.p;
+    a.long_tb_bytes = abm::se_long_tb_bytes(max_len);
+    a.drained = nullptr;
+    a.finished = nullptr;
+    a.host_tail = nullptr;
+    a.read_cycles = nullptr;
+    unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    a.next_read = counter;
+    HIPCHK(abm::launch_map_se_long(a, grid, st));
+  }
+  if (ctx->host_results) {  // what the main launch's last wave would have published (abm_map_se_batch waits for the stream)
+    HIPCHK(hipMemcpyAsync(&ctx->h_tail.p[0], main.cig_arena_count, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&ctx->h_tail.p[1], main.status, 4, hipMemcpyDeviceToHost, st));
+  }
+}
+
 void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob,
                const uint64_t *d_off, uint32_t max_len, abm_hit *d_res, uint32_t *d_cig,
                uint32_t cig_stride, uint32_t *d_cig_n, uint32_t *d_status, hipStream_t st) {
@@ -267,7 +330,10 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (n == 0) return;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamWaitEvent(st, ctx->last_done, 0));
-  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kMaxReadLen);
+  // reads beyond kLdsReadLen bases (rare: long-read libraries) are left out of this launch -- its workspaces, LDS and
+  // filter stay what the batch's ordinary reads need -- and mapped by a launch of their own afterwards (se_long_reads)
+  const bool has_long = max_len > abm::kLdsReadLen;
+  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kLdsReadLen);
   const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
   ctx->packed.reserve(n * 4 * W);
   ctx->lens.reserve(n);
@@ -321,7 +387,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
       a.cig_arena = ctx->h_arena.p;
       a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->h_arena.cap, 0xFFFFFF00u));
       a.finished = ctx->finished.p;
-      a.host_tail = ctx->h_tail.p;
+      a.host_tail = has_long ? nullptr : ctx->h_tail.p;  // (with a long-read launch to follow, the summary words are copied out after it)
     }
     else {
       ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
@@ -355,6 +421,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.drained = ctx->signal_drained ? ctx->drained : nullptr;
   HIPCHK(abm::launch_map_se(a, eff_len, grid, ctx->phase_stamps, st));
   if (e1) HIPCHK(hipEventRecord(e1, st));
+  if (has_long) se_long_reads(ctx, a, n, d_blob, d_off, std::min<abm::u32>(max_len, abm::kMaxReadLen), params->valid_frac, st);
   HIPCHK(hipEventRecord(ctx->last_done, st));
 }
 
@@ -438,7 +505,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   if (n >= (1ull << 32)) throw std::invalid_argument("batch too large (>= 2^32 pairs)");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamWaitEvent(st, ctx->last_done, 0));
-  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kMaxReadLen);
+  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kLdsReadLen);  // (pairs: no long-read launch)
   const abm::u32 W = words_for(eff_len), WB = bitwords_for(eff_len);
   ctx->packed.reserve(n * 4 * W);
   ctx->packed2.reserve(n * 4 * W);
@@ -762,7 +829,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->rep->arena = nullptr;
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -974,9 +1041,9 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     const hipStream_t st = ctx->stream;
     const OffsetScan scan1 = scan_offsets(seq_off1, n, ctx->h_rel), scan2 = scan_offsets(seq_off2, n, ctx->h_rel2);
     const uint32_t max_len = std::max(scan1.max_len, scan2.max_len);
-    if (scan1.too_long + scan2.too_long) {  // (pairs with an end beyond the cap: counted once; rare, so a plain pass)
+    if (max_len > abm::kLdsReadLen) {  // (pairs with an end beyond the paired-end kernels' cap: counted once; rare, so a plain pass)
       for (uint64_t i = 0; i < n; ++i)
-        ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kMaxReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kMaxReadLen;
+        ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kLdsReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kLdsReadLen;
     }
     abm_pair *d_pair = nullptr;
     abm_hit *d_se1 = nullptr, *d_se2 = nullptr;
@@ -1051,7 +1118,7 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
   return guarded([&] {
     if (!ctx) throw std::invalid_argument("ctx is null");
     if (n == 0) return;
-    const uint32_t L = std::min<uint32_t>(std::max<uint32_t>(max_len, 48), abm::kMaxReadLen);
+    const uint32_t L = std::min<uint32_t>(std::max<uint32_t>(max_len, 48), abm::kLdsReadLen);
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
       HIPCHK(hipSetDevice(ctx->device));

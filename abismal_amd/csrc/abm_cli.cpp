@@ -606,6 +606,8 @@ struct Options {
   size_t batch = 0;  // reads (pairs) per batch; 0 = default for the input type
   int mappers = 0;  // mapper threads (contexts) per GPU; 0 = 2 for single-end, 3 for paired-end input
   int ext2 = -1, ext3 = -1;  // -seed-ext a,b: letters of the seed-extension tables (default: chosen from the index's size)
+  bool skip_long = false;     // -skip-long: pairs with an end beyond the paired-end kernels' 1024 bases are written unmapped
+                              // (and counted in the warning) instead of failing the run
   bool host_ceiling = false;  // -host-ceiling (diagnostic): no mapping call; every read gets a made-up hit, so that cut ->
                               // parse -> format -> write run at the rate the host can carry (single-end input)
   double max_distance = 0.1;
@@ -639,6 +641,7 @@ Options parse_map(int argc, char **argv) {
     else if (k == "batch") o.batch = std::stoul(need(i));
     else if (k == "mappers") o.mappers = std::stoi(need(i));
     else if (k == "host-ceiling") o.host_ceiling = true;
+    else if (k == "skip-long") o.skip_long = true;
     else if (k == "seed-ext") { const std::string v = need(i); if (std::sscanf(v.c_str(), "%d,%d", &o.ext2, &o.ext3) != 2) throw std::runtime_error("-seed-ext wants two numbers: a,b"); }
     else if (k == "timing") o.timing = need(i);  // JSON: reads, seconds (first batch submitted -> last byte written), stage busy times
     else if (k == "z" || k == "bam-level") g_bgzf_level = std::max(0, std::min(9, std::stoi(need(i))));
@@ -1600,16 +1603,18 @@ int cmd_map(int argc, char **argv) {
   if (opt.verbose)
     for (int g = 0; g < n_gpus; ++g)
       std::cerr << "[abismal-amd] GPU " << g << ": " << gpu_batches[g] << " batches, " << gpu_reads[g] << (paired ? " pairs\n" : " reads\n");
-  {
-    uint64_t too_long = 0;
-    for (abm_ctx *c : ctxs) too_long += abm_ctx_reads_too_long(c);
-    if (too_long)
-      std::cerr << "[abismal-amd] warning: " << too_long << (paired ? " pairs" : " reads") << " longer than " << abm_max_read_length()
-                << " bases were not mapped (reported as unmapped)\n";
-  }
+  // Single-end reads of any length the reference takes are mapped (longer ones stop the run while the input is parsed,
+  // with the reference's message).  Pairs: the paired-end kernels take ends of up to 1024 bases; a pair with a longer end
+  // was written unmapped, which the reference would not have done -- so the run fails unless -skip-long accepts it.
+  uint64_t too_long = 0;
+  for (abm_ctx *c : ctxs) too_long += abm_ctx_reads_too_long(c);
+  if (too_long)
+    std::cerr << "[abismal-amd] " << (opt.skip_long ? "warning: " : "error: ") << too_long << (paired ? " pairs with an end longer than 1024 bases"
+                                                                                                       : " reads beyond the supported length")
+              << " were not mapped (written as unmapped" << (opt.skip_long ? ")\n" : "); -skip-long accepts this\n");
   for (abm_ctx *c : ctxs) abm_ctx_destroy(c);
   abm_index_close(ix);
-  return EXIT_SUCCESS;
+  return too_long && !opt.skip_long ? EXIT_FAILURE : EXIT_SUCCESS;
 }
 
 }  // namespace

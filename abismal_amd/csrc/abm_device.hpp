@@ -22,7 +22,10 @@ constexpr u32 kKeyWeight3 = 16;  // src/AbismalIndex.hpp:69
 constexpr u32 kWindow = 20;      // src/AbismalIndex.hpp:76 (12 in a short-read index: DevIndex::window)
 constexpr u32 kHashMod3 = 43046721u;
 constexpr u32 kMinReadLen = 44;  // src/abismal.cpp:212-213
-constexpr u32 kMaxReadLen = 1024; // kernel cap (LDS-resident traceback: (L + 61) x 61 bytes per wave)
+constexpr u32 kLdsReadLen = 1024;  // reads up to this keep their traceback table ((L + 61) x 61 bytes) and CIGAR scratch in LDS
+constexpr u32 kMaxReadLen = 32766; // longest read mapped: the reference refuses reads of padding_size = 32767 bases or more
+                                   // (src/abismal.cpp:179-185, src/AbismalIndex.hpp:93); longer single-end reads than
+                                   // kLdsReadLen go through a launch of their own with that table in global memory
 constexpr u32 kMaxBand = 61;     // src/AbismalAlign.hpp:108,133
 constexpr u32 kSeCap = 50;       // src/abismal.cpp:448
 constexpr u32 kPeCapSmall = 32, kPeCapLarge = 32u << 10;  // src/abismal.cpp:861-862

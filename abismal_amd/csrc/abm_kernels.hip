@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict_
 // =============================================================================
 // Kernel 2: single-end mapping, one wave per read (persistent, strided).
 // =============================================================================
-template <bool TIMED, bool COOP>
+// LONG: the launch for reads beyond kLdsReadLen bases (up to kMaxReadLen).  Such a read's packed encodings, bit
+// strings and two alignment windows still fit LDS (117 KB at 32766 bases: one wave per CU), its traceback table
+// ((L + 61) x 61 bytes, 2 MB) and CIGAR scratch lie in a per-wave piece of global memory, its bands are 61 lanes
+// wide (one alignment per set and round), its filter runs on the nibble array (COOP is false), its scores wrap at 16
+// bits like the reference's, and the reads are the ones listed in `order`, their encodings packed by list position.
+template <bool TIMED, bool COOP, bool LONG>
 __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -117,18 +122,20 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   lds.qpk = reinterpret_cast<u64 *>(smem);
   lds.GW = a.GW;
   lds.qbits = lds.qpk + 4 * a.W;
-  lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
+  lds.MB = LONG ? 0u : (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
   lds.qmask = lds.qbits + 4 * a.WB;
+  lds.max_jobs = LONG ? 2u : kMaxJobs;
   {
     unsigned char *p = reinterpret_cast<unsigned char *>(lds.qmask + 4 * lds.MB * 4);
     const u32 cap2 = (a.ctmp_cap + 1) & ~1u;
-    lds.ctmp = reinterpret_cast<u32 *>(p); p += cap2 * 4;
+    if (LONG) lds.ctmp = a.long_ctmp + static_cast<u64>(blockIdx.x) * cap2;
+    else { lds.ctmp = reinterpret_cast<u32 *>(p); p += cap2 * 4; }
     lds.jpos = reinterpret_cast<u32 *>(p); p += kSeCap * 4;
     lds.jdf = reinterpret_cast<u32 *>(p); p += kSeCap * 4;
-    lds.gwin = reinterpret_cast<u64 *>(p); p += kMaxJobs * a.GW * 8;
-    lds.pcache = reinterpret_cast<u64 *>(p); p += (8u << kPosCacheBits) + a.tb_extra;
+    lds.gwin = reinterpret_cast<u64 *>(p); p += lds.max_jobs * a.GW * 8;
+    lds.pcache = reinterpret_cast<u64 *>(p); p += (8u << kPosCacheBits) + (LONG ? 0u : a.tb_extra);
     // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
-    lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
+    lds.tb = LONG ? a.long_tb + static_cast<u64>(blockIdx.x) * a.long_tb_bytes : reinterpret_cast<u8 *>(lds.gwin + a.GW);
     lds.lbest = reinterpret_cast<int *>(p); p += 64 * 4;
     lds.smark = reinterpret_cast<u32 *>(p); p += 128 * 4;
     lds.sdelta = reinterpret_cast<u32 *>(p); p += 128 * 4;
@@ -170,6 +177,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   };
   u64 r_next = blockIdx.x;
   while (r_next < n_items) {
+    const u64 slot = r_next;
     const u64 r = a.order ? static_cast<u64>(a.order[r_next]) : r_next;
     r_next = next_read();  // fetched early; its latency hides under this read's work
     long long t_read = 0;
@@ -180,9 +188,10 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     u32 n_ops = 0;
     u32 *cig_out = a.cig + r * a.cig_stride;
     if (L > kMaxReadLen) too_long = true;
-    if (L >= a.ix.min_len && L <= kMaxReadLen) {
+    // (a read beyond this launch's length is the long-read launch's: it overwrites what is stored for it here)
+    if (L >= a.ix.min_len && L <= a.max_len) {
       // stage the four encodings and derive their 2-letter bit strings
-      const u64 *src = a.packed + r * 4 * a.W;
+      const u64 *src = a.packed + (LONG ? slot : r) * 4 * a.W;
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[k] = src[k];
       wave_sync();
       for (u32 e = 0; e < 4; ++e)
@@ -213,7 +222,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         }
       }
       ABM_STAMP(t_a);
-      choose_se(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln, n_single);
+      choose_se<LONG>(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln, n_single);
       ABM_STAMP(t_b);
       if (TIMED) wt.t_align += t_b - t_a;
     }
@@ -263,7 +272,43 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
 
 // (the launch bound's second argument is waves per SIMD: 5 x 4 SIMDs = 20 one-wave workgroups per CU)
 template <bool TIMED, bool COOP>
-__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP>(a); }
+__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false>(a); }
+__global__ __launch_bounds__(64, 1) void map_se_long_kernel(SeArgs a) { map_se_body<false, false, true>(a); }
+
+// reads of this batch that the long-read launch takes: kLdsReadLen < length <= kMaxReadLen
+__global__ __launch_bounds__(256) void collect_long_kernel(const u32 *__restrict__ lens, u64 n, u32 *__restrict__ list,
+                                                           u32 *__restrict__ count) {
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < n && lens[r] > kLdsReadLen && lens[r] <= kMaxReadLen) list[atomicAdd(count, 1u)] = static_cast<u32>(r);
+}
+// pack_reads_kernel for listed reads: packed[slot][enc][word], slot = position in the list
+__global__ __launch_bounds__(256) void pack_listed_kernel(const char *__restrict__ blob, const u64 *__restrict__ off,
+                                                          const u32 *__restrict__ list, u64 m, u32 W, u64 *__restrict__ packed) {
+  const u64 gid = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const u64 slot = gid / W;
+  const u32 w = static_cast<u32>(gid % W);
+  if (slot >= m) return;
+  const u64 r = list[slot];
+  const u64 b = off[r];
+  const u32 L = static_cast<u32>(off[r + 1] - b);
+  u64 ft = 0, fa = 0, rt = 0, ra = 0;
+  for (u32 j = 0; j < 16; ++j) {
+    const u32 k = w * 16 + j;
+    u32 nft = 15, nfa = 15, nrt = 15, nra = 15;
+    if (k < L) {
+      const u32 cf = static_cast<u8>(blob[b + k]);
+      const u32 cr = comp_base(static_cast<u8>(blob[b + (L - 1 - k)]));
+      nft = read_nibble(cf, false); nfa = read_nibble(cf, true);
+      nrt = read_nibble(cr, false); nra = read_nibble(cr, true);
+    }
+    const u32 sh = j << 2;
+    ft |= static_cast<u64>(nft) << sh; fa |= static_cast<u64>(nfa) << sh;
+    rt |= static_cast<u64>(nrt) << sh; ra |= static_cast<u64>(nra) << sh;
+  }
+  if (w * 16 >= L) ft = fa = rt = ra = ~0ull;
+  u64 *dst = packed + (slot * 4) * W + w;
+  dst[0] = ft; dst[W] = fa; dst[2 * W] = rt; dst[3 * W] = ra;
+}
 
 // =============================================================================
 // Heaviest-first ordering.  Work per read spans four orders of magnitude and is
@@ -445,6 +490,38 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
   const u64 threads = n * W;
   const u32 blocks = static_cast<u32>((threads + 255) / 256);
   hipLaunchKernelGGL(pack_reads_kernel, dim3(blocks), dim3(256), 0, st, d_blob, d_off, n, W, d_packed, d_lens);
+  return hipGetLastError();
+}
+
+size_t se_long_lds_bytes(u32 W, u32 WB, u32 GW) {
+  const size_t b = static_cast<size_t>(4) * W * 8 + static_cast<size_t>(4) * WB * 8 + 2 * kSeCap * 4 + static_cast<size_t>(2) * GW * 8 +
+                   (static_cast<size_t>(8) << kPosCacheBits) + 64 * 4 + 2 * 128 * 4 + 64 * 2;
+  return (b + 15) & ~static_cast<size_t>(15);
+}
+size_t se_long_tb_bytes(u32 max_len) { return (static_cast<size_t>(max_len + kMaxBand) * kMaxBand + 255) & ~static_cast<size_t>(255); }
+int se_long_resident_waves(u32 W, u32 WB, u32 GW) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_long_kernel, 64, se_long_lds_bytes(W, WB, GW)) != hipSuccess) return 0;
+  return min(per_cu, 4) * prop.multiProcessorCount;
+}
+hipError_t launch_collect_long(const u32 *d_lens, u64 n, u32 *d_list, u32 *d_count, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(collect_long_kernel, dim3(static_cast<u32>((n + 255) / 256)), dim3(256), 0, st, d_lens, n, d_list, d_count);
+  return hipGetLastError();
+}
+hipError_t launch_pack_listed(const char *d_blob, const u64 *d_off, const u32 *d_list, u64 m, u32 W, u64 *d_packed, hipStream_t st) {
+  if (m == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_listed_kernel, dim3(static_cast<u32>((m * W + 255) / 256)), dim3(256), 0, st, d_blob, d_off, d_list, m, W, d_packed);
+  return hipGetLastError();
+}
+hipError_t launch_map_se_long(SeArgs a, u32 n_waves, hipStream_t st) {
+  if (a.n_reads == 0) return hipSuccess;
+  const size_t lds = se_long_lds_bytes(a.W, a.WB, a.GW);
+  const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(map_se_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipLaunchKernelGGL(map_se_long_kernel, dim3(blocks), dim3(64), lds, st, a);
   return hipGetLastError();
 }
 

@@ -22,6 +22,9 @@ struct SeArgs {
   u32 *cig;           // [n][cig_stride]
   u32 cig_stride;
   u32 ctmp_cap;       // LDS scratch for a CIGAR's ops: longest read + 2
+  u8 *long_tb;        // long-read launch only: per-wave traceback tables (long_tb_bytes each) ...
+  u32 *long_ctmp;     // ... and CIGAR scratch (ctmp_cap rounded up to even, per wave), in global memory
+  u64 long_tb_bytes;
   u32 *cig_arena;     // CIGARs longer than a slot (see CigarSink); null = none
   u32 *cig_arena_count;
   u32 cig_arena_cap;
@@ -110,6 +113,13 @@ hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned lon
                                 hipStream_t st);
 // n_waves = one-wave workgroups of the (persistent) grid
 hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, bool timed, hipStream_t st);
+// the long-read launch (reads of kLdsReadLen + 1 .. kMaxReadLen bases, listed in a.order, packed by list position)
+size_t se_long_lds_bytes(u32 W, u32 WB, u32 GW);
+size_t se_long_tb_bytes(u32 max_len);
+int se_long_resident_waves(u32 W, u32 WB, u32 GW);
+hipError_t launch_collect_long(const u32 *d_lens, u64 n, u32 *d_list, u32 *d_count, hipStream_t st);
+hipError_t launch_pack_listed(const char *d_blob, const u64 *d_off, const u32 *d_list, u64 m, u32 W, u64 *d_packed, hipStream_t st);
+hipError_t launch_map_se_long(SeArgs a, u32 n_waves, hipStream_t st);
 int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);
 
 }  // namespace abm

@@ -225,6 +225,7 @@ struct WaveLds {
   u16 *hres;   // [128] distances of the candidates of one step (cooperative window loads)
   u32 W, WB, GW, MB;
   u32 G;       // lanes that share one candidate's window (4 or 8), 0 = one lane per window
+  u32 max_jobs;  // window slots in gwin: kMaxJobs, or 2 in the long-read kernel (its bands are 61 lanes wide: one slot of lanes)
 };
 constexpr u32 kPosCacheBits = 8;
 constexpr u32 kMaxJobs = 21;  // 64 lanes / narrowest band (3)
@@ -888,7 +889,12 @@ struct AlnJob {  // per lane: the job whose band column this lane is
 // Runs every job assigned in `job` to completion.  Returns, per lane, the best
 // cell value of its own column (and its first row); with TB also stores one
 // byte per cell: arrow (0 M, 1 I, 2 D, 3 none) | 4 if the cell's score is > 0.
-template <bool TB>
+// WRAP: every candidate score is narrowed to 16 bits before it competes, as the reference's score_t arithmetic does
+// (src/AbismalAlign.hpp:35, :239-262: `const score_t score = ... + *cur_row`); it only ever matters for reads beyond
+// 16383 bases, whose perfect score 2 L no longer fits -- the long-read kernel's instantiations.
+template <bool WRAP> __device__ __forceinline__ int score16(int v) { return WRAP ? static_cast<int>(static_cast<i16>(v)) : v; }
+
+template <bool TB, bool WRAP = false>
 __device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job, int L, int bw_min,
                                           int bw_max, int &bestv, int &bestrow) {
   const int jl = job.jl, bw = job.bw;
@@ -918,16 +924,16 @@ __device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job,
     const int q = i + jl - bw;
     const bool valid = active && q >= 0 && q < L;
     const int lf = from_prev_lane(cur), up = from_next_lane(cur);
-    const int sdiag = cur + ((static_cast<u32>(M) & 1u) ? 2 : -3);
+    const int sdiag = score16<WRAP>(cur + ((static_cast<u32>(M) & 1u) ? 2 : -3));
     int c = max(sdiag, 0);
     int arrow = (c == sdiag) ? 0 : 3;
     if (jl < bw - 1 && q < L - 1) {   // from_above: j in [left, right-1)
-      const int s = up - 4;
+      const int s = score16<WRAP>(up - 4);
       c = max(c, s);
       if (TB && c == s) arrow = 2;
     }
     if (jl > 0 && q > 0) {            // from_left: j in [left+1, right)
-      const int s = lf - 4;
+      const int s = score16<WRAP>(lf - 4);
       c = max(c, s);
       if (TB && c == s) arrow = 1;
     }
@@ -1088,6 +1094,7 @@ __device__ __forceinline__ void stage_windows(const DevIndex &ix, const WaveLds 
 // to the set the lane is working on now, so both sets share the two DPP moves and no
 // select is needed -- each lane just alternates between its two jobs (`jp` on even steps
 // counted from t_start, `jq` on odd ones; dp/dq = 1 if that job belongs to the delayed set).
+template <bool WRAP = false>
 __device__ __forceinline__ void wavefront_pair(const WaveLds &lds, const AlnJob &jp, const AlnJob &jq, int dp,
                                                int dq, int L, int bw_min, int bw_max, int &bestp, int &bestq) {
   const int t_start = max(0, bw_min - 1), t_end = 2 * (L - 1 + bw_max) + 1;
@@ -1111,9 +1118,9 @@ __device__ __forceinline__ void wavefront_pair(const WaveLds &lds, const AlnJob 
     const int q = i + j.jl - j.bw;
     const bool valid = j.bw != 0 && q >= 0 && q < L;
     const int lf = from_prev_lane(pub), up = from_next_lane(pub);
-    int c = max(cur + ((static_cast<u32>(M) & 1u) ? 2 : -3), 0);
-    if (j.jl < j.bw - 1 && q < L - 1) c = max(c, up - 4);  // from_above
-    if (j.jl > 0 && q > 0) c = max(c, lf - 4);             // from_left
+    int c = max(score16<WRAP>(cur + ((static_cast<u32>(M) & 1u) ? 2 : -3)), 0);
+    if (j.jl < j.bw - 1 && q < L - 1) c = max(c, score16<WRAP>(up - 4));  // from_above
+    if (j.jl > 0 && q > 0) c = max(c, score16<WRAP>(lf - 4));             // from_left
     M >>= 4;
     cur = valid ? c : 0;
     best = max(best, cur);
@@ -1138,12 +1145,13 @@ __device__ __forceinline__ int wave_max_i32(int x) {
 // Scores jobs [first, ...) of the LDS job list (jpos / jdf = diffs<<16 | flags), as many as fit
 // one wave: consecutive jobs share a slot of lanes (one in each set), slots sit side by side.
 // Returns one past the last job taken; the score of job first+k is left in lds.lbest[k].
+template <bool WRAP = false>
 __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &lds, int first, int n_jobs,
                                            int L, int md, int qbase) {
   const int lane = lane_id();
   AlnJob ja = {0, 0, 0, 0, 0}, jb = {0, 0, 0, 0, 0};
   int used = 0, s = first, bw_min = 64, bw_max = 0, my_o = 0;
-  while (s < n_jobs && s - first + 2 <= static_cast<int>(kMaxJobs)) {
+  while (s < n_jobs && s - first + 2 <= static_cast<int>(lds.max_jobs)) {
     const bool two = s + 1 < n_jobs;
     const u32 dfa = lds.jdf[s], dfb = two ? lds.jdf[s + 1] : 0u;
     const int bwa = band_for(static_cast<int>(dfa) >> 16, md);
@@ -1173,7 +1181,7 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
   const bool even = ((t_start - my_o) & 1) == 0;  // which of the lane's jobs is due on even steps
   ja.jl = jb.jl = my_o;
   int bp, bq;
-  wavefront_pair(lds, even ? ja : jb, even ? jb : ja, even ? 0 : 1, even ? 1 : 0, L, bw_min, bw_max, bp, bq);
+  wavefront_pair<WRAP>(lds, even ? ja : jb, even ? jb : ja, even ? 0 : 1, even ? 1 : 0, L, bw_min, bw_max, bp, bq);
   lds.lbest[lane] = (even ? bp : bq) | ((even ? bq : bp) << 16);
   wave_sync();
   int base = 0, mine = 0;
@@ -1198,6 +1206,7 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
 }
 
 // align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
+template <bool WRAP = false>
 __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
                                           SeSet &S, Hit &best, u32 *cig_out, const CigarSink &sink,
                                           u32 &n_ops, bool &overflow, u32 &n_aln, u32 &n_single) {
@@ -1255,7 +1264,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   }
   for (int s = 0; s < n_jobs && !single;) {
     const int first = s;
-    s = score_round(ix, lds, first, n_jobs, static_cast<int>(L), md, 0);
+    s = score_round<WRAP>(ix, lds, first, n_jobs, static_cast<int>(L), md, 0);
     // apply the reference's selection in job order
     for (int k = first; k < s; ++k) {
       const u32 df = lds.jdf[k];
@@ -1289,7 +1298,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   stage_windows(ix, lds, 0, 1, md);
   wave_sync();
   int bv, brow;
-  wavefront<true>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
+  wavefront<true, WRAP>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
   // first maximum in row-major order: max value, then smallest row, then smallest column
   const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
                   (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |

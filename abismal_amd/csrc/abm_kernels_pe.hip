@@ -601,6 +601,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
   lds.mark = reinterpret_cast<u16 *>(after_heap + 256);
   lds.hres = reinterpret_cast<u16 *>(lds.lbest);
   lds.G = a.G;
+  lds.max_jobs = kMaxJobs;
   lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
   w.seg_epoch = 0;
 
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
     const u64 r = BIG ? static_cast<u64>(a.subset[it]) : (a.order ? static_cast<u64>(a.order[it]) : it);
     w.L[0] = a.lens1[r];
     w.L[1] = a.lens2[r];
-    if (w.L[0] > kMaxReadLen || w.L[1] > kMaxReadLen) { too_long = true; w.L[0] = w.L[1] = 0; }
+    if (w.L[0] > kLdsReadLen || w.L[1] > kLdsReadLen) { too_long = true; w.L[0] = w.L[1] = 0; }  // (pairs: no long-read launch)
     // stage both ends' four encodings and their 2-letter bit strings
     #pragma unroll
     for (int e = 0; e < 2; ++e) {

@@ -40,37 +40,100 @@ def test_empty_batch_and_all_skipped(ctx):
     assert (pairs["r1"]["pos"] == 0).all() and (se1["pos"] == 0).all() and (se2["pos"] == 0).all()
 
 
-def test_long_reads(ctx, oracle, trex_index):
-    """Reads up to the kernels' cap (1024 bases) map like any other; a longer one comes back unmapped and
-    counted, without disturbing its batch (the reference takes reads below 32767 bases)."""
-    import abismal_amd as A
+def _reads_from_genome(trex_index, lengths, seed, mut=0.02, indel_every=0):
     import bench
-    from tests.test_gpu_se_parity import compare_se
     names, starts, gw = bench.read_index_genome(trex_index)
     dec = np.frombuffer(b"NACNGNNNTNNNNNNN", dtype=np.uint8)
-    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rng = np.random.default_rng(seed)
     reads = []
-    for L in (300, 513, 800, 1024, 1024, 700, 100, 1500, 1025, 64):
-        p = int(rng.integers(int(starts[1]) + 20000, int(starts[2]) - 3000))
-        idx = np.arange(p, p + L)
+    for k, L in enumerate(lengths):
+        ch = 1 + k % 2
+        p = int(rng.integers(int(starts[ch]) + 1000, int(starts[ch + 1]) - L - 1000))
+        idx = np.arange(p, p + L + 64)
         s = dec[(gw[idx >> 4] >> ((idx & 15).astype(np.uint64) << np.uint64(2))) & np.uint64(15)].copy()
+        if indel_every:  # a few small deletions and insertions along the read
+            pieces, at = [], 0
+            while at < len(s):
+                step = int(rng.integers(indel_every // 2, indel_every * 2))
+                pieces.append(s[at:at + step])
+                at += step
+                if rng.random() < 0.5:
+                    at += int(rng.integers(1, 3))
+                else:
+                    pieces.append(acgt[rng.integers(0, 4, int(rng.integers(1, 3)))])
+            s = np.concatenate(pieces)
+        s = s[:L].copy()
+        if k % 3 == 2:  # every third read from the other strand
+            s = np.frombuffer(bytes(s).translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1], dtype=np.uint8).copy()
         s[s == ord("C")] = ord("T")
-        mut = rng.random(L) < 0.02
-        s[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+        m = rng.random(len(s)) < mut
+        s[m] = acgt[rng.integers(0, 4, int(m.sum()))]
         reads.append(bytes(s).decode().replace("N", "A"))
+    return reads
+
+
+def test_long_reads(ctx, oracle, trex_index):
+    """Reads of any length the reference takes (below 32767 bases, src/abismal.cpp:179-185) map like any other: up to
+    1024 bases in the batch's ordinary launch, longer ones in the long-read launch (traceback table in global memory),
+    mixed freely in one batch -- positions, edit distances, flags and CIGARs equal the oracle's."""
+    import abismal_amd as A
+    from tests.test_gpu_se_parity import compare_se
+    assert A.load_library().abm_max_read_length() == 32766
+    lengths = [300, 513, 800, 1024, 1024, 700, 100, 1500, 1025, 64, 2000, 2048, 3000, 5000, 10000, 10000, 1100, 99, 16383, 2500]
+    # (a small indel every few thousand bases: the reference's band is 61 wide, so a long read may drift by 30 at most)
+    reads = _reads_from_genome(trex_index, lengths, seed=9, indel_every=3000)
     before = ctx.reads_too_long()
     res, cig, off = ctx.map_se(reads)
-    assert ctx.reads_too_long() - before == 2
+    assert ctx.reads_too_long() == before
     oix = oracle.index_load(trex_index)
     try:
-        keep = [r if len(r) <= A.load_library().abm_max_read_length() else "" for r in reads]
-        o_res, o_cig, o_n, _ = oracle.map_se(oix, keep, threads=1)
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, threads=8)
+        compare_se(res, cig, off, o_res, o_cig, o_n, reads, "long reads, T-rich")
+        assert (res["pos"] != 0).sum() >= len(reads) - 4
+        mapped_long = [i for i in range(len(reads)) if len(reads[i]) >= 5000 and res["pos"][i] != 0]
+        assert len(mapped_long) >= 2, "the fixture's long reads must map"
+        assert max(int(off[i + 1] - off[i]) for i in mapped_long) > 4, "long reads must carry indels (CIGARs through the arena)"
+        # random-PBAT mode: both conversions tried on every read
+        res2, cig2, off2 = ctx.map_se(reads, mode=2)
+        o2 = oracle.map_se(oix, reads, mode=2, threads=8)
+        compare_se(res2, cig2, off2, o2[0], o2[1], o2[2], reads, "long reads, random PBAT")
     finally:
         oracle.index_free(oix)
-    compare_se(res, cig, off, o_res, o_cig, o_n, keep, "long reads")
-    assert res["pos"][7] == 0 and res["pos"][8] == 0 and (res["pos"][:7] != 0).sum() >= 5
     with pytest.raises(A.AbismalAmdError):
         ctx.map_se(["ACGT" * 30], mode=7)
+
+
+def test_reads_beyond_16383_bases(ctx, oracle, trex_index):
+    """Beyond 16383 bases a perfect alignment's score (2 L) no longer fits the reference's 16-bit score_t
+    (src/AbismalAlign.hpp:35): the long-read launch narrows every score to 16 bits exactly as that arithmetic does, so
+    results still equal the restatement's, whatever they are worth.  32766 bases is the longest read the reference
+    takes; one base more is an error there and comes back unmapped and counted here."""
+    from tests.test_gpu_se_parity import compare_se
+    reads = _reads_from_genome(trex_index, [20000, 32766, 17000, 150], seed=10, mut=0.01)
+    res, cig, off = ctx.map_se(reads)
+    oix = oracle.index_load(trex_index)
+    try:
+        o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, threads=4)
+    finally:
+        oracle.index_free(oix)
+    compare_se(res, cig, off, o_res, o_cig, o_n, reads, "reads beyond 16383 bases")
+    before = ctx.reads_too_long()
+    res, cig, off = ctx.map_se([reads[3], reads[1] + "A", reads[3]])
+    assert ctx.reads_too_long() - before == 1 and res["pos"][1] == 0 and res["pos"][0] == res["pos"][2] != 0
+
+
+def test_pairs_with_a_long_end(ctx, oracle, trex_index):
+    """The paired-end kernels take ends of up to 1024 bases; a pair with a longer end comes back unmapped and counted
+    (the CLI then exits non-zero unless told -skip-long), the rest of its batch is unaffected."""
+    reads = _reads_from_genome(trex_index, [150, 150, 1500, 150], seed=11)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    r1 = reads
+    r2 = [r.encode().translate(comp)[::-1].decode() for r in reads]
+    before = ctx.reads_too_long()
+    pairs, se1, se2, _, _ = ctx.map_pe(r1, r2)
+    assert ctx.reads_too_long() - before == 1
+    assert pairs["r1"]["pos"][2] == 0 and se1["pos"][2] == 0 and se2["pos"][2] == 0
 
 
 def test_unseedable_and_ragged_inputs(ctx, oracle, trex_index, reads):

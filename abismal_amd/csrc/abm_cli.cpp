@@ -730,7 +730,11 @@ int cmd_map(int argc, char **argv) {
       if (gzgets(zf, line, sizeof(line)) && gzgets(zf, line, sizeof(line))) first_len = static_cast<uint32_t>(std::strcspn(line, "\r\n"));
       gzclose(zf);
     }
-    size_t reserve_reads = (opt.batch ? opt.batch : (paired ? (1u << 21) : (1u << 23))) + 256;
+    // (the same expression the mappers use for a full batch, rounded up to whole slices as they do)
+    auto env_reads = [](const char *name, size_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<size_t>(std::atoll(e)) : dflt; };
+    const size_t slice_for_reserve = env_reads("ABM_CLI_SLICE_READS", 1u << 16);
+    size_t reserve_reads = opt.batch ? opt.batch : env_reads("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23));
+    reserve_reads = (reserve_reads + slice_for_reserve - 1) / slice_for_reserve * slice_for_reserve + 256;
     {  // (no more than the input can hold: a record is at least two sequence-length lines)
       struct stat sb;
       if (::stat(opt.reads[0].c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
@@ -738,7 +742,8 @@ int cmd_map(int argc, char **argv) {
         const int fd = ::open(opt.reads[0].c_str(), O_RDONLY);
         const bool gz = fd >= 0 && ::pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
         if (fd >= 0) ::close(fd);
-        if (!gz) reserve_reads = std::min<size_t>(reserve_reads, static_cast<size_t>(sb.st_size) / (2 * std::max<uint32_t>(first_len, 1) + 4) + 256);
+        // (gzip: FASTQ deflates five- to sixfold at most in practice; ten is a safe bound on what the file can hold)
+        reserve_reads = std::min<size_t>(reserve_reads, static_cast<size_t>(sb.st_size) * (gz ? 10 : 1) / (2 * std::max<uint32_t>(first_len, 1) + 4) + 256);
       }
     }
     std::vector<std::thread> warm;

@@ -829,9 +829,10 @@ def main():
     elapsed = float(t_el.item())
     st_host = int(status.item())
 
+    if world > 1:  # (that was the run's one collective: every rank lets go of its communicator before rank 0 starts the CLI)
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
 
     total_reads = n * args.steps * world
@@ -1046,8 +1047,6 @@ def main():
         "index_build_s": round(t_build, 1), "index_upload_s": round(t_load, 1),
     }
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -9,9 +9,16 @@
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ inline uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 
-#define LOAD2(FLAVOUR, a0, a1, p)                                                                      \
-  asm volatile("global_load_dwordx4 %0, %2, off " FLAVOUR "\n\tglobal_load_dwordx4 %1, %2, off offset:16 " FLAVOUR \
-               : "=&v"(a0), "=&v"(a1) : "v"(p) : "memory")
+// four 32-byte gathers of a lane in flight, then one wait -- all inside one asm block, so that no register the loads
+// are still to write can be handed to anything else
+#define GATHER4(FL)                                                                                                 \
+  asm volatile("global_load_dwordx4 %0, %8, off " FL "\n\tglobal_load_dwordx4 %1, %8, off offset:16 " FL "\n\t"      \
+               "global_load_dwordx4 %2, %9, off " FL "\n\tglobal_load_dwordx4 %3, %9, off offset:16 " FL "\n\t"      \
+               "global_load_dwordx4 %4, %10, off " FL "\n\tglobal_load_dwordx4 %5, %10, off offset:16 " FL "\n\t"    \
+               "global_load_dwordx4 %6, %11, off " FL "\n\tglobal_load_dwordx4 %7, %11, off offset:16 " FL "\n\t"    \
+               "s_waitcnt vmcnt(0)"                                                                                 \
+               : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])  \
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory")
 
 template <int F>
 __global__ __launch_bounds__(64) void gather32(const char *__restrict__ tab, uint64_t n32, int iters, unsigned *out) {
@@ -19,16 +26,16 @@ __global__ __launch_bounds__(64) void gather32(const char *__restrict__ tab, uin
   uint64_t s = mix(blockIdx.x * 64ull + threadIdx.x + 1);
   for (int it = 0; it < iters; ++it) {
     v4u x[8];
+    const char *p[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       s = mix(s + it * 4 + k);
-      const char *p = tab + (s % n32) * 32;
-      if (F == 0) LOAD2("", x[2 * k], x[2 * k + 1], p);
-      else if (F == 1) LOAD2("nt", x[2 * k], x[2 * k + 1], p);
-      else if (F == 2) LOAD2("sc1", x[2 * k], x[2 * k + 1], p);
-      else LOAD2("sc0 sc1", x[2 * k], x[2 * k + 1], p);
+      p[k] = tab + (s % n32) * 32;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (F == 0) GATHER4("");
+    else if (F == 1) GATHER4("nt");
+    else if (F == 2) GATHER4("sc1");
+    else GATHER4("sc0 sc1");
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc += x[k].x ^ x[k].w;
   }
@@ -44,7 +51,10 @@ template <int F> void run(const char *d, uint64_t bytes, const char *label, unsi
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   const double n = double(blocks) * 64 * iters * 4;
-  printf("%-44s %8.2f ms  %6.2f G gathers/s  %7.1f GB/s useful (32 B each)\n", label, ms, n / ms / 1e6, n * 32 / ms / 1e6);
+  const hipError_t e = hipGetLastError();
+  printf("%-44s %8.2f ms  %6.2f G gathers/s  %7.1f GB/s useful (32 B each)%s\n", label, ms, n / ms / 1e6, n * 32 / ms / 1e6,
+         e == hipSuccess ? "" : hipGetErrorString(e));
+  fflush(stdout);
 }
 
 int main() {

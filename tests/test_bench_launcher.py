@@ -46,13 +46,21 @@ def test_single_rank_needs_no_launcher():
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def test_under_torchrun_and_world_size_mismatch_is_an_error():
-    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-            "127.0.0.1", "--master-port", "29631", "bench.py"]
-    ok = _run(base + ["--gpus", "2", "--reads", "5000", "--dist-dry-run"])
+    def base():
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", _free_port(), "bench.py"]
+    ok = _run(base() + ["--gpus", "2", "--reads", "5000", "--dist-dry-run"])
     assert ok.returncode == 0, ok.stderr
     assert _line(ok.stdout)["ranks_seen"] == 2
-    bad = _run(base + ["--gpus", "4", "--reads", "5000", "--dist-dry-run"])
+    bad = _run(base() + ["--gpus", "4", "--reads", "5000", "--dist-dry-run"])
     assert bad.returncode != 0
     assert "WORLD_SIZE=2" in bad.stderr
 

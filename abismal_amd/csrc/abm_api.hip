@@ -55,7 +55,7 @@ struct HostTrace {
   }
 };
 
-// Experiment switches (ABM_COOP_WINDOWS, ABM_GRID_WAVES, ABM_PLANES_COPIES, ABM_EXT_LETTERS, ABM_DIRECT_MIN, ABM_NO_PREPASS) are honoured only when
+// Experiment switches (ABM_COOP_WINDOWS, ABM_GRID_WAVES, ABM_PLANES_COPIES, ABM_EXT_LETTERS) are honoured only when
 // ABM_EXPERIMENTS=1 is set as well: a stray variable in a production environment changes nothing.
 const char *experiment_env(const char *name) {
   static const bool on = [] { const char *e = std::getenv("ABM_EXPERIMENTS"); return e && e[0] == '1'; }();
@@ -137,7 +137,6 @@ struct abm_ctx {
   DevBuf<abm::u32> cblob;
   DevBuf<abm::u64> off2;
   DevBuf<abm::u32> lens, order, class33;
-  DevBuf<uint4> pre;  // per-wave rows of the mapping kernel's probing prologue (SeArgs::pre)
   DevBuf<abm::u32> long_list, long_count, long_ctmp;  // the long-read launch (se_long_reads): listed reads, per-wave scratch
   DevBuf<abm::u64> packed_long;
   DevBuf<abm::u8> long_tb;
@@ -311,7 +310,6 @@ void se_long_reads(abm_ctx *ctx, const abm::SeArgs &main, uint64_t n, const char
     a.finished = nullptr;
     a.host_tail = nullptr;
     a.read_cycles = nullptr;
-    a.pre = nullptr; a.pre_out = nullptr;
     unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
@@ -418,13 +416,6 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   abm::u32 grid = static_cast<abm::u32>(waves);  // persistent: one wave per resident slot
   if (const char *e = experiment_env("ABM_GRID_WAVES")) grid = std::max(64, std::atoi(e));
 
-  // The probing prologue (map_se_body, PRE): bit-plane filter kernels only; its per-wave rows of buckets
-  a.pre = nullptr; a.pre_out = nullptr; a.pre_stride = 0;
-  if (a.G != 0 && !experiment_env("ABM_NO_PREPASS")) {
-    const abm::u32 stride = (std::max<abm::u32>(a.ix.window, eff_len >> 1) + 3u) & ~3u;
-    ctx->pre.reserve(static_cast<size_t>(grid) * 4 * stride);
-    a.pre = ctx->pre.p; a.pre_out = ctx->pre.p; a.pre_stride = stride;
-  }
   const hipEvent_t e1 = begin_timed(ctx, st);
   a.next_read = fresh_counter(st);
   a.drained = ctx->signal_drained ? ctx->drained : nullptr;
@@ -615,8 +606,6 @@ namespace {
 abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
   abm::DevIndex d = ctx->dix;
   d.max_candidates = maxc;
-  d.direct_min = d.planes[0] != nullptr ? 1024u : 0u;  // (where the direct search's fixed ~30 probes start to pay)
-  if (const char *e = experiment_env("ABM_DIRECT_MIN")) d.direct_min = d.planes[0] != nullptr ? static_cast<abm::u32>(std::atoi(e)) : 0u;
   DeviceReplica &rep = *ctx->rep;
   std::lock_guard<std::mutex> lk(rep.mu);
   if (rep.dix.ext_maxc != maxc && rep.ext_tried != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
@@ -840,7 +829,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->rep->arena = nullptr;
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->pre.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;

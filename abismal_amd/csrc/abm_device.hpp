@@ -57,9 +57,7 @@ struct DevIndex {
   // tabulated (bisect from the bucket's counters).
   const uint2 *ext2, *ext3t, *ext3a;
   u32 e2, e3, ext_maxc;
-  u32 direct_min;  // ranges of at least this many entries are narrowed directly (narrow_direct); 0 = never
 };
-constexpr u32 kSortDepth = 256;  // letters a bucket is sorted by (src/AbismalIndex.hpp: seed::n_sorting_positions)
 constexpr u32 kPlaneBlock = 64;       // bases per bit-plane block
 constexpr u32 kPlaneLineBlocks = 8;   // blocks per 128-byte line
 constexpr u32 kPlaneChunkBits = 12;   // nmap: log2 of the bases per chunk

@@ -63,6 +63,14 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 // =============================================================================
 // Index upload: the genome's bit planes (DevIndex::planes).  Thread per block of 64 bases.
 // =============================================================================
+__device__ __forceinline__ u32 every_fourth_bit(u64 t) {  // bits 0, 4, 8, ... of t -> 16 contiguous bits
+  t &= 0x1111111111111111ull;
+  t = (t | (t >> 3)) & 0x0303030303030303ull;
+  t = (t | (t >> 6)) & 0x000F000F000F000Full;
+  t = (t | (t >> 12)) & 0x000000FF000000FFull;
+  t = (t | (t >> 24)) & 0xFFFFull;
+  return static_cast<u32>(t);
+}
 __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict__ genome, u64 n_words, u64 n_bases,
                                                           u64 n_blocks, u64 *__restrict__ p0, u64 *__restrict__ p1,
                                                           u32 *__restrict__ nmap, u32 *__restrict__ bad) {
@@ -104,16 +112,7 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict_
 // ((L + 61) x 61 bytes, 2 MB) and CIGAR scratch lie in a per-wave piece of global memory, its bands are 61 lanes
 // wide (one alignment per set and round), its filter runs on the nibble array (COOP is false), its scores wrap at 16
 // bits like the reference's, and the reads are the ones listed in `order`, their encodings packed by list position.
-// PRE: a read's probing and bucket narrowing -- every specific pass's -- runs as a PROLOGUE of the read, before its
-// candidate set exists, and leaves {lo2, na, lo3, nb} per (call, offset) in a per-wave piece of global memory (a.pre:
-// 1.6 KB for a 100-base read, L2-resident); the specific passes start from those.  The point is where the code sits:
-// the direct narrowing of big ranges (narrow_direct) wants a hundred registers, and inside the passes, next to the
-// candidate set and the filter's state, it cost every read more in spills than it saved in probes (729 -> 780 ms per
-// 10 M reads); as a kernel of its own ahead of the mapping kernel it lost the overlap with the other phases (129 + 633
-// ms against 730).  At the top of a read next to nothing is live.  (The reference narrows lazily -- a later call is
-// skipped once the read is certainly ambiguous; here all calls are narrowed, which wastes the work of those rare
-// reads and changes no result.)
-template <bool TIMED, bool COOP, bool LONG, bool PRE = false>
+template <bool TIMED, bool COOP, bool LONG>
 __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -207,34 +206,6 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       if (L < max(a.ix.window, L >> 1) + kKeyWeight - 1)  // 44-46 bases: seeds reach past the end of the read
         ghost_bits(a.packed, a.lens, r, L, a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits);
 
-      uint4 *pre_rows = nullptr;
-      if constexpr (PRE) {
-        pre_rows = a.pre_out + static_cast<u64>(blockIdx.x) * 4u * a.pre_stride;
-        const u32 n_spec = specific_offsets(a.ix, L);
-        const bool use_ext = tables_apply(a.ix, L);
-        u32 probes = 0, iters = 0;
-        long long tp0 = 0, tp1 = 0;
-        ABM_STAMP(tp0);
-        for (u32 cidx = 0; cidx < n_calls; ++cidx) {
-          const bool rc = (call_rc >> cidx) & 1u, ar = (call_ar >> cidx) & 1u;
-          const bool g_to_a = rc != ar;
-          const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
-          for (u32 g0 = 0; g0 < n_spec; g0 += 64) {
-            const u32 i = g0 + lane;
-            if (i < n_spec) {
-              uint4 e;
-              probe_offset<true, true>(a.ix, lds, enc, g_to_a, L, i, use_ext, e.x, e.y, e.z, e.w, probes);
-              pre_rows[cidx * a.pre_stride + i] = e;
-              ++iters;
-            }
-          }
-        }
-        wt.probes += probes;
-        wt.seed_iters += iters;
-        wave_sync();
-        ABM_STAMP(tp1);
-        if (TIMED) wt.t_probe += tp1 - tp0;
-      }
       SeSet S;
       S.begin_read(L);
       for (u32 cidx = 0; cidx < n_calls; ++cidx) {
@@ -243,8 +214,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        seed_pass<true, TIMED, COOP, SeSet, PRE>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch,
-                                                 PRE ? pre_rows + cidx * a.pre_stride : nullptr);
+        seed_pass<true, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         // should_do_sensitive, :367-370
         if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
           S.cutoff = S.top_d();  // set_sensitive
@@ -252,7 +222,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         }
       }
       ABM_STAMP(t_a);
-      choose_se<LONG>(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln, n_single);
+      choose_se<LONG>(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln, n_single);  // (n_aln, n_single: dead unless TIMED)
       ABM_STAMP(t_b);
       if (TIMED) wt.t_align += t_b - t_a;
     }
@@ -262,7 +232,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       if (TIMED && a.read_cycles) a.read_cycles[r] = static_cast<u32>((clock64() - t_read) >> 10);
     }
   }
-  if (a.work) {  // exact per-launch work tallies for the roofline model
+  if (TIMED && a.work) {  // exact work tallies for the roofline model: kept by the diagnostic build only (see seed_pass)
     auto wsum = [&](u32 v) { u32 t; (void)wave_excl_sum(v, t); return t; };
     const u32 s0 = wsum(wt.seed_iters), s1 = wsum(wt.probes), s2 = wsum(wt.cands), s3 = wsum(wt.words);
     const u32 wsum_hits = wsum(wt.cache_hits);
@@ -301,9 +271,8 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
 }
 
 // (the launch bound's second argument is waves per SIMD: 5 x 4 SIMDs = 20 one-wave workgroups per CU)
-template <bool TIMED, bool COOP, bool PRE>
-__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false, PRE>(a); }
-
+template <bool TIMED, bool COOP>
+__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false>(a); }
 __global__ __launch_bounds__(64, 1) void map_se_long_kernel(SeArgs a) { map_se_body<false, false, true>(a); }
 
 // reads of this batch that the long-read launch takes: kLdsReadLen < length <= kMaxReadLen
@@ -498,7 +467,7 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   const size_t lds = se_lds_bytes(W, WB, cig_stride, max_len, valid_frac);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true, false>, 64, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true>, 64, lds) != hipSuccess) return 0;
   // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): what matters is waves without
   // register spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
   // window loads with 8 rounds in flight, 16 waves at 128 registers 1029 ms (20 waves at 96 with spills:
@@ -560,19 +529,14 @@ hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, bool timed, hipStre
   if (a.n_reads == 0) return hipSuccess;
   const size_t lds = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
-  // COOP: lanes share a candidate's window on the bit planes (a.G != 0); otherwise one lane per window.
-  // a.pre != null: the specific passes start from the seed pre-pass kernel's buckets (bit-plane kernels only).
-  if (a.G != 0 && a.pre != nullptr) {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, true>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, true, true>), dim3(blocks), dim3(64), lds, st, a);
-  }
-  else if (a.G != 0) {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, false>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, true, false>), dim3(blocks), dim3(64), lds, st, a);
+  // COOP: lanes share a candidate's window on the bit planes (a.G != 0); otherwise one lane per window
+  if (a.G != 0) {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
   }
   else {
-    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false, false>), dim3(blocks), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((map_se_kernel<false, false, false>), dim3(blocks), dim3(64), lds, st, a);
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, false>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, false>), dim3(blocks), dim3(64), lds, st, a);
   }
   return hipGetLastError();
 }

@@ -22,9 +22,6 @@ struct SeArgs {
   u32 *cig;           // [n][cig_stride]
   u32 cig_stride;
   u32 ctmp_cap;       // LDS scratch for a CIGAR's ops: longest read + 2
-  const uint4 *pre;   // non-null: the kernel variant whose reads start with a probing prologue (map_se_body, PRE) ...
-  uint4 *pre_out;     // ... which leaves {lo2, na, lo3, nb} per (call, offset) here: [grid waves][4 calls][pre_stride]
-  u32 pre_stride;     // entries per call: the longest read's specific offsets
   u8 *long_tb;        // long-read launch only: per-wave traceback tables (long_tb_bytes each) ...
   u32 *long_ctmp;     // ... and CIGAR scratch (ctmp_cap rounded up to even, per wave), in global memory
   u64 long_tb_bytes;

@@ -848,7 +848,26 @@ def main():
     #  * "strict": the counts of the reference algorithm -- the oracle's counters on the cpu-baseline
     #    sample of this very batch, full_compare's early exit included (W = words touched before the
     #    running sum passes the cutoff).  `achieved`/`frac` use the strict figure when it is available.
-    per_launch = {k: v / max(1, launches) for k, v in work.items() if not isinstance(v, dict)}
+    # The production kernel keeps no work tallies (they cost it registers); counts and phase shares come from ONE more
+    # step through the diagnostic build of the kernel (tallies + s_memtime stamps), after the timed region, on a batch
+    # the timed steps mapped as well.  Shares are applied to the real kernel's duration.
+    phases = None
+    ctx.take_work()
+    ctx.set_phase_stamps(True)
+    step()
+    torch.cuda.synchronize()
+    work = ctx.take_work()
+    ctx.set_phase_stamps(False)
+    blob = blobs[(issued[0] - 1) % n_batches]  # (the output buffers now hold this step's results: what the oracle is compared with)
+    long_arena = ctx.long_cigars()
+    pc = work.get("phase_cycles")
+    if pc and not args.no_stage_split:
+        phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
+        # (filter steps of 128 candidates per read, those holding at most 64, set updates applied as runs of ties)
+        phases["filter_steps_per_read"] = round(work.get("filter_steps", 0) / n, 2)
+        phases["light_filter_steps_per_read"] = round(work.get("light_filter_steps", 0) / n, 2)
+        phases["tie_run_updates_per_read"] = round(work.get("fifo_updates", 0) / n, 2)
+    per_launch = {k: float(v) for k, v in work.items() if not isinstance(v, dict)}
     bw_band = 2 * int(0.1 * L) + 1
     nwords = (L + 15) // 16
     ops_per_read = float(cig_n[mapped].sum().item()) / n
@@ -933,24 +952,6 @@ def main():
                                       "C": round(o_work["candidates"] / nr, 2), "W": round(o_work["words"] / nr, 2),
                                       "A": round((o_work["aligns"] + o_work["aligns_tb"]) / nr, 2), "ops": round(o_ops, 3)},
                   "words_per_candidate": round(o_work["words"] / max(1, o_work["candidates"]), 3)}
-
-    # per-stage shares: one more step through the diagnostic (s_memtime-stamped) build of the kernel,
-    # after the timed region; its SHARES are applied to the real kernel's duration
-    phases = None
-    if (args.phase_stamps or (not args.no_stage_split and world == 1)) and rank == 0:
-        ctx.take_work()
-        ctx.set_phase_stamps(True)
-        step()
-        torch.cuda.synchronize()
-        wk = ctx.take_work()
-        pc = wk.get("phase_cycles")
-        ctx.set_phase_stamps(False)
-        if pc:
-            phases = {k: round(v / max(1, pc["total"]), 4) for k, v in pc.items() if k != "total"}
-            # (filter steps of 128 candidates per read, those holding at most 64, set updates applied as runs of ties)
-            phases["filter_steps_per_read"] = round(wk.get("filter_steps", 0) / n, 2)
-            phases["light_filter_steps_per_read"] = round(wk.get("light_filter_steps", 0) / n, 2)
-            phases["tie_run_updates_per_read"] = round(wk.get("fifo_updates", 0) / n, 2)
 
     basis = "strict" if strict else "kernel_tally"
     use_bytes, use_stage = (strict["bytes_per_read"], strict["stage"]) if strict else (k_bytes, k_stage)

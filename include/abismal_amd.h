@@ -183,8 +183,9 @@ uint64_t abm_ctx_reads_too_long(abm_ctx *ctx);
    0 = the nibble array, one lane per window (genomes with IUPAC letters).  Results are the same; the rate is not. */
 int abm_ctx_filter_on_planes(const abm_ctx *ctx);
 
-/* Measurement hook (no reference counterpart): exact work tallies accumulated
- * by every launch on this context since the previous call, then reset:
+/* Measurement hook (no reference counterpart): exact work tallies accumulated by the launches on this context since
+ * the previous call, then reset -- of the paired-end kernels always, of the single-end kernel only in its diagnostic
+ * build (abm_ctx_set_phase_stamps: the production kernel keeps none, they cost it registers):
  * [0] seed offsets probed, [1] bucket-narrowing search probes, [2] candidates
  * compared, [3] read words compared, [4] candidate-set updates, [5] alignments.
  * Feeds the algorithmic-bytes model of SURVEY.md section 8(d). */

@@ -17,6 +17,9 @@ hdr = next(csv.reader(open(os.path.join(src, "pmc_header.csv"))))
 cnt, secs = {}, None
 for row in csv.reader(open(os.path.join(src, "pmc_rdreq_map_se.csv"))):
     r = dict(zip(hdr, row))
+    # the production kernel only (the diagnostic build runs once after it, for the work tallies), its first dispatch
+    if "map_se_kernel<false" not in r["Kernel_Name"] or r["Counter_Name"] in cnt:
+        continue
     cnt[r["Counter_Name"]] = int(float(r["Counter_Value"]))
     secs = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 pmc_line = json_line(os.path.join(src, "bench_line_under_pmc.log"))

@@ -62,12 +62,20 @@ const char *experiment_env(const char *name) {
   return on ? std::getenv(name) : nullptr;
 }
 
+// A buffer that grows frees its old allocation, and hipFree / hipHostFree wait for the whole device (the other context's
+// mapping kernel included) holding the runtime's lock: abm_ctx_reserve exists so that it never happens mid-run, and
+// ABM_TRACE_HOST=1 reports it if it does.
+void note_regrowth(const char *what, size_t from, size_t to) {
+  if (std::getenv("ABM_TRACE_HOST") != nullptr)
+    std::fprintf(stderr, "[abm host] %s buffer regrown %zu -> %zu bytes (frees wait for the device)\n", what, from, to);
+}
+
 template <class T> struct DevBuf {  // grow-only device allocation
   T *p = nullptr;
   size_t cap = 0;
   void reserve(size_t n) {
     if (n <= cap) return;
-    if (p) HIPCHK(hipFree(p));
+    if (p) { note_regrowth("device", cap * sizeof(T), n * sizeof(T)); HIPCHK(hipFree(p)); }
     p = nullptr; cap = 0;
     HIPCHK(hipMalloc(&p, n * sizeof(T)));
     cap = n;
@@ -81,7 +89,7 @@ template <class T> struct HostBuf {
   size_t cap = 0;
   void reserve(size_t n) {
     if (n <= cap) return;
-    if (p) HIPCHK(hipHostFree(p));
+    if (p) { note_regrowth("pinned host", cap * sizeof(T), n * sizeof(T)); HIPCHK(hipHostFree(p)); }
     p = nullptr; cap = 0;
     // (portable + mapped: kernels of whichever device the context lives on write results straight into these buffers)
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocPortable | hipHostMallocMapped));
@@ -1128,7 +1136,10 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
       ctx->packed.reserve(n * 4 * W); ctx->lens.reserve(n); ctx->order.reserve(n); ctx->cls.reserve(n); ctx->class33.reserve(33);
       ctx->cig.reserve(n * stride); ctx->cig_n.reserve(n); ctx->status.reserve(1);
       ctx->cig_arena.reserve(std::max<size_t>(1u << 16, (paired ? 2 : 1) * n)); ctx->cig_arena_count.reserve(1);
-      ctx->h_cn.reserve(n); ctx->h_slots.reserve(n * stride); ctx->h_arena.reserve(1u << 16);
+      ctx->h_cn.reserve(n); ctx->h_slots.reserve(n * stride);
+      // (what se_device asks for: growing any buffer later frees the old one, and hipFree / hipHostFree wait for the whole
+      // device -- i.e. for the other context's mapping kernel -- with the runtime's lock held)
+      ctx->h_arena.reserve(std::max<size_t>({ctx->arena_want, size_t(1) << 16, static_cast<size_t>(n)}));
       if (!paired) { ctx->res.reserve(n); ctx->h_res.reserve(n); }
       else {
         ctx->blob2.reserve(n * L); ctx->off2.reserve(n + 1);

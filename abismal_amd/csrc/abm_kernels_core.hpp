@@ -952,6 +952,62 @@ __device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job,
   }
 }
 
+// The traceback run row by row: ONE job on lanes [0, bw), every lane computes its cell of row i in the same step
+// (the anti-diagonal schedule keeps a lone job's lanes idle every other step).  The one dependency inside a row --
+// from_left, c(i,j) = max(base(i,j), c(i,j-1) - 4) -- unrolls to c(i,j) = max over k <= j of base(i,k) - 4 (j - k), an
+// inclusive running maximum of base + 4 k over the band's lanes: ceil(log2 bw) DPP steps (two for the band of three
+// a read with one mismatch gets).  Cells left of the read (q < 0) compute to 0 like the reference's zero-filled
+// table, cells right of it (q >= L) cannot reach a valid cell through from_left and are masked when published.
+// Arrows as the reference decides them: left wins ties, then above, then the diagonal.  Same table, scores, first
+// maximum per column as wavefront<TB>; 32-bit scores (the long-read kernel keeps wavefront<TB, true>).
+template <bool TB>
+__device__ __forceinline__ void wavefront_rows(const WaveLds &lds, const AlnJob &job, int L, int bw, int &bestv,
+                                               int &bestrow) {
+  const int jl = job.jl;
+  const bool assigned = job.bw != 0;
+  const u64 *qw = lds.qpk + job.qoff;
+  const u64 *gw = lds.gwin + job.g * lds.GW;
+  const int off4 = 4 * jl;
+  const bool up_lane = assigned && jl < bw - 1;
+  const int rows = L + bw;
+  int cur = 0;
+  u64 M = 0;
+  bestv = 0; bestrow = 0;
+  for (int i = 0; i < rows; ++i) {
+    if ((i & 15) == 0) {  // match bits of this lane's next 16 rows
+      u64 x = 0;
+      if (assigned)
+        x = nibbles16(qw, static_cast<int>(lds.W), i + jl - bw) & nibbles16(gw, static_cast<int>(lds.GW), job.t0nib + i - 1);
+      x |= x >> 1;
+      x |= x >> 2;
+      M = x & 0x1111111111111111ull;
+    }
+    const int q = i + jl - bw;
+    const bool valid = assigned && q >= 0 && q < L;
+    const int up = from_next_lane(cur) - 4;
+    const int sdiag = cur + ((static_cast<u32>(M) & 1u) ? 2 : -3);
+    M >>= 4;
+    int base = max(sdiag, 0);
+    int arrow = (base == sdiag) ? 0 : 3;
+    if (up_lane && q < L - 1) {  // from_above
+      base = max(base, up);
+      if (TB && base == up) arrow = 2;
+    }
+    u32 x = static_cast<u32>(base + off4);  // (>= 0: the scans' identity 0 never wins)
+    if (bw > 1) x = max(x, dpp_from<0x111, 0xf>(0u, x));
+    if (bw > 2) x = max(x, dpp_from<0x112, 0xf>(0u, x));
+    if (bw > 4) x = max(x, dpp_from<0x114, 0xf>(0u, x));
+    if (bw > 8) x = max(x, dpp_from<0x118, 0xf>(0u, x));
+    if (bw > 16) x = max(x, dpp_from<0x142, 0xa>(0u, x));
+    if (bw > 32) x = max(x, dpp_from<0x143, 0xc>(0u, x));
+    const int c = static_cast<int>(x) - off4;
+    if (TB && c == from_prev_lane(c) - 4) arrow = 1;  // from_left (an invalid or missing neighbour offers -4)
+    cur = valid ? c : 0;
+    if (valid && c > bestv) { bestv = c; bestrow = i; }
+    if (TB && assigned) lds.tb[i * bw + jl] = static_cast<u8>(valid ? (arrow | (c > 0 ? 4 : 0)) : 3);
+  }
+}
+
 // where CIGARs go: fixed slots of `stride` ops per read; one with more ops goes whole into the launch's
 // overflow arena (bump-allocated), its slot's first word = where, and its count (> stride) says so
 struct CigarSink {
@@ -1303,7 +1359,8 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   stage_windows(ix, lds, 0, 1, md);
   wave_sync();
   int bv, brow;
-  wavefront<true, WRAP>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
+  if constexpr (WRAP) wavefront<true, true>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
+  else wavefront_rows<true>(lds, job, static_cast<int>(L), bw, bv, brow);
   // first maximum in row-major order: max value, then smallest row, then smallest column
   const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
                   (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |

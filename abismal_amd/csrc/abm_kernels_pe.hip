@@ -319,7 +319,7 @@ template <bool BIG, bool COOP> struct PeWave {
       stage_windows(a.ix, lds, 0, 1, md);
       wave_sync();
       int bv, brow;
-      wavefront<true>(lds, job, Ln, bw, bw, bv, brow);
+      wavefront_rows<true>(lds, job, Ln, bw, bv, brow);
       const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
                       (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |
                       static_cast<u64>(0xFFu - static_cast<u32>(lane));

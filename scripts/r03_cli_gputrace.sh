@@ -10,6 +10,7 @@ mkdir -p $WD gpurun_out
 CLI=$REPO/abismal_amd/abismal-amd
 IDX=/tmp/abismal_bench/g3100.idx
 FA=/tmp/abismal_bench/g3100.fa
+[ -f $FA ] || python3 -c "import sys; sys.path.insert(0, '$REPO'); import torch, bench; bench.synth_genome_fasta('$FA', 3100, 1234, torch.device('cuda', 0))"
 [ -f $WD/reads_1.fq ] || $CLI sim -single -seed 1 -n 10000000 -l 100 -m 0.01 -b 0.98 -o $WD/reads $FA > /dev/null
 cd /tmp
 rm -rf /tmp/prof_cli

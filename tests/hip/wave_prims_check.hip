@@ -41,6 +41,42 @@ __global__ __launch_bounds__(64) void locate(const u32 *na, const u32 *nb, const
   }
 }
 
+
+// wavefront_rows<true> against wavefront<true>: one random job per block -- read and window words, length, band --
+// run through both; every cell the anti-diagonal run writes must hold the same arrow byte in the row-by-row run's
+// table, and the per-lane best value and row must agree.
+__global__ __launch_bounds__(64) void rows_vs_antidiagonal(const u64 *qwords, const u64 *gwords, const int *Ls, const int *bws,
+                                                           const int *t0s, u32 W, u32 GW, u32 *bad) {
+  extern __shared__ unsigned char smem[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int L = Ls[b], bw = bws[b];
+  const size_t tb_bytes = static_cast<size_t>(L + bw) * bw;
+  u64 *q = reinterpret_cast<u64 *>(smem);
+  u64 *g = q + W;
+  u8 *tb_a = reinterpret_cast<u8 *>(g + GW);
+  u8 *tb_b = tb_a + ((tb_bytes + 15) & ~size_t(15));
+  for (u32 k = lane; k < W; k += 64) q[k] = qwords[b * W + k];
+  for (u32 k = lane; k < GW; k += 64) g[k] = gwords[b * GW + k];
+  for (size_t k = lane; k < tb_bytes; k += 64) { tb_a[k] = 0xEE; tb_b[k] = 0xEE; }
+  __syncthreads();
+  WaveLds lds{};
+  lds.qpk = q; lds.gwin = g; lds.W = W; lds.GW = GW;
+  AlnJob job = {0, 0, 0, 0, 0};
+  if (lane < bw) { job.bw = bw; job.jl = lane; job.t0nib = t0s[b]; }
+  int va, ra, vb, rb;
+  lds.tb = tb_a;
+  wavefront<true>(lds, job, L, bw, bw, va, ra);
+  __syncthreads();
+  lds.tb = tb_b;
+  wavefront_rows<true>(lds, job, L, bw, vb, rb);
+  __syncthreads();
+  u32 wrong = 0;
+  if (lane < bw && (va != vb || ra != rb)) ++wrong;
+  for (size_t k = lane; k < tb_bytes; k += 64)
+    if (tb_a[k] != 0xEE && tb_a[k] != tb_b[k]) ++wrong;
+  if (wrong) atomicAdd(&bad[b], wrong);
+}
+
 static u32 rnd(u32 &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
 
 int main() {
@@ -106,6 +142,46 @@ int main() {
       std::printf("locate mismatch block %zu candidate %zu: segment %u/%u entry %u/%u\n", k / cap, k % cap, gseg[k], eseg[k], gent[k], eent[k]);
       return 1;
     }
-  std::printf("OK %d scan blocks, %u flattened blocks\n", B, NB);
+  // wavefront_rows vs wavefront
+  const int NJ = 3000;
+  const u32 QW = 10, QGW = 16;  // up to 160 read bases, windows of 256 bases
+  std::vector<u64> qv(static_cast<size_t>(NJ) * QW), gv(static_cast<size_t>(NJ) * QGW);
+  std::vector<int> jl(NJ), jb(NJ), jt(NJ);
+  const u32 enc[4] = {1u, 2u, 4u, 10u};  // T-rich read letters (A, C, G, T->T|C... as bisulfite nibbles)
+  for (int j = 0; j < NJ; ++j) {
+    const int L = 40 + static_cast<int>(rnd(seed) % 121);
+    const int bw = 2 * static_cast<int>(rnd(seed) % (j % 3 == 0 ? 31 : 6)) + 1;
+    jl[j] = L; jb[j] = bw; jt[j] = static_cast<int>(rnd(seed) % 16);
+    // the window: random genome letters (one-hot nibbles); the read: the window's diagonal with mutations and an indel
+    std::vector<u32> gl(QGW * 16), ql(QW * 16, 0u);
+    for (auto &x : gl) x = 1u << (rnd(seed) % 4);
+    int shift = jt[j] + (bw - 1) / 2, at = 0;
+    const int indel_at = static_cast<int>(rnd(seed) % static_cast<u32>(L)), indel = static_cast<int>(rnd(seed) % 5) - 2;
+    for (int k = 0; k < L; ++k) {
+      if (k == indel_at) at += indel;
+      const int gi = shift + k + at;
+      u32 letter = (gi >= 0 && gi < static_cast<int>(gl.size())) ? gl[gi] : 1u;
+      if (rnd(seed) % 12 == 0) letter = 1u << (rnd(seed) % 4);
+      ql[k] = letter == 8u ? 10u : letter;  // (a read T matches genome T and C)
+    }
+    for (u32 w = 0; w < QW; ++w) { u64 x = 0; for (int k = 0; k < 16; ++k) x |= static_cast<u64>(ql[w * 16 + k]) << (4 * k); qv[static_cast<size_t>(j) * QW + w] = x; }
+    for (u32 w = 0; w < QGW; ++w) { u64 x = 0; for (int k = 0; k < 16; ++k) x |= static_cast<u64>(gl[w * 16 + k]) << (4 * k); gv[static_cast<size_t>(j) * QGW + w] = x; }
+  }
+  (void)enc;
+  u64 *d_q, *d_g;
+  int *d_L, *d_bw, *d_t0;
+  u32 *d_bad;
+  hipMalloc(&d_q, qv.size() * 8); hipMalloc(&d_g, gv.size() * 8); hipMalloc(&d_L, NJ * 4); hipMalloc(&d_bw, NJ * 4); hipMalloc(&d_t0, NJ * 4); hipMalloc(&d_bad, NJ * 4);
+  hipMemcpy(d_q, qv.data(), qv.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_g, gv.data(), gv.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(d_L, jl.data(), NJ * 4, hipMemcpyHostToDevice); hipMemcpy(d_bw, jb.data(), NJ * 4, hipMemcpyHostToDevice); hipMemcpy(d_t0, jt.data(), NJ * 4, hipMemcpyHostToDevice);
+  hipMemset(d_bad, 0, NJ * 4);
+  const size_t smem = (QW + QGW) * 8 + 2 * (((160 + 61) * 61 + 15) & ~15);
+  hipLaunchKernelGGL(rows_vs_antidiagonal, dim3(NJ), dim3(64), smem, 0, d_q, d_g, d_L, d_bw, d_t0, QW, QGW, d_bad);
+  std::vector<u32> gbad(NJ);
+  hipMemcpy(gbad.data(), d_bad, NJ * 4, hipMemcpyDeviceToHost);
+  if (hipDeviceSynchronize() != hipSuccess) { std::printf("rows kernel failed\n"); return 1; }
+  for (int j = 0; j < NJ; ++j)
+    if (gbad[j]) { std::printf("rows mismatch job %d (L %d band %d t0 %d): %u cells/lanes differ\n", j, jl[j], jb[j], jt[j], gbad[j]); return 1; }
+  std::printf("OK %d scan blocks, %u flattened blocks, %d traceback tables\n", B, NB, NJ);
   return 0;
 }

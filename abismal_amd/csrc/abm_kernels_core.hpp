@@ -960,6 +960,10 @@ __device__ __forceinline__ void wavefront(const WaveLds &lds, const AlnJob &job,
 // table, cells right of it (q >= L) cannot reach a valid cell through from_left and are masked when published.
 // Arrows as the reference decides them: left wins ties, then above, then the diagonal.  Same table, scores, first
 // maximum per column as wavefront<TB>; 32-bit scores (the long-read kernel keeps wavefront<TB, true>).
+#ifndef ABM_TB_ROWS
+#define ABM_TB_ROWS true  // (false: the traceback run on the anti-diagonal schedule, for same-box comparisons)
+#endif
+constexpr bool kTracebackByRows = ABM_TB_ROWS;
 template <bool TB>
 __device__ __forceinline__ void wavefront_rows(const WaveLds &lds, const AlnJob &job, int L, int bw, int &bestv,
                                                int &bestrow) {
@@ -1266,6 +1270,169 @@ __device__ __forceinline__ int score_round(const DevIndex &ix, const WaveLds &ld
   return s;
 }
 
+// ---- scoring runs, four jobs per slot of lanes ----------------------------------------
+// Scores fit 16 bits (2 L <= 2048 in these kernels), so a lane can carry TWO jobs of a set in the halves of one
+// register and advance both with one packed instruction (v_pk_add_i16 / v_pk_max_i16): with the two sets of the
+// anti-diagonal schedule that is four jobs per slot.  For the halves to share the lane's control flow the slot is laid
+// out around the band's centre: lane offset o, c = o - K (K = the slot's half width, its widest job's), and a job of
+// half width k <= K owns the lanes |c| <= k.  In these coordinates the read index q = i + o - width and the row's
+// target base pos + i - K - 1 are the same for every job of the slot (the reference's column is j = c + k, its row
+// i_ref = i - (K - k): q_ref = i_ref + j - bw = q, target = t_beg + i_ref - 1), so validity by q, the row clock and the DPP
+// moves are shared, and what differs per job is loop-invariant: the band mask (halves 0xFFFF inside the job's band), the
+// edge masks of from_above (c < k) and from_left (c > -k), and the offset of its staged window (row 1's target base
+// sits K - k nibbles earlier).  A masked-off candidate is 0, which never beats a cell value (>= 0).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) {
+  return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+// maximum of both halves over the wave (values >= 0), uniform
+__device__ __forceinline__ u32 wave_max_pk(u32 x) {
+  x = pk_max(x, dpp_from<0x111, 0xf>(0u, x));
+  x = pk_max(x, dpp_from<0x112, 0xf>(0u, x));
+  x = pk_max(x, dpp_from<0x114, 0xf>(0u, x));
+  x = pk_max(x, dpp_from<0x118, 0xf>(0u, x));
+  x = pk_max(x, dpp_from<0x142, 0xa>(0u, x));
+  x = pk_max(x, dpp_from<0x143, 0xc>(0u, x));
+  return rdlane(x, 63);
+}
+
+struct QuadJob {         // per lane: the two jobs of one set that share this lane's slot (low half, high half)
+  u32 mv, ma, ml;        // halves 0xFFFF: lane inside the job's band / may take from_above / may take from_left
+  int qoff_lo, qoff_hi;  // word offsets of the query encodings in lds.qpk
+  int g_lo, g_hi;        // genome-window slots in lds.gwin
+  int gs_lo, gs_hi;      // nibble index of row 1's target base in the window, moved to the slot's band
+};
+
+__device__ __forceinline__ void wavefront_quad(const WaveLds &lds, const QuadJob &jp, const QuadJob &jq, int dp, int dq,
+                                               int o, int width, int L, int w_min, int w_max, u32 &bestp, u32 &bestq) {
+  const int t_start = max(0, w_min - 1), t_end = 2 * (L - 1 + w_max) + 1;
+  u32 curp = 0, curq = 0, pub = 0;
+  u64 Mp = 0, Mq = 0;
+  bestp = bestq = 0;
+  const int W = static_cast<int>(lds.W), GW = static_cast<int>(lds.GW);
+  auto refill = [&](const QuadJob &j, int time) -> u64 {
+    const int i0 = (time - o) >> 1;
+    const int qs = i0 + o - width;
+    u64 lo = 0, hi = 0;
+    if (j.mv & 0xFFFFu) lo = nibbles16(lds.qpk + j.qoff_lo, W, qs) & nibbles16(lds.gwin + j.g_lo * GW, GW, j.gs_lo + i0 - 1);
+    if (j.mv >> 16) hi = nibbles16(lds.qpk + j.qoff_hi, W, qs) & nibbles16(lds.gwin + j.g_hi * GW, GW, j.gs_hi + i0 - 1);
+    lo |= lo >> 1; lo |= lo >> 2;
+    hi |= hi >> 1; hi |= hi >> 2;
+    return (lo & 0x1111111111111111ull) | ((hi & 0x1111111111111111ull) << 1);
+  };
+  auto cell = [&](const QuadJob &j, int time, u32 &cur, u64 &M, u32 &best) {
+    const int i = (time - o) >> 1;
+    const int q = i + o - width;
+    const u32 lf = static_cast<u32>(from_prev_lane(static_cast<int>(pub))), up = static_cast<u32>(from_next_lane(static_cast<int>(pub)));
+    const u32 x = static_cast<u32>(M);
+    const u32 delta = 0xFFFDFFFDu ^ ((x & 1u) ? 0x0000FFFFu : 0u) ^ ((x & 2u) ? 0xFFFF0000u : 0u);  // halves: +2 on a match, -3 otherwise
+    u32 c = pk_max(pk_add(cur, delta), 0u);
+    c = pk_max(c, pk_add(up, 0xFFFCFFFCu) & (q < L - 1 ? j.ma : 0u));  // from_above
+    c = pk_max(c, pk_add(lf, 0xFFFCFFFCu) & (q > 0 ? j.ml : 0u));      // from_left
+    M >>= 4;
+    cur = static_cast<u32>(q) < static_cast<u32>(L) ? (c & j.mv) : 0u;
+    best = pk_max(best, cur);
+    pub = cur;
+  };
+  for (int t = t_start; t <= t_end; t += 2) {
+    if (((t - t_start) & 31) == 0) {
+      Mp = refill(jp, t - dp);
+      Mq = refill(jq, t + 1 - dq);
+    }
+    cell(jp, t - dp, curp, Mp, bestp);
+    cell(jq, t + 1 - dq, curq, Mq, bestq);
+  }
+}
+
+// score_round with four jobs per slot: job first+4m+h of slot m is set (h & 1), half (h >> 1)
+__device__ __forceinline__ int score_round_quad(const DevIndex &ix, const WaveLds &lds, int first, int n_jobs, int L, int md,
+                                                int qbase) {
+  const int lane = lane_id();
+  QuadJob ja = {0, 0, 0, 0, 0, 0, 0, 0, 0}, jb = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int used = 0, s = first, w_min = 64, w_max = 0, my_o = 0, my_w = 0;
+  while (s < n_jobs) {
+    const int cnt = min(4, n_jobs - s);
+    if (s - first + cnt > static_cast<int>(lds.max_jobs)) break;
+    int bwh[4], width = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      bwh[h] = h < cnt ? band_for(static_cast<int>(lds.jdf[s + h]) >> 16, md) : 0;
+      width = max(width, bwh[h]);
+    }
+    if (used + width > 64) break;
+    const int o = lane - used, K = (width - 1) / 2, c = o - K;
+    const bool in = o >= 0 && o < width;
+    if (in) { my_o = o; my_w = width; }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h >= cnt) break;
+      const int k = (bwh[h] - 1) / 2;
+      if (in && c >= -k && c <= k) {
+        const u32 df = lds.jdf[s + h];
+        const u64 t_beg = static_cast<u64>(lds.jpos[s + h]) - static_cast<u64>(k);
+        const u32 half = (h >> 1) ? 0xFFFF0000u : 0x0000FFFFu;
+        QuadJob &j = (h & 1) ? jb : ja;
+        j.mv |= half;
+        if (c < k) j.ma |= half;
+        if (c > -k) j.ml |= half;
+        const int qoff = qbase + static_cast<int>(enc_of(df & 0xFFFFu) * lds.W);
+        const int gs = static_cast<int>(t_beg & 15u) - (K - k);
+        if (h >> 1) { j.qoff_hi = qoff; j.g_hi = s + h - first; j.gs_hi = gs; }
+        else { j.qoff_lo = qoff; j.g_lo = s + h - first; j.gs_lo = gs; }
+      }
+    }
+    used += width;
+    w_min = min(w_min, width);
+    w_max = max(w_max, width);
+    s += cnt;
+  }
+  stage_windows(ix, lds, first, s - first, md);
+  wave_sync();
+  const int t_start = max(0, w_min - 1);
+  const bool even = ((t_start - my_o) & 1) == 0;  // which of the lane's sets is due on even steps
+  u32 bp, bq;
+  wavefront_quad(lds, even ? ja : jb, even ? jb : ja, even ? 0 : 1, even ? 1 : 0, my_o, my_w, L, w_min, w_max, bp, bq);
+  const u32 best_a = even ? bp : bq, best_b = even ? bq : bp;
+  int base = 0, mine = 0;
+  for (int k = first; k < s;) {
+    const int cnt = min(4, s - k);
+    int width = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      if (h < cnt) width = max(width, band_for(static_cast<int>(lds.jdf[k + h]) >> 16, md));
+    const bool in = lane >= base && lane < base + width;
+    const u32 xa = wave_max_pk(in ? best_a : 0u), xb = cnt > 1 ? wave_max_pk(in ? best_b : 0u) : 0u;
+    if (lane == k - first) mine = static_cast<int>(xa & 0xFFFFu);
+    if (lane == k + 1 - first && cnt > 1) mine = static_cast<int>(xb & 0xFFFFu);
+    if (lane == k + 2 - first && cnt > 2) mine = static_cast<int>(xa >> 16);
+    if (lane == k + 3 - first && cnt > 3) mine = static_cast<int>(xb >> 16);
+    base += width;
+    k += cnt;
+  }
+  wave_sync();
+  lds.lbest[lane] = mine;
+  wave_sync();
+  return s;
+}
+
+// a round of scoring runs: four jobs per slot (packed cells) when at least kQuadMinJobs are left, else two (plain cells);
+// the long-read kernel's 16-bit wrapping arithmetic stays on the plain cells.  The packed cell costs a quarter more
+// than the plain one, so by instruction count it pays from a slot's third job on -- but the kernel that holds only one
+// of the two loops is the faster one (10 M reads, same box, profiles/r03_exp_quad_scoring.log: never 701-712 ms, from
+// three jobs on 685-695 ms, always 678-681 ms).
+#ifndef ABM_QUAD_MIN_JOBS
+#define ABM_QUAD_MIN_JOBS 1
+#endif
+constexpr int kQuadMinJobs = ABM_QUAD_MIN_JOBS;
+template <bool WRAP = false>
+__device__ __forceinline__ int score_jobs(const DevIndex &ix, const WaveLds &lds, int first, int n_jobs, int L, int md, int qbase) {
+  if constexpr (!WRAP) {
+    if (n_jobs - first >= kQuadMinJobs) return score_round_quad(ix, lds, first, n_jobs, L, md, qbase);
+  }
+  return score_round<WRAP>(ix, lds, first, n_jobs, L, md, qbase);
+}
+
 // align_se_candidates (src/abismal.cpp:1435-1497) on the wave-resident set
 template <bool WRAP = false>
 __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds, u32 L, double frac,
@@ -1325,7 +1492,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   }
   for (int s = 0; s < n_jobs && !single;) {
     const int first = s;
-    s = score_round<WRAP>(ix, lds, first, n_jobs, static_cast<int>(L), md, 0);
+    s = score_jobs<WRAP>(ix, lds, first, n_jobs, static_cast<int>(L), md, 0);
     // apply the reference's selection in job order
     for (int k = first; k < s; ++k) {
       const u32 df = lds.jdf[k];
@@ -1359,7 +1526,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   stage_windows(ix, lds, 0, 1, md);
   wave_sync();
   int bv, brow;
-  if constexpr (WRAP) wavefront<true, true>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
+  if constexpr (WRAP || !kTracebackByRows) wavefront<true, WRAP>(lds, job, static_cast<int>(L), bw, bw, bv, brow);
   else wavefront_rows<true>(lds, job, static_cast<int>(L), bw, bv, brow);
   // first maximum in row-major order: max value, then smallest row, then smallest column
   const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |

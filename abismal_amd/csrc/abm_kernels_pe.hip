@@ -282,7 +282,7 @@ template <bool BIG, bool COOP> struct PeWave {
         if (n_jobs == 0) break;
         for (int s = 0; s < n_jobs;) {  // rounds of side-by-side bands
           const int first = s;
-          s = score_round(a.ix, lds, first, n_jobs, static_cast<int>(L[end]), md, static_cast<int>(end * 4 * lds.W));
+          s = score_jobs(a.ix, lds, first, n_jobs, static_cast<int>(L[end]), md, static_cast<int>(end * 4 * lds.W));
           if (lane < s - first) pl.lsc[which][pl.jidx[first + lane]] = static_cast<i16>(lds.lbest[lane]);
           n_aln += static_cast<u32>(s - first);
           wave_sync();
@@ -319,7 +319,8 @@ template <bool BIG, bool COOP> struct PeWave {
       stage_windows(a.ix, lds, 0, 1, md);
       wave_sync();
       int bv, brow;
-      wavefront_rows<true>(lds, job, Ln, bw, bv, brow);
+      if constexpr (kTracebackByRows) wavefront_rows<true>(lds, job, Ln, bw, bv, brow);
+      else wavefront<true>(lds, job, Ln, bw, bw, bv, brow);
       const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
                       (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |
                       static_cast<u64>(0xFFu - static_cast<u32>(lane));

@@ -77,6 +77,41 @@ __global__ __launch_bounds__(64) void rows_vs_antidiagonal(const u64 *qwords, co
   if (wrong) atomicAdd(&bad[b], wrong);
 }
 
+// score_round_quad (four jobs per slot, packed 16-bit cells) against score_round (two per slot): random job lists --
+// positions on a random genome, Hamming counts that give every band width, all four read encodings -- scored by
+// both, job by job.
+__global__ __launch_bounds__(64) void quad_vs_pair(const u64 *genome, const u64 *qwords, const u32 *jpos_in, const u32 *jdf_in,
+                                                   const int *n_jobs_in, const int *Ls, u32 W, u32 GW, int md, int *score_pair,
+                                                   int *score_quad) {
+  extern __shared__ unsigned char smem[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  u64 *q = reinterpret_cast<u64 *>(smem);            // [4 * W]
+  u64 *gwin = q + 4 * W;                              // [kMaxJobs * GW]
+  u32 *jpos = reinterpret_cast<u32 *>(gwin + kMaxJobs * GW);
+  u32 *jdf = jpos + 64;
+  int *lbest = reinterpret_cast<int *>(jdf + 64);
+  const int n = n_jobs_in[b], L = Ls[b];
+  for (u32 k = lane; k < 4 * W; k += 64) q[k] = qwords[static_cast<size_t>(b) * 4 * W + k];
+  if (lane < n) { jpos[lane] = jpos_in[b * 64 + lane]; jdf[lane] = jdf_in[b * 64 + lane]; }
+  __syncthreads();
+  DevIndex ix{};
+  ix.genome = genome;
+  WaveLds lds{};
+  lds.qpk = q; lds.gwin = gwin; lds.jpos = jpos; lds.jdf = jdf; lds.lbest = lbest; lds.W = W; lds.GW = GW; lds.max_jobs = kMaxJobs;
+  for (int s = 0; s < n;) {
+    const int first = s;
+    s = score_round<false>(ix, lds, first, n, L, md, 0);
+    if (lane < s - first) score_pair[b * 64 + first + lane] = lbest[lane];
+    __syncthreads();
+  }
+  for (int s = 0; s < n;) {
+    const int first = s;
+    s = score_round_quad(ix, lds, first, n, L, md, 0);
+    if (lane < s - first) score_quad[b * 64 + first + lane] = lbest[lane];
+    __syncthreads();
+  }
+}
+
 static u32 rnd(u32 &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
 
 int main() {
@@ -182,6 +217,63 @@ int main() {
   if (hipDeviceSynchronize() != hipSuccess) { std::printf("rows kernel failed\n"); return 1; }
   for (int j = 0; j < NJ; ++j)
     if (gbad[j]) { std::printf("rows mismatch job %d (L %d band %d t0 %d): %u cells/lanes differ\n", j, jl[j], jb[j], jt[j], gbad[j]); return 1; }
-  std::printf("OK %d scan blocks, %u flattened blocks, %d traceback tables\n", B, NB, NJ);
+  // score_round_quad vs score_round
+  const int NQ = 2000, md = 15;
+  const u32 SW = 10, SGW = 14;   // reads of up to 160 bases; windows of 150 + 61 + 15 bases
+  const size_t GWORDS = 1u << 16;  // a genome of 1 M bases (one-hot nibbles)
+  std::vector<u64> gen(GWORDS), sq(static_cast<size_t>(NQ) * 4 * SW);
+  for (auto &x : gen) { u64 v = 0; for (int k = 0; k < 16; ++k) v |= static_cast<u64>(1u << (rnd(seed) % 4)) << (4 * k); x = v; }
+  std::vector<u32> qpos(NQ * 64, 0), qdf(NQ * 64, 0);
+  std::vector<int> qn(NQ), qL(NQ);
+  auto gn = [&](u64 k) { return static_cast<u32>(gen[k >> 4] >> ((k & 15) << 2)) & 15u; };
+  for (int b = 0; b < NQ; ++b) {
+    const int L = 60 + static_cast<int>(rnd(seed) % 91), n = 1 + static_cast<int>(rnd(seed) % 50);
+    qn[b] = n; qL[b] = L;
+    // four encodings of "the read": each a mutated copy of a genome stretch (so that scores are far from trivial)
+    const u64 origin = 1000 + rnd(seed) % (GWORDS * 16 - 4000);
+    for (int e = 0; e < 4; ++e) {
+      std::vector<u32> ql(SW * 16, 0u);
+      int drift = 0;
+      for (int k = 0; k < L; ++k) {
+        if (rnd(seed) % 40 == 0) drift += static_cast<int>(rnd(seed) % 3) - 1;
+        u32 letter = gn(origin + k + drift);
+        if (rnd(seed) % 10 == 0) letter = 1u << (rnd(seed) % 4);
+        ql[k] = (e & 1) ? (letter == 1u ? 5u : letter) : (letter == 8u ? 10u : letter);
+      }
+      for (u32 w = 0; w < SW; ++w) { u64 x = 0; for (int k = 0; k < 16; ++k) x |= static_cast<u64>(ql[w * 16 + k]) << (4 * k); sq[(static_cast<size_t>(b) * 4 + e) * SW + w] = x; }
+    }
+    for (int j = 0; j < n; ++j) {
+      const int shape = b % 4;
+      const u32 d = shape == 0 ? rnd(seed) % 40 : (shape == 1 ? 1 + rnd(seed) % 3 : (shape == 2 ? 15 + rnd(seed) % 20 : rnd(seed) % 16));
+      qpos[b * 64 + j] = static_cast<u32>(origin + static_cast<int>(rnd(seed) % 9) - 4);
+      qdf[b * 64 + j] = (d << 16) | ((rnd(seed) & 1) ? kFlagRC : 0u) | ((rnd(seed) & 1) ? kFlagARich : 0u);
+    }
+  }
+  u64 *d_gen, *d_sq;
+  u32 *d_qpos, *d_qdf;
+  int *d_qn, *d_qL, *d_sp, *d_sqd;
+  hipMalloc(&d_gen, gen.size() * 8); hipMalloc(&d_sq, sq.size() * 8); hipMalloc(&d_qpos, qpos.size() * 4); hipMalloc(&d_qdf, qdf.size() * 4);
+  hipMalloc(&d_qn, NQ * 4); hipMalloc(&d_qL, NQ * 4); hipMalloc(&d_sp, NQ * 64 * 4); hipMalloc(&d_sqd, NQ * 64 * 4);
+  hipMemcpy(d_gen, gen.data(), gen.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_sq, sq.data(), sq.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(d_qpos, qpos.data(), qpos.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_qdf, qdf.data(), qdf.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_qn, qn.data(), NQ * 4, hipMemcpyHostToDevice); hipMemcpy(d_qL, qL.data(), NQ * 4, hipMemcpyHostToDevice);
+  hipMemset(d_sp, 0xFF, NQ * 64 * 4); hipMemset(d_sqd, 0xFE, NQ * 64 * 4);
+  const size_t smem2 = (4 * SW + kMaxJobs * SGW) * 8 + 3 * 64 * 4;
+  hipLaunchKernelGGL(quad_vs_pair, dim3(NQ), dim3(64), smem2, 0, d_gen, d_sq, d_qpos, d_qdf, d_qn, d_qL, SW, SGW, md, d_sp, d_sqd);
+  std::vector<int> sp(NQ * 64), sqd(NQ * 64);
+  hipMemcpy(sp.data(), d_sp, sp.size() * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(sqd.data(), d_sqd, sqd.size() * 4, hipMemcpyDeviceToHost);
+  if (hipDeviceSynchronize() != hipSuccess) { std::printf("quad kernel failed\n"); return 1; }
+  long long jobs_checked = 0, positive = 0;
+  for (int b = 0; b < NQ; ++b)
+    for (int j = 0; j < qn[b]; ++j) {
+      if (sp[b * 64 + j] != sqd[b * 64 + j]) {
+        std::printf("quad mismatch list %d job %d of %d (L %d, diffs %u): pair %d quad %d\n", b, j, qn[b], qL[b], qdf[b * 64 + j] >> 16, sp[b * 64 + j], sqd[b * 64 + j]);
+        return 1;
+      }
+      ++jobs_checked; positive += sp[b * 64 + j] > 20;
+    }
+  if (positive * 4 < jobs_checked) { std::printf("quad check degenerate: %lld of %lld scores above 20\n", positive, jobs_checked); return 1; }
+  std::printf("OK %d scan blocks, %u flattened blocks, %d traceback tables, %lld scoring jobs\n", B, NB, NJ, jobs_checked);
   return 0;
 }

@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = [
     "abm_last_error", "abm_default_params", "abm_index_open", "abm_index_close",
     "abm_index_max_candidates", "abm_index_n_chroms", "abm_index_chrom_name",
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_reserve", "abm_ctx_destroy",
-    "abm_map_se_batch", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
+    "abm_map_se_batch", "abm_map_se_batch_sliced", "abm_ctx_slice_results", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
     "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_ctx_seed_extension",
 ]
@@ -196,6 +196,62 @@ class Context:
                                           off.ctypes.data, res.ctypes.data, cig.ctypes.data, cap,
                                           cig_off.ctypes.data))
         return res, cig[: int(cig_off[-1])], cig_off
+
+    def map_se_sliced(self, reads, slice_first, mode=SE_T_RICH, params=None):
+        """abm_map_se_batch_sliced + abm_ctx_slice_results: the batch's results taken slice by slice as the kernel
+        completes them.  slice_first: n_slices + 1 read indices (the last one len(reads)).  Returns (hits, cigar_blob,
+        cigar_off) laid out as map_se's for the reads from slice_first[0] on, and the order the slices arrived in."""
+        params = params or Params()
+        blob, off = blob_and_offsets(reads)
+        n = len(off) - 1
+        first = np.ascontiguousarray(slice_first, dtype=np.uint64)
+        n_slices = len(first) - 1
+        res = np.zeros(n, dtype=HIT_DTYPE)
+        per_slice, arrived = {}, []
+        errors = []
+
+        def on_done(_user, s):
+            try:
+                lo, hi = int(first[s]), int(first[s + 1])
+                m = hi - lo
+                h = np.zeros(max(m, 1), dtype=HIT_DTYPE)
+                co = np.zeros(m + 1, dtype=np.uint64)
+                cg = np.zeros(max(1, 4 * m), dtype=np.uint32)
+                rc = self._lib.abm_ctx_slice_results(self.handle, lo, hi, h.ctypes.data, cg.ctypes.data, len(cg), co.ctypes.data)
+                if rc == -2:  # ABM_ERR_CAPACITY: the needed size is in co[m]
+                    cg = np.zeros(int(co[m]), dtype=np.uint32)
+                    rc = self._lib.abm_ctx_slice_results(self.handle, lo, hi, h.ctypes.data, cg.ctypes.data, len(cg), co.ctypes.data)
+                _check(rc)
+                if s in per_slice:
+                    raise AbismalAmdError(f"slice {s} handed over twice")
+                per_slice[s] = (h[:m].copy(), cg[: int(co[m])].copy(), co.copy())
+                arrived.append(int(s))
+            except Exception as e:  # (never let an exception cross the C frame)
+                errors.append(e)
+
+        cb_type = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)
+        cb = cb_type(on_done)
+        self._lib.abm_map_se_batch_sliced.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                      C.c_uint32, C.c_void_p, cb_type, C.c_void_p]
+        self._lib.abm_ctx_slice_results.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        _check(self._lib.abm_map_se_batch_sliced(self.handle, mode, C.addressof(params), n, blob.ctypes.data, off.ctypes.data,
+                                                 n_slices, first.ctypes.data, cb, None))
+        if errors:
+            raise errors[0]
+        if sorted(arrived) != list(range(n_slices)):
+            raise AbismalAmdError("not every slice was handed over")
+        cig_parts, cig_off = [], np.zeros(n + 1, dtype=np.uint64)
+        at = 0
+        for s in range(n_slices):
+            lo, hi = int(first[s]), int(first[s + 1])
+            h, cg, co = per_slice[s]
+            res[lo:hi] = h
+            cig_off[lo:hi + 1] = co + at
+            at += int(co[-1])
+            cig_parts.append(cg)
+        cig_off[: int(first[0])] = 0
+        cig = np.concatenate(cig_parts) if cig_parts else np.zeros(0, dtype=np.uint32)
+        return res, cig, cig_off, arrived
 
     def map_se_device(self, mode, params, n, d_blob, d_off, max_len, d_res, d_cig, cig_stride, d_cig_n,
                       d_status, stream=0):

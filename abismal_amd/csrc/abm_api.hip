@@ -158,6 +158,14 @@ struct abm_ctx {
   HostBuf<uint64_t> h_rel, h_rel2;  // offsets relative to the batch's first read (batches that do not start at 0)
   HostBuf<abm::u32> h_tail;         // {arena count, status} of the last launch of a host-buffer entry point
   DevBuf<abm::u32> finished;
+  // results leaving slice by slice (abm_map_se_batch_sliced): slice boundaries and per-read slice numbers on the device,
+  // the reads each slice still waits for, the ordering kernels' histogram; one completion word per slice in pinned memory
+  DevBuf<abm::u32> slice_first_d, slice_left, slice_hist;
+  DevBuf<abm::u16> slice_id;
+  HostBuf<abm::u32> h_slice_first, h_slice_done;
+  uint32_t sliced_n = 0;           // slices of the launch being set up (0 = an ordinary launch)
+  uint32_t sliced_stride = 0;      // slot width of the results abm_ctx_slice_results reads
+  uint64_t sliced_reads = 0;
   bool host_results = false;        // set by abm_map_se_batch around its launches: arena and summary words in pinned memory
   HostBuf<abm_hit> h_res;           // hits on their way out (a pinned target keeps the copy on the DMA engines)
   unsigned launch_seq = 0;
@@ -350,7 +358,21 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
                                 ctx->lens.p, st));
   abm::SeArgs a{};
   a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates);
-  if (n < (1ull << 32)) {
+  const bool sliced = ctx->sliced_n != 0 && !has_long && n < (1ull << 32);
+  if (sliced) {  // (slice boundaries are uploaded by the entry point)
+    ctx->order.reserve(n);
+    ctx->cls.reserve(n);
+    ctx->slice_id.reserve(n);
+    ctx->slice_left.reserve(ctx->sliced_n);
+    ctx->slice_hist.reserve(abm::order_sliced_hist_words(ctx->sliced_n));
+    HIPCHK(abm::launch_order_reads_sliced(a.ix, ctx->packed.p, ctx->lens.p, n, W, mode, ctx->cls.p, ctx->slice_first_d.p,
+                                          ctx->sliced_n, ctx->slice_id.p, ctx->slice_hist.p, ctx->slice_left.p, ctx->order.p, st));
+    a.order = ctx->order.p;
+    a.slice_id = ctx->slice_id.p;
+    a.slice_left = ctx->slice_left.p;
+    a.slice_done = ctx->h_slice_done.p;
+  }
+  else if (n < (1ull << 32)) {
     ctx->order.reserve(n);
     ctx->cls.reserve(n);
     ctx->class33.reserve(33);
@@ -1020,6 +1042,141 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
   });
 }
 
+int abm_map_se_batch_sliced(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *seq_blob,
+                            const uint64_t *seq_off, uint32_t n_slices, const uint64_t *slice_first,
+                            abm_slice_done_fn done, void *user) {
+  return guarded([&] {
+    if (!ctx || !seq_off || !slice_first || !done || n_slices == 0) throw std::invalid_argument("null argument");
+    if (slice_first[n_slices] != n) throw std::invalid_argument("slice_first must end at n");
+    for (uint32_t s = 0; s < n_slices; ++s)
+      if (slice_first[s] > slice_first[s + 1]) throw std::invalid_argument("slice_first not monotone");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::vector<char> delivered(n_slices, 0);
+    uint32_t n_delivered = 0;
+    const uint32_t stride = 4;
+    auto deliver = [&](uint32_t s) {
+      delivered[s] = 1;
+      ++n_delivered;
+      done(user, s);
+    };
+    ctx->sliced_stride = stride;
+    ctx->sliced_reads = n;
+    if (n == 0) {
+      for (uint32_t s = 0; s < n_slices; ++s) deliver(s);
+      return;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const hipStream_t st = ctx->stream;
+    const uint64_t base = seq_off[0], bytes = seq_off[n] - base;
+    HostTrace t0;
+    const OffsetScan scan = scan_offsets(seq_off, n, ctx->h_rel);
+    const uint32_t max_len = scan.max_len;
+    ctx->too_long += scan.too_long;
+    t0.mark("  offsets scanned");
+    // slices complete while the kernel runs unless the batch holds reads of the long-read launch (which follows the
+    // ordinary one) or more slices than a 16-bit slice number holds: then they are all handed over at the end
+    const bool stream = max_len <= abm::kLdsReadLen && n_slices < 65000u && n < (1ull << 32);
+    ctx->blob.reserve(std::max<uint64_t>(bytes, 1));
+    ctx->off.reserve(n + 1);
+    ctx->status.reserve(1);
+    ctx->h_res.reserve(n);
+    ctx->h_cn.reserve(n);
+    ctx->h_slots.reserve(n * stride);
+    if (stream) {
+      ctx->h_slice_first.reserve(n_slices + 1);
+      ctx->slice_first_d.reserve(n_slices + 1);
+      ctx->h_slice_done.reserve(n_slices);
+      for (uint32_t s = 0; s <= n_slices; ++s) ctx->h_slice_first.p[s] = static_cast<abm::u32>(slice_first[s]);
+    }
+    HostTrace t2;
+    if (bytes) HIPCHK(hipMemcpyAsync(ctx->blob.p, seq_blob + base, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->off.p, scan.use, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    if (stream) HIPCHK(hipMemcpyAsync(ctx->slice_first_d.p, ctx->h_slice_first.p, (n_slices + 1) * 4ull, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    t2.mark("  H2D");
+    for (;;) {
+      HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4, st));
+      if (stream)  // (an empty slice has no read to complete it: it counts as done from the start)
+        for (uint32_t s = 0; s < n_slices; ++s)
+          __atomic_store_n(&ctx->h_slice_done.p[s], slice_first[s] == slice_first[s + 1] ? 1u : 0u, __ATOMIC_RELAXED);
+      uint32_t status = 0;
+      {
+        std::unique_lock<std::mutex> turn(*ctx->kernel_turn);
+        __atomic_store_n(ctx->drained, 0u, __ATOMIC_RELAXED);
+        ctx->signal_drained = true;
+        ctx->host_results = true;
+        ctx->sliced_n = stream ? n_slices : 0;
+        try {
+          se_device(ctx, mode, params, n, ctx->blob.p, ctx->off.p, max_len, ctx->h_res.p, ctx->h_slots.p, stride, ctx->h_cn.p,
+                    ctx->status.p, st);
+        }
+        catch (...) { ctx->host_results = false; ctx->signal_drained = false; ctx->sliced_n = 0; throw; }
+        ctx->host_results = false;
+        ctx->signal_drained = false;
+        ctx->sliced_n = 0;
+        // until the kernel is through: pass the turn on once it has handed out its last read, and hand every slice
+        // whose completion word has arrived to the caller (slices complete roughly in order: the scan starts at the
+        // first one still open)
+        uint32_t first_open = 0;
+        for (;;) {
+          const bool running = hipStreamQuery(st) == hipErrorNotReady;
+          if (turn.owns_lock() && (!running || __atomic_load_n(ctx->drained, __ATOMIC_RELAXED) != 0u)) {
+            turn.unlock();
+            t2.mark("  map: drained");
+          }
+          bool any = false;
+          if (stream) {
+            while (first_open < n_slices && delivered[first_open]) ++first_open;
+            for (uint32_t s = first_open; s < n_slices; ++s)
+              if (!delivered[s] && __atomic_load_n(&ctx->h_slice_done.p[s], __ATOMIC_ACQUIRE) != 0u) { deliver(s); any = true; }
+          }
+          if (!running) break;
+          if (!any) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        status = ctx->h_tail.p[1];
+        t2.mark("  map: tail");
+      }
+      if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW | ABM_STATUS_READ_TOO_LONG))
+        throw std::runtime_error("kernel reported status " + std::to_string(status));
+      if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) break;
+      // some CIGAR found no room in the arena: its slice stayed open; map again with a larger arena (slices handed
+      // over already were complete -- their results have been taken -- and are not handed over twice)
+      if (ctx->h_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
+      ctx->arena_want = ctx->h_arena.cap * 4;
+    }
+    for (uint32_t s = 0; s < n_slices; ++s)
+      if (!delivered[s]) deliver(s);
+  });
+}
+
+int abm_ctx_slice_results(abm_ctx *ctx, uint64_t lo, uint64_t hi, abm_hit *out_res, uint32_t *out_cig_blob,
+                          uint64_t cig_capacity, uint64_t *out_cig_off) {
+  // (called from inside abm_map_se_batch_sliced's callback, on its thread: the context is already locked)
+  return guarded([&] {
+    if (!ctx || !out_res || !out_cig_off) throw std::invalid_argument("null argument");
+    if (lo > hi || hi > ctx->sliced_reads) throw std::invalid_argument("bad read range");
+    const uint64_t m = hi - lo;
+    const uint32_t stride = ctx->sliced_stride;
+    const uint32_t *cn = ctx->h_cn.p + lo, *slots = ctx->h_slots.p + lo * stride;
+    out_cig_off[0] = 0;
+    for (uint64_t i = 0; i < m; ++i) out_cig_off[i + 1] = out_cig_off[i] + cn[i];
+    if (out_cig_off[m] > cig_capacity || (out_cig_off[m] && !out_cig_blob)) throw std::length_error("cig_capacity too small");
+    std::memcpy(out_res, ctx->h_res.p + lo, m * sizeof(abm_hit));
+    const uint64_t arena_n = ctx->h_arena.cap;
+    for (uint64_t i = 0; i < m; ++i) {
+      const uint32_t k = cn[i];
+      if (k == 0) continue;
+      const uint32_t *src = slots + i * stride;
+      if (k > stride) {
+        if (static_cast<uint64_t>(src[0]) + k > arena_n) throw std::runtime_error("CIGAR arena reference out of range");
+        src = ctx->h_arena.p + src[0];
+      }
+      std::memcpy(out_cig_blob + out_cig_off[i], src, k * 4ull);
+    }
+  });
+}
+
 int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                       const char *d_seq_blob1, const uint64_t *d_seq_off1, const char *d_seq_blob2,
                       const uint64_t *d_seq_off2, uint32_t max_len, abm_pair *d_pair,
@@ -1140,7 +1297,13 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
       // (what se_device asks for: growing any buffer later frees the old one, and hipFree / hipHostFree wait for the whole
       // device -- i.e. for the other context's mapping kernel -- with the runtime's lock held)
       ctx->h_arena.reserve(std::max<size_t>({ctx->arena_want, size_t(1) << 16, static_cast<size_t>(n)}));
-      if (!paired) { ctx->res.reserve(n); ctx->h_res.reserve(n); }
+      if (!paired) {
+        ctx->res.reserve(n); ctx->h_res.reserve(n);
+        // (slices of at least 4096 reads; smaller ones make these buffers grow, which only tests do)
+        const size_t ns = n / 4096 + 2;
+        ctx->slice_id.reserve(n); ctx->slice_left.reserve(ns); ctx->slice_hist.reserve(abm::order_sliced_hist_words(static_cast<abm::u32>(ns)));
+        ctx->slice_first_d.reserve(ns + 1); ctx->h_slice_first.reserve(ns + 1); ctx->h_slice_done.reserve(ns);
+      }
       else {
         ctx->blob2.reserve(n * L); ctx->off2.reserve(n + 1);
         ctx->packed2.reserve(n * 4 * W); ctx->lens2.reserve(n);

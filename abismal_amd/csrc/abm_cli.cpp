@@ -162,6 +162,12 @@ struct Slice {
   size_t base = 0;                   // ... from this index on
   RawBuf text;                       // formatted output
   Stats3 stats;
+  // single-end batches hand their results over slice by slice while the kernel runs (abm_map_se_batch_sliced): the
+  // slice then holds its own copy -- hits and a compact CIGAR blob with n() + 1 offsets
+  bool own = false;
+  PodVec<abm_hit> own_se;
+  PodVec<uint32_t> own_cig;
+  PodVec<uint64_t> own_cig_off;
 };
 
 // written slices are recycled with their buffers (names, reads, output text keep their capacity): a
@@ -185,6 +191,7 @@ struct SlicePool {
     s->stats = Stats3();
     s->batch = nullptr;
     s->base = 0;
+    s->own = false;
     std::lock_guard<std::mutex> lk(mu);
     if (free_list.size() < 1024) free_list.push_back(std::move(s));
   }
@@ -828,7 +835,7 @@ int cmd_map(int argc, char **argv) {
   auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
   const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 16));
   // size of the run's very first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
-  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", 1u << 21));
+  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", (opt.reads.size() == 1 && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM")) ? 1u << 20 : 1u << 21));
   const bool plain_input = [&] {
     for (const std::string &path : opt.reads) {
       const int fd = ::open(path.c_str(), O_RDONLY);
@@ -1203,6 +1210,9 @@ int cmd_map(int argc, char **argv) {
     cv_map.notify_all();
   };
 
+  // single-end results leave the library slice by slice while the kernel runs (ABM_CLI_NO_STREAM=1: whole batches, as
+  // the paired-end path takes them)
+  const bool stream_slices = !paired && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM");
   auto mapper = [&](int slot) {
     const int g = slot / per_gpu;
     abm_ctx *ctx = ctxs[slot];
@@ -1221,13 +1231,18 @@ int cmd_map(int argc, char **argv) {
           // of parsing) what is left is split evenly into batches of at most that size -- and into two even when one
           // would do, if each half still has a few million reads: a batch's output is formatted and written while
           // the next one is being mapped.
+          // Batches whose results leave slice by slice (single-end) are sized the other way round at the end: a
+          // slice is complete when its costliest read is, a fifth of a second into the kernel, so only a LONG last
+          // kernel leaves time to format and write most of its output while it still runs -- 1 M reads first, then
+          // four times as many per batch up to -batch, and what is left in as few batches as possible.
           auto target = [&]() -> size_t {
             size_t cap = batch_reads;
-            if (first_batch_reads) cap = std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, first_batch_reads << std::min<uint64_t>(gpu_batches[g], 20)));
+            const uint64_t grown = std::min<uint64_t>(gpu_batches[g], 10) * (stream_slices ? 2 : 1);
+            if (first_batch_reads) cap = std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, first_batch_reads << grown));
             if (!cut_done) return cap;
             const size_t left = static_cast<size_t>(n_slices - next_to_map) * slice_reads;
             size_t k = (left + cap - 1) / cap;
-            if (k <= 1) k = left >= (1u << 22) ? 2 : 1;
+            if (k <= 1) k = (!stream_slices && left >= (1u << 22)) ? 2 : 1;
             return std::max<size_t>(slice_reads, (left + k - 1) / k);
           };
           cv_map.wait(lk, [&] { return failure || run_reads >= target() || (all_parsed() && (run_end > next_to_map || parsed.empty())); });
@@ -1277,6 +1292,8 @@ int cmd_map(int argc, char **argv) {
         }
         const size_t lead = b->carry[0].size();
         const size_t n = b->n + lead;
+        const uint64_t seq_no = b->seq;  // (a batch whose slices were handed over during the call may be recycled before it returns)
+        bool queued = false;
         const auto t0 = now();
         trace("batch formed", b->seq, n);
         // the slices' reads, concatenated as the C ABI takes them (a single slice with nothing to lead it is used in place)
@@ -1336,6 +1353,7 @@ int cmd_map(int argc, char **argv) {
           // allocated if the first size turns out too small
           const uint64_t worst = std::max<uint64_t>(1, std::max(blob_n[0], blob_n[1]) + 2 * n);
           uint64_t cap = std::min<uint64_t>(worst, 4 * n + 1024);
+          queued = false;
           for (;;) {
             int rc;
             if (!paired && opt.host_ceiling) {
@@ -1361,6 +1379,43 @@ int cmd_map(int argc, char **argv) {
               b->cig_off[0][n] = n;
               rc = 0;
             }
+            else if (!paired && stream_slices) {
+              // results arrive slice by slice while the kernel runs: each slice takes its own copy inside the callback
+              // and goes straight to the formatters
+              std::vector<uint64_t> first(b->slices.size() + 1);
+              first[0] = lead;
+              for (size_t k = 0; k < b->slices.size(); ++k) first[k + 1] = first[k] + b->slices[k]->n();
+              struct Taker {
+                abm_ctx *ctx; Batch *b; const std::vector<uint64_t> *first; std::mutex *mu; std::deque<Slice *> *q;
+                std::condition_variable *cv; int rc; std::string err;
+              } taker{ctx, b, &first, &mu, &q_format, &cv_work, 0, std::string()};
+              auto on_done = [](void *user, uint32_t s) {
+                Taker &t = *static_cast<Taker *>(user);
+                Slice &sl = *t.b->slices[s];
+                const uint64_t lo = (*t.first)[s], hi = (*t.first)[s + 1], m = hi - lo;
+                sl.own_se.resize(std::max<uint64_t>(m, 1));
+                sl.own_cig_off.resize(m + 1);
+                uint64_t room = 4 * m + 64;
+                for (int attempt = 0; attempt < 2 && t.rc == 0; ++attempt) {
+                  sl.own_cig.resize(room);
+                  const int rc = abm_ctx_slice_results(t.ctx, lo, hi, sl.own_se.data(), sl.own_cig.data(), room, sl.own_cig_off.data());
+                  if (rc == 0) break;
+                  if (rc == ABM_ERR_CAPACITY && attempt == 0) { room = sl.own_cig_off[m]; continue; }
+                  t.rc = rc;
+                  t.err = abm_last_error();
+                }
+                sl.own = true;
+                {
+                  std::lock_guard<std::mutex> lk(*t.mu);
+                  t.q->push_back(&sl);
+                }
+                t.cv->notify_one();
+              };
+              rc = abm_map_se_batch_sliced(ctx, se_mode, &par, n, blob_p[0], off_p[0], static_cast<uint32_t>(b->slices.size()),
+                                           first.data(), on_done, &taker);
+              if (rc == 0 && taker.rc != 0) throw std::runtime_error("taking a slice's results: " + taker.err);
+              queued = true;
+            }
             else if (!paired) {
               b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
               rc = abm_map_se_batch(ctx, se_mode, &par, n, blob_p[0], off_p[0], b->se[0].data(),
@@ -1379,11 +1434,12 @@ int cmd_map(int argc, char **argv) {
           }
         }
         else { b->cig_off[0].assign(1, 0); b->cig_off[1].assign(1, 0); }
-        trace("batch mapped", b->seq, n);
+        trace("batch mapped", seq_no, n);
         {
           std::lock_guard<std::mutex> lk(mu);
           busy_map += since(t0);
-          for (auto &sl : b->slices) q_format.push_back(sl.get());
+          if (!queued)
+            for (auto &sl : b->slices) q_format.push_back(sl.get());
         }
         cv_work.notify_all();
       }
@@ -1403,12 +1459,15 @@ int cmd_map(int argc, char **argv) {
     const size_t m = sl.n(), base = sl.base;
     sam.reserve(m * (paired ? 2 : 1) * 320);
     if (!paired) {
+      // (a slice that took its own copy of the results indexes it by its own read numbers)
+      const abm_hit *hits = sl.own ? sl.own_se.data() : b->se[0].data() + base;
+      const uint32_t *cig_blob = sl.own ? sl.own_cig.data() : b->cig[0].data();
+      const uint64_t *cig_off = sl.own ? sl.own_cig_off.data() : b->cig_off[0].data() + base;
       for (size_t k = 0; k < m; ++k) {
-        const size_t i = base + k;
-        abm_hit h = b->se[0][i];
+        abm_hit h = hits[k];
         const size_t len = sl.off[0][k + 1] - sl.off[0][k];
-        const uint32_t *cg = b->cig[0].data() + b->cig_off[0][i];
-        const size_t ncg = b->cig_off[0][i + 1] - b->cig_off[0][i];
+        const uint32_t *cg = cig_blob + cig_off[k];
+        const size_t ncg = cig_off[k + 1] - cig_off[k];
         if (len && emit_se(sam, opt.ambig, h, ch, sl.names[0][k], sl.blob[0].data() + sl.off[0][k], len, cg, ncg) == UNMAPPED) h.pos = 0;
         st.s[0].tally(len == 0, h, opt.ambig, ref_len(cg, ncg));
       }
@@ -1537,7 +1596,16 @@ int cmd_map(int argc, char **argv) {
   for (int slot = 0; slot < n_gpus * per_gpu; ++slot) threads.emplace_back(mapper, slot);
   for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(worker);
   threads.emplace_back(writer);
-  for (auto &t : threads) t.join();
+  {
+    size_t k = 0;
+    for (auto &t : threads) {  // (a join that has to wait shows in the trace: which thread the run's end hung on)
+      const auto tj = now();
+      t.join();
+      if (since(tj) > 2e-3) trace("waited on join", k, static_cast<uint64_t>(since(tj) * 1e6));
+      ++k;
+    }
+  }
+  trace("threads joined", threads.size(), 0);
   for (LineFile &F : lf) if (F.fd >= 0) ::close(F.fd);
   if (failure) std::rethrow_exception(failure);
   if (opt.bam) {  // BGZF end-of-file marker
@@ -1547,6 +1615,7 @@ int cmd_map(int argc, char **argv) {
   }
   out_closer.fd = -1;
   if (::close(out_fd) != 0) throw std::runtime_error("failed writing output file: " + opt.out);
+  trace("output closed", file_offset, 0);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
   // statistics (6 counters x 3 structs, src/abismal.cpp:865-895, :1034-1037).  Every GPU's counters

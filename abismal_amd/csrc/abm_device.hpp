@@ -138,6 +138,18 @@ __device__ __forceinline__ u64 wave_max_u64(u64 x) {
   return x;
 }
 
+// Results (hits, op counts, CIGAR slots and arena entries) are written THROUGH to memory at system scope (sc0 sc1):
+// a host that takes them while the kernel is still running (abm_map_se_batch_sliced) must never find them waiting in
+// an L2 for the end of the kernel -- a plain store to pinned host memory does (measured: a run whose slices were
+// announced after an s_waitcnt alone wrote stale results).  A handful of stores per read; device buffers take them too.
+__device__ __forceinline__ void store_out(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_out(Hit *p, const Hit &h) {
+  static_assert(sizeof(Hit) == 8, "a hit is one 8-byte store");
+  u64 bits;
+  __builtin_memcpy(&bits, &h, 8);
+  __hip_atomic_store(reinterpret_cast<u64 *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- sequence primitives ------------------------------------------------------
 // read nibble: src/dna_four_bit_bisulfite.hpp:26-57
 __device__ __forceinline__ u32 read_nibble(u32 c, bool a_alphabet) {

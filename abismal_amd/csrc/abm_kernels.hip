@@ -182,6 +182,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     r_next = next_read();  // fetched early; its latency hides under this read's work
     long long t_read = 0;
     if (TIMED) t_read = clock64();
+    const bool overflow_before = overflow;
     const u32 L = a.lens[r];
     Hit best;
     best.diffs = 0x7fff; best.flags = 0; best.pos = 0;
@@ -227,9 +228,26 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       if (TIMED) wt.t_align += t_b - t_a;
     }
     if (lane == 0) {
-      a.res[r] = best;
-      a.cig_n[r] = best.pos != 0 ? n_ops : 0u;
+      store_out(a.res + r, best);
+      store_out(a.cig_n + r, best.pos != 0 ? n_ops : 0u);
       if (TIMED && a.read_cycles) a.read_cycles[r] = static_cast<u32>((clock64() - t_read) >> 10);
+    }
+    if (!LONG && a.slice_left != nullptr) {
+      // results leave slice by slice: everything this read wrote (hit, count, slot, arena entries) was written through
+      // to memory (store_out), and the wave waits for those stores to be acknowledged before its slice's count goes
+      // down (a system-scope fence per read instead writes back and invalidates the L2 each time: the kernel took
+      // 1.7 times as long).
+      // The wave that takes a count to zero fences at system scope once, then tells the host.  A read whose CIGAR
+      // found no room in the arena never counts: its slice stays open and the host maps the batch again.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every store of this wave acknowledged)
+      if (lane == 0 && !(overflow && !overflow_before)) {
+        const u32 sl = a.slice_id[r];
+        if (sl != 0xFFFFu && atomicSub(&a.slice_left[sl], 1u) == 1u) {
+          __threadfence_system();
+          __hip_atomic_store(a.slice_done + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
     }
   }
   if (TIMED && a.work) {  // exact work tallies for the roofline model: kept by the diagnostic build only (see seed_pass)
@@ -391,6 +409,146 @@ hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32
   hipLaunchKernelGGL(weigh_reads_kernel, dim3(blocks), dim3(256), 0, st, ix, d_packed, d_lens, n, W, mode, d_cls, d_class33);
   hipLaunchKernelGGL(order_bases_kernel, dim3(1), dim3(64), 0, st, d_class33);
   hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, st, d_cls, n, d_class33, d_order);
+  return hipGetLastError();
+}
+
+// ---- the order of a batch whose results leave slice by slice -----------------------------
+// Heaviest-first over the whole batch would finish every slice at the end of the launch.  Here only the few heaviest
+// reads go first -- the classes from the top that together hold at most 1/32 of the batch: they are what a launch's
+// tail is made of -- then the reads before the first slice (a batch's lead-in), then slice after slice in input
+// order, so that slices complete one after the other while the kernel runs.
+// hist: rows [n_slices + 1][33] (row n_slices = the lead-in), cursors [33] + [n_slices + 1], then the threshold class.
+__device__ __forceinline__ u32 slice_row(const u32 *__restrict__ first, u32 n_slices, u32 r) {
+  if (r < first[0]) return n_slices;
+  u32 lo = 0, hi = n_slices;  // first[lo] <= r < first[hi]
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (first[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void weigh_sliced_kernel(DevIndex ix, const u64 *__restrict__ packed, const u32 *__restrict__ lens,
+                                                           u64 n, u32 W, int mode, u8 *__restrict__ cls,
+                                                           const u32 *__restrict__ slice_first, u32 n_slices,
+                                                           u16 *__restrict__ slice_id, u32 *__restrict__ hist) {
+  __shared__ u32 local[4][33];
+  __shared__ u32 row0;
+  for (u32 k = threadIdx.x; k < 4 * 33; k += blockDim.x) (&local[0][0])[k] = 0;
+  const u64 r_first = static_cast<u64>(blockIdx.x) * blockDim.x;
+  if (threadIdx.x == 0) row0 = slice_row(slice_first, n_slices, static_cast<u32>(r_first));
+  __syncthreads();
+  const u64 r = r_first + threadIdx.x;
+  if (r < n) {
+    const u32 L = lens[r];
+    u32 c = 0;
+    if (L >= ix.min_len) {
+      const u64 *pk = packed + r * 4 * W;
+      const bool ar = mode == 1;
+      c = max(weight_class(ix, pk + (ar ? 1 : 0) * W, L, ar), weight_class(ix, pk + (2 + (ar ? 0 : 1)) * W, L, !ar));
+    }
+    cls[r] = static_cast<u8>(c);
+    const u32 row = slice_row(slice_first, n_slices, static_cast<u32>(r));
+    slice_id[r] = row < n_slices ? static_cast<u16>(row) : static_cast<u16>(0xFFFFu);
+    const u32 rel = row - row0;
+    if (rel < 4u) atomicAdd(&local[rel][c], 1u);
+    else atomicAdd(&hist[static_cast<size_t>(row) * 33 + c], 1u);
+  }
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < 4 * 33; k += blockDim.x) {
+    const u32 v = (&local[0][0])[k], row = row0 + k / 33;
+    if (v && row <= n_slices) atomicAdd(&hist[static_cast<size_t>(row) * 33 + k % 33], v);
+  }
+}
+
+__global__ __launch_bounds__(256) void order_bases_sliced_kernel(u32 *__restrict__ hist, u32 n_slices, u64 n,
+                                                                 u32 *__restrict__ slice_left) {
+  __shared__ u32 tot[33];
+  __shared__ u32 threshold, heavy_total;
+  u32 *cur_heavy = hist + static_cast<size_t>(n_slices + 1) * 33, *cur_slice = cur_heavy + 33, *t_out = cur_slice + n_slices + 1;
+  if (threadIdx.x < 33) {
+    u32 sum = 0;
+    for (u32 row = 0; row <= n_slices; ++row) sum += hist[static_cast<size_t>(row) * 33 + threadIdx.x];
+    tot[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 at = 0, T = 33;
+    for (int c = 32; c >= 1; --c) {
+      if (at + tot[c] > n / 32) break;
+      at += tot[c];
+      T = static_cast<u32>(c);
+    }
+    u32 run = 0;
+    for (int c = 32; c >= static_cast<int>(T); --c) { cur_heavy[c] = run; run += tot[c]; }
+    heavy_total = run;
+    threshold = T;
+    *t_out = T;
+  }
+  __syncthreads();
+  const u32 T = threshold;
+  for (u32 row = threadIdx.x; row <= n_slices; row += blockDim.x) {
+    u32 light = 0, all = 0;
+    for (u32 c = 0; c < 33; ++c) {
+      const u32 v = hist[static_cast<size_t>(row) * 33 + c];
+      all += v;
+      if (c < T) light += v;
+    }
+    cur_slice[row] = light;
+    if (row < n_slices) slice_left[row] = all;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 at = heavy_total;
+    u32 v = cur_slice[n_slices];
+    cur_slice[n_slices] = at;
+    at += v;
+    for (u32 row = 0; row < n_slices; ++row) { v = cur_slice[row]; cur_slice[row] = at; at += v; }
+  }
+}
+
+__global__ __launch_bounds__(256) void order_scatter_sliced_kernel(const u8 *__restrict__ cls, const u16 *__restrict__ slice_id, u64 n,
+                                                                   u32 n_slices, u32 *__restrict__ hist, u32 *__restrict__ order) {
+  // one global reservation per (block, bin): bins = the 33 classes (heavy reads) and the block's first four rows
+  __shared__ u32 cnt[37], base[37];
+  __shared__ u32 row0;
+  u32 *cur_heavy = hist + static_cast<size_t>(n_slices + 1) * 33, *cur_slice = cur_heavy + 33;
+  const u32 T = cur_slice[n_slices + 1];
+  if (threadIdx.x < 37) cnt[threadIdx.x] = 0;
+  const u64 r_first = static_cast<u64>(blockIdx.x) * blockDim.x;
+  if (threadIdx.x == 0) { const u16 s0 = slice_id[r_first]; row0 = s0 == 0xFFFFu ? n_slices : s0; }
+  __syncthreads();
+  const u64 r = r_first + threadIdx.x;
+  u32 bin = 0xFFFFFFFFu, rank = 0, row = 0;
+  if (r < n) {
+    const u32 c = cls[r];
+    const u16 s = slice_id[r];
+    row = s == 0xFFFFu ? n_slices : s;
+    if (c >= T) bin = c;
+    else if (row - row0 < 4u) bin = 33 + (row - row0);
+    if (bin != 0xFFFFFFFFu) rank = atomicAdd(&cnt[bin], 1u);
+    else order[atomicAdd(&cur_slice[row], 1u)] = static_cast<u32>(r);
+  }
+  __syncthreads();
+  if (threadIdx.x < 37 && cnt[threadIdx.x]) {
+    const u32 b = threadIdx.x;
+    base[b] = b < 33 ? atomicAdd(&cur_heavy[b], cnt[b]) : (row0 + (b - 33) <= n_slices ? atomicAdd(&cur_slice[row0 + (b - 33)], cnt[b]) : 0u);
+  }
+  __syncthreads();
+  if (r < n && bin != 0xFFFFFFFFu) order[base[bin] + rank] = static_cast<u32>(r);
+}
+
+hipError_t launch_order_reads_sliced(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W, int mode,
+                                     u8 *d_cls, const u32 *d_slice_first, u32 n_slices, u16 *d_slice_id, u32 *d_hist,
+                                     u32 *d_slice_left, u32 *d_order, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_hist, 0, order_sliced_hist_words(n_slices) * sizeof(u32), st);
+  if (e != hipSuccess) return e;
+  const u32 blocks = static_cast<u32>((n + 255) / 256);
+  hipLaunchKernelGGL(weigh_sliced_kernel, dim3(blocks), dim3(256), 0, st, ix, d_packed, d_lens, n, W, mode, d_cls, d_slice_first,
+                     n_slices, d_slice_id, d_hist);
+  hipLaunchKernelGGL(order_bases_sliced_kernel, dim3(1), dim3(256), 0, st, d_hist, n_slices, n, d_slice_left);
+  hipLaunchKernelGGL(order_scatter_sliced_kernel, dim3(blocks), dim3(256), 0, st, d_cls, d_slice_id, n, n_slices, d_hist, d_order);
   return hipGetLastError();
 }
 

@@ -35,6 +35,13 @@ struct SeArgs {
   u32 *finished;      // optional: waves that have run to their end (zero at launch) ...
   u32 *host_tail;     // ... the last of which writes {arena count, status} here (pinned host memory): a host that takes
                       // its results from pinned buffers then needs no device-to-host copy at all after the kernel
+  // optional, for hosts that take results slice by slice while the kernel runs (abm_map_se_batch_sliced): the slice a
+  // read belongs to (0xFFFF = none), the reads each slice still waits for (device memory), and one word per slice in
+  // pinned host memory that the wave finishing a slice's last read sets -- after a system-scope fence, so the slice's
+  // hits, counts, slots and arena entries are in host memory by then
+  const u16 *slice_id;
+  u32 *slice_left;
+  u32 *slice_done;
   u32 *read_cycles;   // optional [n], diagnostic kernel only: per-read shader cycles / 1024
   unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments
@@ -107,6 +114,13 @@ hipError_t launch_pack_reads(const char *d_blob, const u64 *d_off, u64 n, u32 W,
                              u32 *d_lens, hipStream_t st);
 hipError_t launch_order_reads(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W,
                               int mode, u8 *d_cls, u32 *d_class33, u32 *d_order, hipStream_t st);
+// the same for a batch whose results leave slice by slice: the few heaviest reads first (as many classes from the top
+// as hold at most 1/32 of the batch), then the reads before the first slice, then slice after slice.  slice_first:
+// [n_slices + 1] read indices in device memory; slice_id: [n] out; hist: [(n_slices + 1) * 33 + 33 + n_slices + 2] scratch
+hipError_t launch_order_reads_sliced(const DevIndex &ix, const u64 *d_packed, const u32 *d_lens, u64 n, u32 W, int mode,
+                                     u8 *d_cls, const u32 *d_slice_first, u32 n_slices, u16 *d_slice_id, u32 *d_hist,
+                                     u32 *d_slice_left, u32 *d_order, hipStream_t st);
+inline size_t order_sliced_hist_words(u32 n_slices) { return static_cast<size_t>(n_slices + 1) * 33 + 33 + n_slices + 2; }
 hipError_t launch_compact_cigars(const Hit *d_res, const u32 *d_cig, const u32 *d_cig_n, u64 n, u32 stride,
                                  unsigned long long *d_off, u32 *d_blob, void *tmp, size_t *tmp_bytes, hipStream_t st);
 hipError_t launch_gather_cigars(const u32 *d_cig, u32 stride, const unsigned long long *d_off, u64 n, u32 *d_blob,

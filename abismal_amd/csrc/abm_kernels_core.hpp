@@ -1031,7 +1031,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   const int lane = lane_id();
   ins = del = 0;  // count_total_ops<I>/<D> with oplen() narrowed to uint8_t (abismal_cigar_utils.hpp:50-53)
   if (score == 0 || diffs == 0) {
-    if (lane == 0) cig_out[0] = static_cast<u32>(L) << 4;
+    if (lane == 0) store_out(cig_out, static_cast<u32>(L) << 4);
     n_ops = 1;
     aln_len = static_cast<u32>(L);
     return;
@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
     }
     if (at != 0xFFFFFFFFu) {
       dst = sink.arena + at;
-      if (lane == 0) cig_out[0] = at;
+      if (lane == 0) store_out(cig_out, at);
     }
     else {  // no room: the slot gets what fits and the launch is flagged
       overflow = true;
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
     if (clip_head > 0 && k == 0) v = (static_cast<u32>(clip_head) << 4) | 4u;
     else if (kk < body) v = ctmp[body - 1 - kk];
     else v = (static_cast<u32>(clip_tail) << 4) | 4u;
-    dst[k] = v;
+    store_out(dst + k, v);
   }
   n_ops = full;  // > stride: the ops are in the arena at slot[0] (or, with ABM_STATUS_CIGAR_OVERFLOW set, nowhere complete)
   aln_len = static_cast<u32>(L - clip_tail - clip_head);
@@ -1445,7 +1445,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   n_ops = 0;
   if (S.best_p != 0) {  // exact match: no alignment needed
     best.diffs = static_cast<i16>(S.best_d); best.flags = static_cast<u16>(S.best_f); best.pos = S.best_p;
-    if (lane == 0) cig_out[0] = L << 4;
+    if (lane == 0) store_out(cig_out, L << 4);
     n_ops = 1;
     return;
   }

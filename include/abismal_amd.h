@@ -125,6 +125,25 @@ int abm_map_se_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
                      const char *seq_blob, const uint64_t *seq_off, abm_hit *out_res,
                      uint32_t *out_cig_blob, uint64_t cig_capacity, uint64_t *out_cig_off);
 
+/* The same batch with its results handed over SLICE BY SLICE while the kernel is still running -- for a caller that
+ * formats and writes output as it arrives (the reference's counterpart: its output loop runs per batch after the
+ * mapping loop, src/abismal.cpp:1578-1598; a GPU batch is millions of reads, and waiting for all of it leaves the
+ * host idle for the length of a kernel and then the device idle for the length of the formatting).
+ * slice_first: n_slices + 1 read indices, non-decreasing, the last one n; reads before slice_first[0] belong to no
+ * slice (a batch's lead-in, mapped for its effect on later reads only).  The kernel works through the batch's few
+ * heaviest reads first and then slice after slice; when a slice's last read is done, `done(user, slice)` is called
+ * on the calling thread, and INSIDE that call abm_ctx_slice_results copies the slice's reads [lo, hi) out of the
+ * context's pinned buffers: hits, and CIGARs as a compact blob with hi - lo + 1 offsets relative to the range
+ * (ABM_ERR_CAPACITY if cig_capacity ops do not suffice; out_cig_off[hi - lo] then holds the number needed).  After
+ * `done` returns the slice's results may be overwritten.  Every slice is handed over exactly once before the call
+ * returns; slices of a batch with reads of more than 1024 bases all arrive at the end. */
+typedef void (*abm_slice_done_fn)(void *user, uint32_t slice);
+int abm_map_se_batch_sliced(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
+                            const char *seq_blob, const uint64_t *seq_off, uint32_t n_slices,
+                            const uint64_t *slice_first, abm_slice_done_fn done, void *user);
+int abm_ctx_slice_results(abm_ctx *ctx, uint64_t lo, uint64_t hi, abm_hit *out_res,
+                          uint32_t *out_cig_blob, uint64_t cig_capacity, uint64_t *out_cig_off);
+
 /* Same computation with every buffer already resident in HBM (d_* are device
  * pointers), enqueued on `stream` (a hipStream_t; NULL = default stream) and
  * not synchronised.  CIGARs land in fixed slots of cig_stride ops per read,

@@ -1246,7 +1246,14 @@ int cmd_map(int argc, char **argv) {
             return std::max<size_t>(slice_reads, (left + k - 1) / k);
           };
           cv_map.wait(lk, [&] { return failure || run_reads >= target() || (all_parsed() && (run_end > next_to_map || parsed.empty())); });
-          if (failure || run_end == next_to_map) break;
+          if (failure || run_end == next_to_map) {
+            // (the unused batch goes back to the pool: destroying it here would free its page-locked buffers -- a
+            // device-wide wait and 0.1-0.2 s of unpinning -- inside the run's clock; the trace showed the run's end
+            // waiting on exactly these two threads)
+            lk.unlock();
+            batch_pool.put(std::move(owned));
+            break;
+          }
           const size_t want = std::min(target(), std::max<size_t>(run_reads, 1));
           while (next_to_map < run_end) {
             auto it = parsed.find(next_to_map);

@@ -14,7 +14,7 @@ for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_A
 import csv, sys, collections
 acc = collections.defaultdict(float); info = {}
 for row in csv.DictReader(open(sys.argv[1])):
-    if "map_se_kernel" in row.get("Kernel_Name", ""):
+    if "map_se_kernel<false" in row.get("Kernel_Name", ""):  # (the production kernel; the diagnostic build runs once after it)
         acc[row["Counter_Name"]] += float(row["Counter_Value"])
         for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"):
             if k in row: info[k] = row[k]

@@ -591,7 +591,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   {
     a.cap = abm::kPeTier1Cap;
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, false);
-    const int waves = abm::pe_resident_waves(lds, false);
+    const int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    const int waves = abm::pe_resident_waves(lds, false, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 1) does not fit on this device");
     ctx->payload1.reserve(static_cast<size_t>(waves) * a.cap);
     a.payload_ws = ctx->payload1.p;
@@ -600,7 +601,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
     const hipEvent_t e1 = begin_timed(ctx, st);
-    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, ctx->phase_stamps, st));
+    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, ctx->phase_stamps, wps, st));
     if (e1) HIPCHK(hipEventRecord(e1, st));
   }
   // tier 2: the pairs whose candidate sets outgrew tier 1, one wave per CU, 32768-entry sets
@@ -609,7 +610,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     a.cap = abm::kPeCapLarge;
     a.order = nullptr;
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, true);
-    const int waves = abm::pe_resident_waves(lds, true);
+    const int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    const int waves = abm::pe_resident_waves(lds, true, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
     ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);
     ctx->list2.reserve(static_cast<size_t>(waves) * 4 * a.cap);
@@ -624,7 +626,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     a.next_read = counter;
     a.work = ctx->work.p + 16;  // tier 2 tallies separately (abm_ctx_take_work_tiers)
     const hipEvent_t e1 = begin_timed(ctx, st);
-    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, ctx->phase_stamps, st));
+    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, ctx->phase_stamps, wps, st));
     if (e1) HIPCHK(hipEventRecord(e1, st));
   }
   HIPCHK(hipEventRecord(ctx->last_done, st));

@@ -86,8 +86,9 @@ struct PeArgs {
 // window cache, both idle while a traceback runs); the kernels carve exactly this much extra
 u32 tb_extra_bytes(u32 GW, u32 max_len, double valid_frac);
 size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big);
-int pe_resident_waves(size_t lds, bool big);
-hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st);
+int pe_waves_per_simd(size_t lds, bool timed, bool coop);  // which build of the pair kernels a launch with this much LDS per wave takes
+int pe_resident_waves(size_t lds, bool big, int wps);
+hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, int wps, hipStream_t st);
 hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *class33, u32 *subset, u32 *count,
                               hipStream_t st);
 #ifndef ABM_PE_TIER1_CAP

@@ -11,6 +11,10 @@
 #include "abm_kernels_core.hpp"
 #include "abm_pe_set.hpp"
 
+// Waves per SIMD the pair kernels are compiled for: 4 (128 registers per lane), and for the production kernels on the
+// bit planes also 3 (170 registers): with 2x150-base pairs the LDS of a wave allows 13 waves per CU anyway, and the
+// build with more registers is the faster one there; with 2x100 the LDS allows 16 and four waves per SIMD win
+// (profiles/r03_exp_pe_loop_and_registers.log, r03_exp_pe_2x100_variants.log).  pe_waves_per_simd() picks per launch.
 #ifndef ABM_PE_WAVES_PER_SIMD
 #define ABM_PE_WAVES_PER_SIMD 4
 #endif
@@ -70,6 +74,9 @@ template <bool BIG, bool COOP> struct PeWave {
   u32 *log_base;  // tier 2: this wave's best_single log
   int max_set;
 
+  // (ends are run-time values -- the orientation calls are ONE piece of code looped over -- so the two-element register
+  // arrays are read and written through selects, never indexed)
+  __device__ __forceinline__ u32 len_of(int end) const { return end ? L[1] : L[0]; }
   __device__ __forceinline__ WaveLds lds_of(int end) const {
     WaveLds w = lds;
     w.qpk = lds.qpk + end * 4 * lds.W;
@@ -89,13 +96,13 @@ template <bool BIG, bool COOP> struct PeWave {
     lflags[which] = flags;
     P.lpos = pl.lpos[which];
     P.ld = pl.ld[which];
-    P.begin_read(L[end]);
-    if (L[end] >= a.ix.min_len) {
+    P.begin_read(len_of(end));
+    if (len_of(end) >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt, seg_epoch);
+      seed_pass<true, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, L[end], P, wt, seg_epoch);
+        seed_pass<false, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       }
     }
     need_big |= P.overflow;
@@ -198,7 +205,7 @@ template <bool BIG, bool COOP> struct PeWave {
     // unique + recompute diffs
     const WaveLds w = lds_of(end);
     const u64 *qpk = w.qpk + enc_of(lflags[which]) * w.W;
-    const u32 nwords = (L[end] + 15) >> 4;
+    const u32 nwords = (len_of(end) + 15) >> 4;
     int out = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
       const int i = i0 + lane;
@@ -209,7 +216,7 @@ template <bool BIG, bool COOP> struct PeWave {
         const int dst = out + __popcll(kept & ((1ull << lane) - 1));
         pl.lpos[which][dst] = v;
         pl.ld[which][dst] = static_cast<i16>(v != 0 ? hamming(a.ix.genome, qpk, nwords, v)
-                                                    : static_cast<int>(static_cast<i16>(0.4 * L[end])));
+                                                    : static_cast<int>(static_cast<i16>(0.4 * len_of(end))));
       }
       out += __popcll(kept);
     }
@@ -233,7 +240,7 @@ template <bool BIG, bool COOP> struct PeWave {
   __device__ __forceinline__ void score_pairable(int endA) {
     const int lane = lane_id();
     const int ends[2] = {endA, 1 - endA};
-    const long long lenB = L[ends[1]];
+    const long long lenB = len_of(ends[1]);
     // pass 1: mark.  score 0 = cannot pair, 2L = exact hit (align() returns at once), -1 = needs the DP
     #pragma unroll
     for (int which = 0; which < 2; ++which) {
@@ -248,7 +255,7 @@ template <bool BIG, bool COOP> struct PeWave {
           else { lo = static_cast<long long>(pos) + lenB - a.max_frag; hi = static_cast<long long>(pos) + lenB - a.min_frag; }
           const int k = lower_bound_pos(other, lo);
           if (k < lsz[other] && static_cast<long long>(ld_list<BIG>(pl.lpos[other] + k)) <= hi)
-            mark = ld_list<BIG>(pl.ld[which] + i) == 0 ? static_cast<int>(static_cast<i16>(2 * L[ends[which]])) : -1;
+            mark = ld_list<BIG>(pl.ld[which] + i) == 0 ? static_cast<int>(static_cast<i16>(2 * len_of(ends[which]))) : -1;
         }
         pl.lsc[which][i] = static_cast<i16>(mark);
       }
@@ -258,7 +265,7 @@ template <bool BIG, bool COOP> struct PeWave {
     #pragma unroll
     for (int which = 0; which < 2; ++which) {
       const int end = ends[which], n = lsz[which];
-      const int md = static_cast<i16>(a.valid_frac * L[end]);
+      const int md = static_cast<i16>(a.valid_frac * len_of(end));
       int cursor = 0;
       for (;;) {
         int n_jobs = 0;
@@ -282,7 +289,7 @@ template <bool BIG, bool COOP> struct PeWave {
         if (n_jobs == 0) break;
         for (int s = 0; s < n_jobs;) {  // rounds of side-by-side bands
           const int first = s;
-          s = score_jobs(a.ix, lds, first, n_jobs, static_cast<int>(L[end]), md, static_cast<int>(end * 4 * lds.W));
+          s = score_jobs(a.ix, lds, first, n_jobs, static_cast<int>(len_of(end)), md, static_cast<int>(end * 4 * lds.W));
           if (lane < s - first) pl.lsc[which][pl.jidx[first + lane]] = static_cast<i16>(lds.lbest[lane]);
           n_aln += static_cast<u32>(s - first);
           wave_sync();
@@ -295,8 +302,8 @@ template <bool BIG, bool COOP> struct PeWave {
   __device__ __forceinline__ void traceback_end(int end, u64 r, int scoring, int &d, u32 flags, u32 &pos,
                                                 u32 &alen) {
     const int lane = lane_id();
-    const int Ln = static_cast<int>(L[end]);
-    const int md = static_cast<i16>(a.valid_frac * L[end]);
+    const int Ln = static_cast<int>(len_of(end));
+    const int md = static_cast<i16>(a.valid_frac * len_of(end));
     u32 *cig_out = cig_of(end, r);
     u32 nops = 0;
     int n_ins = 0, n_del = 0;
@@ -334,8 +341,9 @@ template <bool BIG, bool COOP> struct PeWave {
       wave_sync();
     }
     d = edit_distance(scoring, alen, n_ins, n_del);
-    n_ops[end] = nops;
-    ref_len[end] = alen - static_cast<u32>(n_ins) + static_cast<u32>(n_del);
+    const u32 rl = alen - static_cast<u32>(n_ins) + static_cast<u32>(n_del);
+    if (end) { n_ops[1] = nops; ref_len[1] = rl; }
+    else { n_ops[0] = nops; ref_len[0] = rl; }
   }
 
   // best_pair, src/abismal.cpp:1722-1831.  List 0 is endA's (the reference's res1), list 1
@@ -356,7 +364,7 @@ template <bool BIG, bool COOP> struct PeWave {
     const int endB = 1 - endA;
     const bool swapped = endA == 1;
     const int na = lsz[0], nb = lsz[1];
-    const u32 lenB = L[endB];
+    const u32 lenB = len_of(endB);
     const u32 *posA = pl.lpos[0], *posB = pl.lpos[1];
     int last_sa = 0, keep_sa = 0, keep_sb = 0;
     u32 keep_pa = 0, keep_pb = 0;
@@ -501,9 +509,9 @@ template <bool BIG, bool COOP> struct PeWave {
   }
 
   // map_fragments + select_maps + best_single (:1715-1720, :1833-1885)
-  template <bool TIMED, int O> __device__ __forceinline__ bool orientation(int endA, bool ar, u64 r, PairBest &best) {
+  template <bool TIMED> __device__ __forceinline__ bool orientation(int O, int endA, bool ar, u64 r, PairBest &best) {
     const int endB = 1 - endA;
-    const bool emptyA = L[endA] < a.ix.min_len, emptyB = L[endB] < a.ix.min_len;
+    const bool emptyA = len_of(endA) < a.ix.min_len, emptyB = len_of(endB) < a.ix.min_len;
     if (emptyA && emptyB) {
       // res1/res2 are reset and nothing else happens (:1863-1866)
       return false;
@@ -548,10 +556,13 @@ template <bool BIG, bool COOP> struct PeWave {
       wave_sync();
     }
     else {
-      // best_single: every entry of each set, in array order, into that end's single-end set
-#pragma unroll
-      for (int which = 0; which < 2; ++which)
-        feed_single(se[ends[which]], pl.lpos[which], pl.ld[which], lsz[which], lflags[which]);
+      // best_single: every entry of each set, in array order, into that end's single-end set.  List 0 is endA's:
+      // with endA == 1 the two (register-resident) sets trade places around the two calls, so that each call names
+      // its set at compile time
+      if (endA) { const SeSet t = se[0]; se[0] = se[1]; se[1] = t; }
+      feed_single(se[0], pl.lpos[0], pl.ld[0], lsz[0], lflags[0]);
+      feed_single(se[1], pl.lpos[1], pl.ld[1], lsz[1], lflags[1]);
+      if (endA) { const SeSet t = se[0]; se[0] = se[1]; se[1] = t; }
     }
     ABM_STAMP(t1);
     if (TIMED) t_single += t1 - t0;
@@ -559,8 +570,8 @@ template <bool BIG, bool COOP> struct PeWave {
   }
 };
 
-template <bool BIG, bool TIMED, bool COOP>
-__global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArgs a) {
+template <bool BIG, bool TIMED, bool COOP, int WPS>
+__global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   PeWave<BIG, COOP> w{a};
@@ -671,16 +682,15 @@ __global__ __launch_bounds__(64, ABM_PE_WAVES_PER_SIMD) void map_pe_kernel(PeArg
 
     bool any = false;
     // orientation(endA, alphabet): src/abismal.cpp:1963-1979, :2106-2133
-    if (a.mode == 2) {
-      any |= w.template orientation<TIMED, 0>(0, false, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 1>(1, true, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 2>(0, true, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 3>(1, false, r, best);
-    }
-    else {
-      const bool ar = a.mode == 1;
-      any |= w.template orientation<TIMED, 0>(0, ar, r, best);
-      if (!(w.need_big && !BIG)) any |= w.template orientation<TIMED, 1>(1, !ar, r, best);
+    // ONE copy of the orientation code, looped over (six inlined copies made the tier-1 kernel 155 k lines of assembly)
+    {
+      const int n_or = a.mode == 2 ? 4 : 2;
+#pragma clang loop unroll(disable)
+      for (int o = 0; o < n_or; ++o) {
+        if (o > 0 && w.need_big && !BIG) break;
+        const bool ar_o = a.mode == 2 ? (o == 1 || o == 2) : ((a.mode == 1) != (o == 1));
+        any |= w.template orientation<TIMED>(o, o & 1, ar_o, r, best);
+      }
     }
     if (w.need_big && !BIG) {
       if (lane == 0) a.need_big[r] = 1;
@@ -809,29 +819,42 @@ size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double v
   return (b + 15) & ~static_cast<size_t>(15);
 }
 
-int pe_resident_waves(size_t lds, bool big) {
+int pe_waves_per_simd(size_t lds, bool timed, bool coop) {
+  // (LDS of a CU: 160 KB on gfx950)
+  return (!timed && coop && lds != 0 && (160u * 1024u) / lds <= 13u) ? 3 : ABM_PE_WAVES_PER_SIMD;
+}
+
+int pe_resident_waves(size_t lds, bool big, int wps) {
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  const hipError_t e = big ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<true, false, true>, 64, lds)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<false, false, true>, 64, lds);
+  hipError_t e;
+  if (wps == 3) e = big ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<true, false, true, 3>, 64, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<false, false, true, 3>, 64, lds);
+  else e = big ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<true, false, true, ABM_PE_WAVES_PER_SIMD>, 64, lds)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<false, false, true, ABM_PE_WAVES_PER_SIMD>, 64, lds);
   if (e != hipSuccess) return 0;
   return per_cu * prop.multiProcessorCount;
 }
 
 template <bool BIG, bool TIMED>
-static void launch_pe_variant(const PeArgs &a, size_t lds, u32 grid, hipStream_t st) {
+static void launch_pe_variant(const PeArgs &a, size_t lds, u32 grid, int wps, hipStream_t st) {
   // a.G != 0: the filter reads the genome's bit planes (cooperative window loads)
-  if (a.G != 0) hipLaunchKernelGGL((map_pe_kernel<BIG, TIMED, true>), dim3(grid), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL((map_pe_kernel<BIG, TIMED, false>), dim3(grid), dim3(64), lds, st, a);
+  if (a.G != 0) {
+    if constexpr (!TIMED) {
+      if (wps == 3) { hipLaunchKernelGGL((map_pe_kernel<BIG, false, true, 3>), dim3(grid), dim3(64), lds, st, a); return; }
+    }
+    hipLaunchKernelGGL((map_pe_kernel<BIG, TIMED, true, ABM_PE_WAVES_PER_SIMD>), dim3(grid), dim3(64), lds, st, a);
+  }
+  else hipLaunchKernelGGL((map_pe_kernel<BIG, TIMED, false, ABM_PE_WAVES_PER_SIMD>), dim3(grid), dim3(64), lds, st, a);
 }
 
-hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st) {
+hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, int wps, hipStream_t st) {
   if (grid == 0) return hipSuccess;
-  if (big && timed) launch_pe_variant<true, true>(a, lds, grid, st);
-  else if (big) launch_pe_variant<true, false>(a, lds, grid, st);
-  else if (timed) launch_pe_variant<false, true>(a, lds, grid, st);
-  else launch_pe_variant<false, false>(a, lds, grid, st);
+  if (big && timed) launch_pe_variant<true, true>(a, lds, grid, wps, st);
+  else if (big) launch_pe_variant<true, false>(a, lds, grid, wps, st);
+  else if (timed) launch_pe_variant<false, true>(a, lds, grid, wps, st);
+  else launch_pe_variant<false, false>(a, lds, grid, wps, st);
   return hipGetLastError();
 }
 

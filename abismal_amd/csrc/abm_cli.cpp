@@ -739,7 +739,7 @@ int cmd_map(int argc, char **argv) {
     }
     // (the same expression the mappers use for a full batch, rounded up to whole slices as they do)
     auto env_reads = [](const char *name, size_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<size_t>(std::atoll(e)) : dflt; };
-    const size_t slice_for_reserve = env_reads("ABM_CLI_SLICE_READS", 1u << 16);
+    const size_t slice_for_reserve = env_reads("ABM_CLI_SLICE_READS", 1u << 15);
     size_t reserve_reads = opt.batch ? opt.batch : env_reads("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23));
     reserve_reads = (reserve_reads + slice_for_reserve - 1) / slice_for_reserve * slice_for_reserve + 256;
     {  // (no more than the input can hold: a record is at least two sequence-length lines)
@@ -810,7 +810,7 @@ int cmd_map(int argc, char **argv) {
   const int se_mode = opt.rpbat ? ABM_SE_RANDOM : ((opt.arich || opt.pbat) ? ABM_SE_A_RICH : ABM_SE_T_RICH);
   const int pe_mode = opt.rpbat ? ABM_PE_RANDOM : (opt.pbat ? ABM_PE_PBAT : ABM_PE_NORMAL);
 
-  // Pipeline.  The unit of host work is a SLICE (64 k records, in file order); every stage runs on many
+  // Pipeline.  The unit of host work is a SLICE (32 k records, in file order); every stage runs on many
   // slices at once and only the assignment of output offsets looks at their order:
   //   cut      plain files: a pool counts newlines chunk by chunk (pread), one thread turns the counts into
   //            slice byte ranges -- record j starts at line 4j, so no guessing at record boundaries;
@@ -833,7 +833,7 @@ int cmd_map(int argc, char **argv) {
   // (test hooks: ABM_CLI_SLICE_READS / ABM_CLI_CHUNK_BYTES / ABM_CLI_MARK_LINES shrink the units so that small
   // fixtures cross many slice, chunk and mark boundaries)
   auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
-  const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 16));
+  const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 15));
   // size of the run's very first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
   const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", (opt.reads.size() == 1 && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM")) ? 1u << 20 : 1u << 21));
   const bool plain_input = [&] {

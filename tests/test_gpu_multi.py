@@ -60,7 +60,7 @@ def test_cli_two_gpus_same_output_as_one(oracle, trex_index, tmp_path):
         lines[k + 1], lines[k + 3] = lines[k + 1][:cut], lines[k + 3][:cut]
     open(tmp_path / "r_1.fq", "w").write("\n".join(lines))
     body = {}
-    # slices and batches of 1024 reads (the units are 64 k reads by default: one slice would be one batch on one GPU)
+    # slices and batches of 1024 reads (the units are 32 k reads by default: one or two slices would be one batch on one GPU)
     env = dict(os.environ, ABM_CLI_SLICE_READS="1024", ABM_CLI_FIRST_BATCH="1024", ABM_CLI_CHUNK_BYTES="65536",
                ABM_CLI_MARK_LINES="64")
     for g in (1, 2):

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_reserve", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_batch_sliced", "abm_ctx_slice_results", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
-    "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_ctx_seed_extension",
+    "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_index_set_direct_narrowing", "abm_ctx_seed_extension",
 ]
 
 
@@ -154,6 +154,11 @@ class Index:
         self.max_candidates = self._lib.abm_index_max_candidates(h)
         self.window = self._lib.abm_index_window(h)
         self.device_bytes = self._lib.abm_index_bytes(h)
+
+    def set_direct_narrowing(self, min_entries):
+        """abm_index_set_direct_narrowing: smallest range the paired-end calls narrow directly (0 = never)."""
+        self._lib.abm_index_set_direct_narrowing.argtypes = [C.c_void_p, C.c_uint32]
+        _check(self._lib.abm_index_set_direct_narrowing(self.handle, int(min_entries)))
 
     def close(self):
         if self.handle:

@@ -121,6 +121,7 @@ struct abm_index {
   mutable std::mutex mu;  // guards the map itself and the wishes below (a replica's contents: DeviceReplica::mu)
   mutable std::map<int, DeviceReplica> replicas;  // by device ordinal; nodes stay for the index's lifetime
   uint32_t want_maxc = 0;  // max_candidates the tables are built for; 0 = the index file's
+  uint32_t direct_min = abm::kDirectMin;  // pair kernels: smallest range narrowed directly (abm_index_set_direct_narrowing)
 };
 
 struct abm_ctx {
@@ -638,6 +639,7 @@ namespace {
 abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
   abm::DevIndex d = ctx->dix;
   d.max_candidates = maxc;
+  { std::lock_guard<std::mutex> lk(ctx->ix->mu); d.direct_min = d.planes[0] != nullptr ? ctx->ix->direct_min : 0u; }
   DeviceReplica &rep = *ctx->rep;
   std::lock_guard<std::mutex> lk(rep.mu);
   if (rep.dix.ext_maxc != maxc && rep.ext_tried != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
@@ -719,6 +721,14 @@ int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3) {
     for (auto &r : ix->replicas) if (r.second.refs) throw std::invalid_argument("set the seed extension before the first context is created");
     ix->want_e2 = letters2;
     ix->want_e3 = letters3;
+  });
+}
+
+int abm_index_set_direct_narrowing(abm_index *ix, uint32_t min_entries) {
+  return guarded([&] {
+    if (!ix) throw std::invalid_argument("index is null");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->direct_min = min_entries;
   });
 }
 

@@ -57,7 +57,17 @@ struct DevIndex {
   // tabulated (bisect from the bucket's counters).
   const uint2 *ext2, *ext3t, *ext3a;
   u32 e2, e3, ext_maxc;
+  u32 direct_min;  // pair kernels: ranges of at least this many entries are narrowed directly (narrow_direct); 0 = never
 };
+constexpr u32 kSortDepth = 256;  // letters a bucket is sorted by (src/AbismalIndex.hpp: seed::n_sorting_positions)
+// direct narrowing of big ranges (narrow_direct, abm_kernels_core.hpp): the pair kernels, ranges of at least kDirectMin entries
+#ifndef ABM_PE_DIRECT_NARROWING
+#define ABM_PE_DIRECT_NARROWING true
+#endif
+#ifndef ABM_PE_DIRECT_MIN
+#define ABM_PE_DIRECT_MIN 128  // (2x150 at hg38 scale: 4.20-4.24 M reads/s at 128, 4.01-4.16 at 256, 4.01-4.21 at 64, 3.57-4.03 without; profiles/r03_exp_pe_direct_threshold.log)
+#endif
+constexpr u32 kDirectMin = ABM_PE_DIRECT_MIN;
 constexpr u32 kPlaneBlock = 64;       // bases per bit-plane block
 constexpr u32 kPlaneLineBlocks = 8;   // blocks per 128-byte line
 constexpr u32 kPlaneChunkBits = 12;   // nmap: log2 of the bases per chunk

@@ -63,14 +63,6 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const char *__restrict_
 // =============================================================================
 // Index upload: the genome's bit planes (DevIndex::planes).  Thread per block of 64 bases.
 // =============================================================================
-__device__ __forceinline__ u32 every_fourth_bit(u64 t) {  // bits 0, 4, 8, ... of t -> 16 contiguous bits
-  t &= 0x1111111111111111ull;
-  t = (t | (t >> 3)) & 0x0303030303030303ull;
-  t = (t | (t >> 6)) & 0x000F000F000F000Full;
-  t = (t | (t >> 12)) & 0x000000FF000000FFull;
-  t = (t | (t >> 24)) & 0xFFFFull;
-  return static_cast<u32>(t);
-}
 __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict__ genome, u64 n_words, u64 n_bases,
                                                           u64 n_blocks, u64 *__restrict__ p0, u64 *__restrict__ p1,
                                                           u32 *__restrict__ nmap, u32 *__restrict__ bad) {

@@ -320,6 +320,160 @@ __device__ __forceinline__ void narrow_both(const DevIndex &ix, const u32 *__res
   len3 = pB;
 }
 
+__device__ __forceinline__ u32 every_fourth_bit(u64 t) {  // bits 0, 4, 8, ... of t -> 16 contiguous bits
+  t &= 0x1111111111111111ull;
+  t = (t | (t >> 3)) & 0x0303030303030303ull;
+  t = (t | (t >> 6)) & 0x000F000F000F000Full;
+  t = (t | (t >> 12)) & 0x000000FF000000FFull;
+  t = (t | (t >> 24)) & 0xFFFFull;
+  return static_cast<u32>(t);
+}
+
+// ---- direct narrowing of big buckets ---------------------------------------------------------------------------
+// find_candidates / find_candidates_three extend a seed letter by letter while its range holds more than
+// max_candidates entries, each letter a bisection of the range: for a seed inside a high-copy repeat that is dozens of
+// letters times log2(range) dependent probes, each a random line -- a quarter of the kernel's line requests at hg38
+// scale.  The loop's outcome can be had with far fewer.  Let m(k) be the number of letters, from the current depth p0
+// on and at most T = limit - p0, that entry k shares with the read.  The range after t more letters is {k: m(k) >= t};
+// the loop stops at the first t whose range holds at most maxc entries (stepping back one letter if that range is
+// empty) or at T.  With V the (maxc + 1)-th largest m and Mmax the largest, that is t_f = V + 1 if V < T and Mmax > V,
+// else V.  A bucket is sorted by those very letters (src/AbismalIndex.cpp:857-978, 256 of them), so m rises towards the
+// place `ins` where the read would be inserted and falls after it: ins costs one bisection with whole-string
+// comparisons (64 letters per step from the bit planes), V is the best min(m(s), m(s + maxc)) over windows of
+// maxc + 1 entries around ins (a bisection on a monotone difference), and the final range's ends are two more
+// bisections -- log2(range) + ~30 probes in all, whatever the depth.  Exact wherever the bisections are: same sortedness
+// they rely on; entries within reach of an N (which the planes cannot express: nmap) send their lane back to the
+// letter-by-letter loop.  mode 0: 2-letter table; 1 / 2: 3-letter table, C->T / G->A alphabet (letter classes as
+// find_candidates_three orders them: below mid, mid, top and above).
+__device__ __forceinline__ void classes16(int mode, u64 x, u32 &c1, u32 &c2) {
+  const u64 y = mode == 1 ? x : x >> 1;  // sym = nib & 5: 1 -> class 1, 4 or 5 -> class 2;  sym = nib & 10: 2 -> class 1, 8 or 10 -> class 2
+  c2 = every_fourth_bit(y >> 2);
+  c1 = every_fourth_bit(y & ~(y >> 2));
+}
+// the read's letter classes for positions [s, s + 64) as two bit strings (2-letter table: its bit string and 0)
+__device__ __forceinline__ void read_classes64(int mode, const u64 *qb, u32 n_bits, const u64 *qpk, u32 W, u32 L, u32 s, u64 &r1, u64 &r2) {
+  if (mode == 0) {
+    const u32 w = s >> 6, sh = s & 63u;
+    const u64 a = s < n_bits ? qb[w] : ~0ull, b = s + 64 < n_bits ? qb[w + 1] : ~0ull;
+    r1 = sh ? (a >> sh) | (b << (64 - sh)) : a;
+    r2 = 0;
+    return;
+  }
+  r1 = r2 = 0;
+#pragma unroll
+  for (u32 j = 0; j < 4; ++j) {
+    u32 c1, c2;
+    classes16(mode, q_window16(qpk, W, s + 16 * j, L), c1, c2);
+    r1 |= static_cast<u64>(c1) << (16 * j);
+    r2 |= static_cast<u64>(c2) << (16 * j);
+  }
+}
+// (Inlined into the single-end kernel this search cost more than it saved: that kernel runs at the register budget of
+// its filter loop, and 200 bytes per lane of scratch instead of 100 made every read slower -- 729 -> 780 ms per 10 M
+// reads although the probes fell from 585 to 241 per read; profiles/r03_exp_direct_narrowing_*.  The pair kernels, built
+// for 128 / 170 registers and bound by line requests of which a quarter are narrowing probes, are where it runs.)
+struct DirectArgs { const u64 *planes0; const u32 *nmap; const u64 *qb; const u64 *qpk; u32 n_bits, W, L, maxc; };
+struct DirectRange { u32 lo, hi, len, probes; bool ok; };
+__device__ __forceinline__ DirectRange narrow_direct(int mode, DirectArgs da, const u32 *__restrict__ tbl, u32 qbase, u32 limit, u32 lo, u32 hi, u32 len) {
+  const u64 *qb = da.qb, *qpk = da.qpk;
+  const u32 n_bits = da.n_bits, W = da.W, L = da.L, maxc = da.maxc;
+  u32 probes = 0;
+  const u32 p0 = len, T = limit - p0, s0 = qbase + p0;
+  u64 R1, R2;
+  read_classes64(mode, qb, n_bits, qpk, W, L, s0, R1, R2);
+  bool bad = false;
+  // m(k) and how entry k compares with the read (cmp < 0: before it)
+  auto eval = [&](u32 k, int &cmp) -> u32 {
+    ++probes;
+    const u64 q = static_cast<u64>(tbl[k]) + p0;
+    if ((da.nmap[q >> (kPlaneChunkBits + 5)] >> ((q >> kPlaneChunkBits) & 31u)) & 1u) bad = true;
+    for (u32 w = 0; 64 * w < T; ++w) {
+      const u64 at = q + 64 * w;
+      const u64 *b = da.planes0 + 2 * (at / kPlaneBlock);
+      const u32 sh = static_cast<u32>(at % kPlaneBlock);
+      u64 gl = b[0] >> sh, gh = b[1] >> sh;
+      if (sh) { gl |= b[2] << (64 - sh); gh |= b[3] << (64 - sh); }
+      u64 r1 = R1, r2 = R2;
+      if (w) read_classes64(mode, qb, n_bits, qpk, W, L, s0 + 64 * w, r1, r2);
+      const u64 g1 = mode == 0 ? gl : (mode == 1 ? ~gl & ~gh : gl & ~gh);
+      const u64 g2 = mode == 0 ? 0ull : (mode == 1 ? ~gl & gh : gl & gh);
+      u64 x = (g1 ^ r1) | (g2 ^ r2);
+      const u32 have = T - 64 * w;
+      if (have < 64) x &= (1ull << have) - 1;
+      if (x) {
+        const u32 j = static_cast<u32>(__builtin_ctzll(x));
+        const u32 gv = static_cast<u32>((g1 >> j) & 1ull) + 2u * static_cast<u32>((g2 >> j) & 1ull);
+        const u32 rv = static_cast<u32>((r1 >> j) & 1ull) + 2u * static_cast<u32>((r2 >> j) & 1ull);
+        cmp = gv < rv ? -1 : 1;
+        return 64 * w + j;
+      }
+    }
+    cmp = 0;
+    return T;
+  };
+  // One loop, one probe per turn, whatever step of the search a lane is at (lanes of a wave are at different ones):
+  //  kIns   bisection for `ins`, where the read would be inserted
+  //  kWinL / kWinR  bisection for the first window start s1 with m(s1) >= m(s1 + maxc): m(s) - m(s + maxc) is <= 0 for
+  //         windows left of ins, >= 0 from ins on and monotone in between, so the best window is at the sign change
+  //  kV1 / kV2  V = max(m(s1 + maxc), m(s1 - 1)), whichever exist
+  //  kM1 / kM2  the largest m: next to ins
+  //  kLeft / kRight  the ends of {k: m(k) >= tf} (m does not fall towards ins from either side)
+  enum { kIns, kWinL, kWinR, kV1, kV2, kM1, kM2, kTf, kLeft, kRight, kDone };
+  const u32 d_lo = lo, d_hi = hi - 1 - maxc;  // window starts: s in [d_lo, d_hi]  (hi - lo > maxc)
+  int phase = kIns;
+  u32 base = lo, cnt = hi - lo, ins = lo, s1 = 0, sx = 0, ml = 0, V = 0, mmax = 0, tf = 0, left = lo, right = hi, r_end = hi;
+  while (phase != kDone) {
+    // transitions that need no probe
+    if (phase == kIns && cnt == 0) {
+      ins = base;
+      const u32 a = ins > maxc + 1 ? max(d_lo, ins - maxc - 1) : d_lo, b_end = min(d_hi, ins);
+      base = min(a, b_end); cnt = b_end + 1 - base;
+      phase = kWinL;
+    }
+    if (phase == kWinL && cnt == 0) { s1 = base; phase = kV1; }
+    if (phase == kV1 && s1 > d_hi) phase = kV2;
+    if (phase == kV2 && s1 <= d_lo) phase = kM1;
+    if (phase == kM1 && ins <= lo) phase = kM2;
+    if (phase == kM2 && ins >= hi) phase = kTf;
+    if (phase == kTf) {
+      tf = (V < T && mmax > V) ? V + 1 : V;
+      u32 l0 = lo;
+      r_end = hi;
+      if (tf == V + 1) { l0 = ins > maxc ? max(lo, ins - maxc) : lo; r_end = min(hi, ins + maxc); }  // (at most maxc entries, all next to ins)
+      if (tf == 0) { left = lo; right = hi; phase = kDone; }
+      else { base = l0; cnt = ins - l0; phase = kLeft; }
+    }
+    if (phase == kLeft && cnt == 0) { left = base; base = ins; cnt = r_end - ins; phase = kRight; }
+    if (phase == kRight && cnt == 0) { right = base; phase = kDone; }
+    if (phase == kDone) break;
+    // this turn's probe
+    const u32 half = cnt >> 1;
+    u32 k;
+    if (phase == kIns || phase == kLeft || phase == kRight) k = base + half;
+    else if (phase == kWinL) { sx = base + half; k = sx; }
+    else if (phase == kWinR) k = sx + maxc;
+    else if (phase == kV1) k = s1 + maxc;
+    else if (phase == kV2) k = s1 - 1;
+    else if (phase == kM1) k = ins - 1;
+    else k = ins;
+    int c;
+    const u32 m = eval(k, c);
+    if (phase == kIns) { if (c < 0) { base += half + 1; cnt -= half + 1; } else cnt = half; }
+    else if (phase == kWinL) { ml = m; phase = kWinR; }
+    else if (phase == kWinR) { if (ml < m) { base = sx + 1; cnt -= half + 1; } else cnt = half; phase = kWinL; }
+    else if (phase == kV1) { V = max(V, m); phase = kV2; }
+    else if (phase == kV2) { V = max(V, m); phase = kM1; }
+    else if (phase == kM1) { mmax = max(mmax, m); phase = kM2; }
+    else if (phase == kM2) { mmax = max(mmax, m); phase = kTf; }
+    else if (phase == kLeft) { if (m < tf) { base += half + 1; cnt -= half + 1; } else cnt = half; }
+    else { if (m >= tf) { base += half + 1; cnt -= half + 1; } else cnt = half; }
+  }
+  DirectRange out;
+  out.lo = left; out.hi = right; out.len = p0 + tf; out.probes = probes; out.ok = !bad;
+  return out;
+}
+
+
 // full_compare (src/abismal.cpp:1105-1122).  The reference adds one word's mismatches at a
 // time and gives up as soon as the running sum exceeds the cutoff, so a candidate is admitted
 // iff EVERY prefix sum stays within the cutoff, and then with the complete distance.  Both are
@@ -658,6 +812,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   // work tallies: the paired-end kernels and the single-end kernel's diagnostic build keep them; the single-end
   // production kernel does not (they cost it registers: 100 -> 64 bytes per lane of scratch without them)
   constexpr bool TALLY = TIMED || Set::kAppend;
+  // direct narrowing of big ranges: in the pair kernels only (see narrow_direct)
+  constexpr bool kDirect = Set::kAppend && ABM_PE_DIRECT_NARROWING;
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
   if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
     for (u32 k = lane; k < (1u << kPosCacheBits); k += 64) lds.pcache[k] = 0;
@@ -708,6 +864,27 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         else {
           lo2 = ix.counter[k2]; hi2 = ix.counter[k2 + 1];
           lo3 = cnt3[k3];       hi3 = cnt3[k3 + 1];
+        }
+        if constexpr (kDirect) {
+          if (ix.direct_min != 0 && L <= kSortDepth && ix.planes[0] != nullptr) {
+            // big ranges -- seeds inside high-copy repeats -- are narrowed directly (narrow_direct); small ones, and
+            // lanes whose probes come within reach of an N, by the letter-by-letter loop below
+            const u32 limit = L - i;
+            const DirectArgs da = {ix.planes[0], ix.nmap, qb, qpk, 64u * lds.WB, lds.W, L, maxc};
+#pragma unroll 1
+            for (int chain = 0; chain < 2; ++chain) {  // (one copy of the search in the code: 2-letter table, then the 3-letter one)
+              const bool three = chain != 0;
+              const u32 clo = three ? lo3 : lo2, chi = three ? hi3 : hi2, clen = three ? len3 : len2;
+              if ((three ? run3 : run2) && chi - clo >= ix.direct_min && chi - clo > maxc && clen != limit) {
+                const DirectRange r = narrow_direct(three ? (g_to_a ? 2 : 1) : 0, da, three ? idx3 : ix.index, i, limit, clo, chi, clen);
+                probes += r.probes;
+                if (r.ok) {
+                  if (three) { lo3 = r.lo; hi3 = r.hi; len3 = r.len; run3 = false; }
+                  else { lo2 = r.lo; hi2 = r.hi; len2 = r.len; run2 = false; }
+                }
+              }
+            }
+          }
         }
         narrow_both(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, run2, lo2, hi2, len2, run3, lo3, hi3, len3, probes);
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;

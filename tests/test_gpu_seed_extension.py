@@ -89,3 +89,29 @@ def test_pe_with_and_without_tables(oracle, rep):
         finally:
             ctx.close()
             ix.close()
+
+
+@pytest.mark.parametrize("min_entries", [0, 16, 64, 100000])
+def test_pe_direct_narrowing_any_threshold(oracle, rep, min_entries):
+    """abm_index_set_direct_narrowing: whichever ranges the pair kernels narrow directly (none, nearly all, only
+    the big ones, none because the threshold is never reached) -- with and without seed-extension tables in front of
+    it -- the pairs, fallback hits and CIGARs equal the oracle's."""
+    import abismal_amd as A
+    from tests import synth
+    fa, idx, oix = rep
+    r1, r2 = synth.mutated_pairs(fa, 3000, 100, seed=13)
+    r1, r2 = synth.trim_like_readloader(r1), synth.trim_like_readloader(r2)
+    orc = oracle.map_pe(oix, r1, r2, mode=0, threads=8)
+    for letters in ((0, 0), (3, 2)):
+        ix = A.Index(idx, seed_extension=letters)
+        ix.set_direct_narrowing(min_entries)
+        ctx = A.Context(ix, 0)
+        try:
+            compare_pe(ctx.map_pe(r1, r2, mode=0), orc, f"PE direct narrowing from {min_entries} entries, tables {letters}")
+            if min_entries == 16:  # (also at -c 20: ranges stay big for longer)
+                p = A.Params(max_candidates=20)
+                orc20 = oracle.map_pe(oix, r1, r2, mode=0, threads=8, max_candidates=20)
+                compare_pe(ctx.map_pe(r1, r2, mode=0, params=p), orc20, f"PE direct narrowing from 16 entries, -c 20, tables {letters}")
+        finally:
+            ctx.close()
+            ix.close()

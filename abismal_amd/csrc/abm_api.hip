@@ -55,7 +55,7 @@ struct HostTrace {
   }
 };
 
-// Experiment switches (ABM_COOP_WINDOWS, ABM_GRID_WAVES, ABM_PLANES_COPIES, ABM_EXT_LETTERS) are honoured only when
+// Experiment switches (ABM_COOP_WINDOWS, ABM_GRID_WAVES, ABM_PLANES_COPIES, ABM_EXT_LETTERS, ABM_PE_WPS / ABM_PE_WPS2) are honoured only when
 // ABM_EXPERIMENTS=1 is set as well: a stray variable in a production environment changes nothing.
 const char *experiment_env(const char *name) {
   static const bool on = [] { const char *e = std::getenv("ABM_EXPERIMENTS"); return e && e[0] == '1'; }();
@@ -592,7 +592,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   {
     a.cap = abm::kPeTier1Cap;
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, false);
-    const int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    if (const char *e = experiment_env("ABM_PE_WPS")) { if (!ctx->phase_stamps && a.G != 0 && (e[0] == '3' || e[0] == '4')) wps = e[0] - '0'; }
     const int waves = abm::pe_resident_waves(lds, false, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 1) does not fit on this device");
     ctx->payload1.reserve(static_cast<size_t>(waves) * a.cap);
@@ -611,7 +612,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     a.cap = abm::kPeCapLarge;
     a.order = nullptr;
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, true);
-    const int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    if (const char *e = experiment_env("ABM_PE_WPS2")) { if (!ctx->phase_stamps && a.G != 0 && (e[0] == '3' || e[0] == '4')) wps = e[0] - '0'; }
     const int waves = abm::pe_resident_waves(lds, true, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
     ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);

@@ -29,7 +29,8 @@ import os
 # Paired-end steps of several (context, stream) slots overlap on the device (tier 2 ends in a few pairs that keep
 # single waves busy for seconds); the HIP runtime multiplexes streams onto 4 hardware queues unless told otherwise,
 # and must be told before it starts.  Measured at hg38 scale, 1 M pairs per step: 4 queues / 3 slots 1.8 M reads/s,
-# 16 queues / 12 slots 3.0 M reads/s (scripts/r02_pe_queues.sh).  Single-end is unaffected.
+# 16 queues / 12 slots 3.0 M reads/s (scripts/r02_pe_queues.sh); round 3's kernels: 16 slots 4.2-4.4 M against 4.1-4.2 M
+# with 12 (profiles/r03_exp_pe_slots.log).  Single-end is unaffected.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import json
 import os
@@ -656,7 +657,7 @@ def main():
     ap.add_argument("--pe", action="store_true",
                     help="paired-end variant (BASELINE config 3): 2 x --read-len pairs from 150-500 bp fragments; "
                          "not the headline metric -- prints its own JSON line")
-    ap.add_argument("--streams", type=int, default=12,
+    ap.add_argument("--streams", type=int, default=16,
                     help="--pe only: consecutive steps alternate over this many (context, stream) slots")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="SE: number of different synthetic batches the steps cycle through")
@@ -1012,7 +1013,7 @@ def main():
         other = {}
         common = [sys.executable, os.path.abspath(__file__), "--no-e2e", "--no-other-configs", "--genome-mbp", str(args.genome_mbp),
                   "--workdir", args.workdir]
-        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "12", "--warmup", "12", "--cpu-sample", "200000"]),
+        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "16", "--warmup", "16", "--cpu-sample", "200000"]),
                            ("config5_random_pbat_150", ["--mode", "random", "--read-len", "150", "--reads", "4000000", "--steps", "3", "--warmup", "1",
                                                         "--cpu-sample", "200000"])):
             t0 = time.time()

@@ -95,6 +95,9 @@ hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *cla
 #define ABM_PE_TIER1_CAP 128
 #endif
 constexpr u32 kPeTier1Cap = ABM_PE_TIER1_CAP;
+// (a power of two: sort_unique pads a list to the next power of two inside a buffer of this many entries -- builds with
+// 48 and 96 returned wrong pairs, profiles/r03_exp_pe_tier1_cap_small.log; 32 ... 256 measured: 64 and 128 level, 256 slower)
+static_assert(kPeTier1Cap >= 32 && (kPeTier1Cap & (kPeTier1Cap - 1)) == 0, "tier-1 list capacity: a power of two, at least the sets' initial 32");
 
 u32 se_window_words(u32 max_len, double valid_frac);
 size_t se_lds_bytes(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_frac);

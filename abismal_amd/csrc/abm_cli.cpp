@@ -835,7 +835,7 @@ int cmd_map(int argc, char **argv) {
   auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
   const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 15));
   // size of the run's very first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
-  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", (opt.reads.size() == 1 && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM")) ? 1u << 20 : 1u << 21));
+  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", (opt.reads.size() == 1 && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM")) ? 1u << 19 : 1u << 21));
   const bool plain_input = [&] {
     for (const std::string &path : opt.reads) {
       const int fd = ::open(path.c_str(), O_RDONLY);
@@ -1233,8 +1233,10 @@ int cmd_map(int argc, char **argv) {
           // the next one is being mapped.
           // Batches whose results leave slice by slice (single-end) are sized the other way round at the end: a
           // slice is complete when its costliest read is, a fifth of a second into the kernel, so only a LONG last
-          // kernel leaves time to format and write most of its output while it still runs -- 1 M reads first, then
-          // four times as many per batch up to -batch, and what is left in as few batches as possible.
+          // kernel leaves time to format and write most of its output while it still runs -- 512 k reads first, then
+          // four times as many per batch up to -batch, and what is left in as few batches as possible (10 M reads:
+          // 0.5 M, 2 M, 7.5 M -- 0.737-0.796 s against 0.817-0.831 s with 1 M, 3 M, 6 M on the same box,
+          // profiles/r03_exp_e2e_first_batch.log).
           auto target = [&]() -> size_t {
             size_t cap = batch_reads;
             const uint64_t grown = std::min<uint64_t>(gpu_batches[g], 10) * (stream_slices ? 2 : 1);

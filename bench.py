@@ -996,7 +996,10 @@ def main():
         ctx.close()
         index.close()
         torch.cuda.empty_cache()
-        e2e = run_e2e(args, idx, fasta, L, gpus=world)
+        try:
+            e2e = run_e2e(args, idx, fasta, L, gpus=world)
+        except Exception as exc:  # the line's `value` has been measured: a failing end-to-end leg must not lose it
+            e2e = {"error": f"{type(exc).__name__}: {exc}"[:1500]}
         log(f"e2e: {e2e}")
 
     # the other single-GPU configurations of BASELINE.json, each by a fresh child process of this script once this

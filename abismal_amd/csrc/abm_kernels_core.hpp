@@ -875,7 +875,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
             for (int chain = 0; chain < 2; ++chain) {  // (one copy of the search in the code: 2-letter table, then the 3-letter one)
               const bool three = chain != 0;
               const u32 clo = three ? lo3 : lo2, chi = three ? hi3 : hi2, clen = three ? len3 : len2;
-              if ((three ? run3 : run2) && chi - clo >= ix.direct_min && chi - clo > maxc && clen != limit) {
+              // (clen < limit: the last offsets of a 44-46-base read start BEYOND the end of the read -- limit = L - i is below the
+              // key weight -- and the reference extends those through whatever its reused buffer holds: the letter loop's
+              // business, with the ghost bits)
+              if ((three ? run3 : run2) && chi - clo >= ix.direct_min && chi - clo > maxc && clen < limit) {
                 const DirectRange r = narrow_direct(three ? (g_to_a ? 2 : 1) : 0, da, three ? idx3 : ix.index, i, limit, clo, chi, clen);
                 probes += r.probes;
                 if (r.ok) {

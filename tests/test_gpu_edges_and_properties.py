@@ -329,6 +329,11 @@ def test_ghost_reads(oracle, tmp_path_factory, mode, maxc):
         orc = oracle.map_pe(oix, r1, r2, mode=mode, max_candidates=maxc, threads=1)
         gpu = ctx.map_pe(r1, r2, mode=mode, params=A.Params(max_candidates=maxc))
         compare_pe(gpu, orc, f"ghost pairs mode {mode} -c {maxc}")
+        # ... and with the pair kernels narrowing every range above -c directly: the offsets that start beyond a
+        # short read's end must still go through the letter loop and its ghost bits
+        ix.set_direct_narrowing(1)
+        gpu = ctx.map_pe(r1, r2, mode=mode, params=A.Params(max_candidates=maxc))
+        compare_pe(gpu, orc, f"ghost pairs mode {mode} -c {maxc}, direct narrowing from 1 entry")
     finally:
         oracle.index_free(oix)
         ctx.close()

@@ -174,7 +174,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     r_next = next_read();  // fetched early; its latency hides under this read's work
     long long t_read = 0;
     if (TIMED) t_read = clock64();
-    const bool overflow_before = overflow;
+    bool rd_overflow = false;  // THIS read's CIGAR found no room (the launch's flag `overflow` is sticky)
     const u32 L = a.lens[r];
     Hit best;
     best.diffs = 0x7fff; best.flags = 0; best.pos = 0;
@@ -215,7 +215,8 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         }
       }
       ABM_STAMP(t_a);
-      choose_se<LONG>(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, overflow, n_aln, n_single);  // (n_aln, n_single: dead unless TIMED)
+      choose_se<LONG>(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, rd_overflow, n_aln, n_single);  // (n_aln, n_single: dead unless TIMED)
+      overflow |= rd_overflow;
       ABM_STAMP(t_b);
       if (TIMED) wt.t_align += t_b - t_a;
     }
@@ -233,7 +234,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       // found no room in the arena never counts: its slice stays open and the host maps the batch again.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every store of this wave acknowledged)
-      if (lane == 0 && !(overflow && !overflow_before)) {
+      if (lane == 0 && !rd_overflow) {
         const u32 sl = a.slice_id[r];
         if (sl != 0xFFFFu && atomicSub(&a.slice_left[sl], 1u) == 1u) {
           __threadfence_system();

@@ -89,3 +89,40 @@ def test_arena_overflow_maps_again_and_hands_no_slice_twice(trex_index):
     finally:
         c.close()
         ix.close()
+
+
+_MANY_PER_WAVE = r"""
+import sys
+import numpy as np
+import abismal_amd as A
+from tests.test_gpu_edges_and_properties import _reads_from_genome, cigars
+idx = sys.argv[1]
+rs = _reads_from_genome(idx, [1000] * 9000, seed=8, indel_every=100)
+first = list(range(0, 9000, 500)) + [9000]
+ix = A.Index(idx)
+c = A.Context(ix, 0)
+s_res, s_cig, s_off, arrived = c.map_se_sliced(rs, first)
+assert sorted(arrived) == list(range(len(first) - 1)), arrived
+assert int(s_off[-1]) > 70000, "the batch must overflow the default arena"
+res, cig, off = c.map_se(rs)
+for f in ("pos", "diffs", "flags"):
+    assert (res[f] == s_res[f]).all(), f
+a, b = cigars(cig, off), cigars(s_cig, s_off)
+bad = [i for i in range(len(a)) if a[i] != b[i]]
+assert not bad, f"{len(bad)} reads handed over with another CIGAR than the whole-batch call's, first {bad[:5]}"
+c.close(); ix.close()
+print("ok")
+"""
+
+
+def test_arena_overflow_with_many_overflowing_reads_per_wave(trex_index):
+    # ADVICE r3 (high): `overflow` was sticky per wave, so only a wave's FIRST read without room in the arena kept its
+    # slice open; every later one was handed over truncated.  64 waves for 9000 reads = 140 overflowing reads per wave
+    # (the grid switch is an experiment variable read once per process: a child process).
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ABM_EXPERIMENTS="1", ABM_GRID_WAVES="64", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _MANY_PER_WAVE, trex_index], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

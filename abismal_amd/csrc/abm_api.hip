@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -682,6 +683,19 @@ void abm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int abm_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+// NUMA node of the host memory nearest to a device (sysfs, from the device's PCI address); -1 = unknown
+int abm_device_numa_node(int device) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, static_cast<int>(sizeof(bdf)), device) != hipSuccess) return -1;
+  for (char *c = bdf; *c; ++c) *c = static_cast<char>(std::tolower(static_cast<unsigned char>(*c)));
+  const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+  std::FILE *f = std::fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int node = -1;
+  if (std::fscanf(f, "%d", &node) != 1) node = -1;
+  std::fclose(f);
+  return node;
 }
 uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx) { return ctx ? ctx->too_long : 0; }
@@ -1381,6 +1395,19 @@ int abm_stats_allreduce(abm_ctx *const *ctxs, int n_ctx, uint64_t *const *counte
     static std::map<std::vector<int>, Group> groups;
     std::vector<int> devs(n_ctx);
     for (int k = 0; k < n_ctx; ++k) { if (!ctxs[k]) throw std::invalid_argument("null context"); devs[k] = ctxs[k]->device; }
+    {
+      // Contexts that share a device (replicas of the sharding on one GPU: `abismal-amd map -devices 0,0`, tests on a
+      // one-GPU box) cannot be two ranks of one communicator -- RCCL refuses a device listed twice -- so their counters
+      // are summed here on the host; the collective is for distinct devices.
+      std::vector<int> sorted(devs);
+      std::sort(sorted.begin(), sorted.end());
+      if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+        unsigned long long total[18] = {0};
+        for (int k = 0; k < n_ctx; ++k) for (int j = 0; j < 18; ++j) total[j] += counters[k][j];
+        for (int k = 0; k < n_ctx; ++k) for (int j = 0; j < 18; ++j) counters[k][j] = total[j];
+        return;
+      }
+    }
     auto nccl_check = [](ncclResult_t r, const char *what) {
       if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
     };

@@ -9,6 +9,8 @@
 #include "../../include/abismal_amd.h"
 
 #include <fcntl.h>
+#include <sched.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <malloc.h>
@@ -150,7 +152,11 @@ struct Batch;
 // The unit of host work: up to `slice_reads` records of the input, in file order.  Slices are cut,
 // parsed, formatted and written independently; a batch handed to a GPU is a run of consecutive slices.
 struct Slice {
-  uint64_t g = 0;                    // slice number = output order
+  uint64_t g = 0;                    // slice number within its region = output order
+  int region = 0;                    // which contiguous share of the input (= which output file) it belongs to
+  int node = 0;                      // NUMA node its buffers were first touched on: where it is parsed and formatted
+  uint64_t place = 0;                // its text's offset in the region's file, once every earlier slice's size is known
+  std::vector<uint32_t> tail;        // records that can still be a ghost-bit source for later reads (ghost_tail)
   uint64_t first_line[2] = {0, 0};
   uint64_t byte_lo[2] = {0, 0}, byte_hi[2] = {0, 0};  // plain files: the slice's text in each file
   RawBuf raw[2];                     // the FASTQ text (names point into it)
@@ -192,15 +198,18 @@ struct SlicePool {
     s->batch = nullptr;
     s->base = 0;
     s->own = false;
+    s->tail.clear();
     std::lock_guard<std::mutex> lk(mu);
     if (free_list.size() < 1024) free_list.push_back(std::move(s));
   }
 };
 
+bool g_pin_batches = true;  // batch blobs in page-locked memory (not with virtual GPUs: it comes from the HIP runtime)
 struct Batch {
-  Batch() { for (int e = 0; e < 2; ++e) blob[e].pinned = off_bytes[e].pinned = true; }
+  Batch() { for (int e = 0; e < 2; ++e) blob[e].pinned = off_bytes[e].pinned = g_pin_batches; }
   uint64_t seq = 0;
   int gpu = 0;
+  int node = 0;                      // NUMA node of its GPU: the pool it returns to
   std::vector<std::unique_ptr<Slice>> slices;
   size_t n = 0;
   std::vector<std::string> carry[2]; // reads of the input just before this batch, mapped along for their side effects only
@@ -213,6 +222,28 @@ struct Batch {
   PodVec<uint64_t> cig_off[2];
   int slices_left = 0;               // not yet written
 };
+
+// What a read of 44-46 bases finds past its end comes, position by position, from the nearest EARLIER
+// read that is longer than that position -- up to 64 positions out, so a read of kGhostReach = 46 + 64 bases hides
+// everything before it, and reads the reference never preps (shorter than the index's minimum) leave nothing.
+// ghost_tail: of n records (off[e][k], off[e][k + 1]: read k of end e), scanning backwards, those that are longer in
+// some end than every record after them, until all ends have reached kGhostReach -- the only records of this input
+// that can still be such a source for reads that come later.  Indices in descending order; at most 67 per end.
+constexpr uint32_t kGhostReach = 110;
+inline uint32_t ghost_len(uint64_t len) { return len < g_min_read_len ? 0u : static_cast<uint32_t>(std::min<uint64_t>(len, kGhostReach)); }
+std::vector<uint32_t> ghost_tail(const std::vector<uint64_t> *off, size_t n, int ends) {
+  std::vector<uint32_t> out;
+  uint32_t reach[2] = {0, ends == 2 ? 0u : kGhostReach};
+  for (size_t k = n; k-- > 0 && (reach[0] < kGhostReach || reach[1] < kGhostReach);) {
+    bool raises = false;
+    for (int e = 0; e < ends; ++e) {
+      const uint32_t len = ghost_len(off[e][k + 1] - off[e][k]);
+      if (len > reach[e]) { raises = true; reach[e] = len; }
+    }
+    if (raises) out.push_back(static_cast<uint32_t>(k));
+  }
+  return out;
+}
 
 // batches are recycled with their buffers as well (a full batch's arrays are a gigabyte)
 struct BatchPool {
@@ -615,8 +646,12 @@ struct Options {
   int ext2 = -1, ext3 = -1;  // -seed-ext a,b: letters of the seed-extension tables (default: chosen from the index's size)
   bool skip_long = false;     // -skip-long: pairs with an end beyond the paired-end kernels' 1024 bases are written unmapped
                               // (and counted in the warning) instead of failing the run
-  bool host_ceiling = false;  // -host-ceiling (diagnostic): no mapping call; every read gets a made-up hit, so that cut ->
-                              // parse -> format -> write run at the rate the host can carry (single-end input)
+  bool host_ceiling = false;  // -host-ceiling / -virtual-gpus N (diagnostic): no device and no mapping call; every "GPU" hands
+                              // back made-up hits at once, so that count -> cut -> parse -> deal -> format -> write run at the
+                              // rate the host can carry around N GPUs (single-end input)
+  std::vector<int> devices;   // -devices a,b,...: GPU g of the run is device ordinal devices[g]; an ordinal may repeat
+                              // (replicas of the sharding on one device)
+  int out_parts = 1;          // -out-parts R: the input's R contiguous shares mapped side by side, each into <out>.partNNN
   double max_distance = 0.1;
   std::vector<std::string> reads;
 };
@@ -648,6 +683,17 @@ Options parse_map(int argc, char **argv) {
     else if (k == "batch") o.batch = std::stoul(need(i));
     else if (k == "mappers") o.mappers = std::stoi(need(i));
     else if (k == "host-ceiling") o.host_ceiling = true;
+    else if (k == "virtual-gpus") { o.host_ceiling = true; o.gpus = std::stoi(need(i)); }
+    else if (k == "devices") {
+      const std::string v = need(i);
+      for (size_t at = 0; at < v.size();) {
+        size_t used = 0;
+        o.devices.push_back(std::stoi(v.substr(at), &used));
+        at += used;
+        if (at < v.size() && v[at] == ',') ++at;
+      }
+    }
+    else if (k == "out-parts") o.out_parts = std::stoi(need(i));
     else if (k == "skip-long") o.skip_long = true;
     else if (k == "seed-ext") { const std::string v = need(i); if (std::sscanf(v.c_str(), "%d,%d", &o.ext2, &o.ext3) != 2) throw std::runtime_error("-seed-ext wants two numbers: a,b"); }
     else if (k == "timing") o.timing = need(i);  // JSON: reads, seconds (first batch submitted -> last byte written), stage busy times
@@ -676,12 +722,82 @@ int cmd_idx(int argc, char **argv) {
   return EXIT_SUCCESS;
 }
 
+// ---- where threads run and where their memory lives --------------------------------------------------------------
+// The NUMA nodes of the box and the CPUs this process may use on each (its affinity mask at start-up), the first SMT
+// sibling of every core listed apart: a group of threads that fits on a node's cores is kept off their second siblings.
+// ABM_CLI_PIN=0 leaves every thread where the scheduler puts it (round 3's behaviour).
+struct Topology {
+  std::vector<std::vector<int>> primary, all;  // [node] -> CPUs
+  bool pinning = true;
+  static std::vector<int> parse_list(const std::string &s) {
+    std::vector<int> out;
+    size_t i = 0;
+    while (i < s.size() && std::isdigit(static_cast<unsigned char>(s[i]))) {
+      const int a = std::atoi(s.c_str() + i);
+      while (i < s.size() && std::isdigit(static_cast<unsigned char>(s[i]))) ++i;
+      int b = a;
+      if (i < s.size() && s[i] == '-') { ++i; b = std::atoi(s.c_str() + i); while (i < s.size() && std::isdigit(static_cast<unsigned char>(s[i]))) ++i; }
+      for (int c = a; c <= b; ++c) out.push_back(c);
+      if (i < s.size() && s[i] == ',') ++i;
+    }
+    return out;
+  }
+  static std::string first_line(const std::string &path) {
+    std::ifstream f(path);
+    std::string s;
+    std::getline(f, s);
+    return s;
+  }
+  Topology() {
+    if (const char *e = std::getenv("ABM_CLI_PIN")) pinning = e[0] != '0';
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    const bool have_mask = sched_getaffinity(0, sizeof(mine), &mine) == 0;
+    for (int n = 0; n < 64; ++n) {
+      const std::vector<int> cpus = parse_list(first_line("/sys/devices/system/node/node" + std::to_string(n) + "/cpulist"));
+      if (cpus.empty()) { if (n == 0) continue; else break; }
+      std::vector<int> p, a;
+      for (int c : cpus) {
+        if (have_mask && !CPU_ISSET(c, &mine)) continue;
+        a.push_back(c);
+        const std::vector<int> sib = parse_list(first_line("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/thread_siblings_list"));
+        if (sib.empty() || sib.front() == c) p.push_back(c);
+      }
+      if (a.empty()) continue;
+      if (p.empty()) p = a;
+      primary.push_back(p);
+      all.push_back(a);
+    }
+    if (all.empty()) {  // no sysfs: one node holding whatever the mask allows
+      std::vector<int> a;
+      for (int c = 0; c < CPU_SETSIZE; ++c) if (!have_mask || CPU_ISSET(c, &mine)) { if (have_mask || c < static_cast<int>(std::thread::hardware_concurrency())) a.push_back(c); }
+      primary.push_back(a);
+      all.push_back(a);
+      pinning = false;
+    }
+  }
+  int n_nodes() const { return static_cast<int>(all.size()); }
+  size_t n_cores() const { size_t k = 0; for (const auto &p : primary) k += p.size(); return k; }
+  // the calling thread onto `node`: onto its cores' first siblings while the `group` threads that share the node fit there
+  void pin(int node, size_t group) const {
+    if (!pinning) return;
+    const std::vector<int> &cpus = group <= primary[node].size() ? primary[node] : all[node];
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof(set), &set);
+  }
+};
+
 int cmd_map(int argc, char **argv) {
   const Options opt = parse_map(argc, argv);
   if (opt.out.empty()) { std::cerr << "Missing required argument\n-o, -outfile\n"; return EXIT_SUCCESS; }
   if (opt.reads.size() != 1 && opt.reads.size() != 2) { std::cerr << "usage: abismal-amd map -i idx -o out.sam [flags] reads_1.fq [reads_2.fq]\n"; return EXIT_SUCCESS; }
   if (opt.index.empty() == opt.genome.empty()) { std::cerr << "Select one of index file (-i) or genome file (-g)\n"; return EXIT_SUCCESS; }
   const bool paired = opt.reads.size() == 2;
+  const int ends = paired ? 2 : 1;
+  if (opt.host_ceiling && paired) throw std::runtime_error("-host-ceiling / -virtual-gpus take single-end input");
+  const Topology topo;
 
   std::string index_path = opt.index;
   if (index_path.empty()) {  // -g: index the genome on the fly (src/abismal.cpp:2439-2446)
@@ -697,38 +813,64 @@ int cmd_map(int argc, char **argv) {
   for (uint32_t i = 0; i < abm_index_n_chroms(ix); ++i) ch.names.push_back(abm_index_chrom_name(ix, i));
   ch.starts.assign(abm_index_chrom_starts(ix), abm_index_chrom_starts(ix) + ch.names.size() + 1);
 
-  // one replica of the index in each GPU's HBM, shared by that GPU's contexts; a context is one
-  // mapper thread's workspaces + stream, and two per GPU keep the device busy while the other
-  // thread's batch is in transit over PCIe
-  int n_gpus = opt.gpus;
+  // GPUs.  "GPU g" of the run is device dev_of[g]: the visible devices in order, the first -gpus of them, or the list
+  // -devices gives -- in which a device may appear more than once (replicas of the read sharding on one GPU: how a
+  // one-GPU box runs the multi-GPU code path).  -host-ceiling / -virtual-gpus N: no device at all; every "GPU" hands
+  // back made-up hits at once, so that what is measured is the host pipeline around N GPUs.
+  // One replica of the index in each device's HBM, shared by that device's contexts; a context is one mapper thread's
+  // workspaces + stream, and two per GPU keep the device busy while the other thread's batch is in transit over PCIe.
+  std::vector<int> dev_of = opt.devices;
+  int n_gpus = dev_of.empty() ? opt.gpus : static_cast<int>(dev_of.size());
+  const bool virtual_gpus = opt.host_ceiling;
   const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 3 : 2);
-  if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
-  if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
-  std::vector<abm_ctx *> ctxs;
-  {
-    // the first context on a GPU uploads the index and derives its tables there: every GPU's at the same time
-    if (n_gpus <= 0) n_gpus = abm_device_count();  // all that are visible
-    if (n_gpus <= 0) { std::cerr << "creating GPU context: no HIP device present (the mapping path has no CPU fallback)\n"; return EXIT_FAILURE; }
+  if (!virtual_gpus) {
+    if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
+    if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
+    const int visible = abm_device_count();
+    if (visible <= 0) { std::cerr << "creating GPU context: no HIP device present (the mapping path has no CPU fallback)\n"; return EXIT_FAILURE; }
+    if (n_gpus <= 0) n_gpus = visible;  // all that are visible
+    if (dev_of.empty()) for (int g = 0; g < n_gpus; ++g) dev_of.push_back(g);
+  }
+  else {
+    if (n_gpus <= 0) n_gpus = 1;
+    dev_of.assign(n_gpus, -1);
+    g_pin_batches = false;  // (page-locked memory comes from the HIP runtime)
+  }
+  bool shared_device = false;
+  for (int g = 0; g < n_gpus; ++g) for (int h = 0; h < g; ++h) shared_device |= dev_of[g] >= 0 && dev_of[g] == dev_of[h];
+  std::vector<abm_ctx *> ctxs;  // [g * per_gpu + k]
+  if (!virtual_gpus) {
+    // the first context on a device uploads the index and derives its tables there: every device's at the same time
     std::vector<abm_ctx *> first(n_gpus, nullptr);
     std::vector<std::thread> th;
     std::mutex emu;
     std::string err;
-    for (int d = 0; d < n_gpus; ++d)
-      if (!first[d]) th.emplace_back([&, d] {
-        if (abm_ctx_create(ix, d, &first[d]) != 0) { std::lock_guard<std::mutex> lk(emu); err = abm_last_error(); }
+    for (int g = 0; g < n_gpus; ++g) {
+      bool seen = false;
+      for (int h = 0; h < g; ++h) seen |= dev_of[h] == dev_of[g];
+      if (!seen) th.emplace_back([&, g] {
+        if (abm_ctx_create(ix, dev_of[g], &first[g]) != 0) { std::lock_guard<std::mutex> lk(emu); err = abm_last_error(); }
       });
+    }
     for (auto &t : th) t.join();
     if (!err.empty()) { std::cerr << "creating GPU context: " << err << "\n"; return EXIT_FAILURE; }
-    for (int d = 0; d < n_gpus; ++d) {
-      ctxs.push_back(first[d]);
-      for (int k = 1; k < per_gpu; ++k) {
-        abm_ctx *c = nullptr;
-        if (abm_ctx_create(ix, d, &c) != 0) die_abm("creating GPU context");
+    for (int g = 0; g < n_gpus; ++g)
+      for (int k = 0; k < per_gpu; ++k) {
+        abm_ctx *c = k == 0 ? first[g] : nullptr;
+        if (!c && abm_ctx_create(ix, dev_of[g], &c) != 0) die_abm("creating GPU context");
         ctxs.push_back(c);
       }
-    }
   }
-  {
+  // where each GPU's mapper threads and batch buffers live: the NUMA node its PCIe root hangs off (virtual GPUs: in
+  // blocks, as the GPUs of a real node are wired)
+  std::vector<int> gpu_node(n_gpus, 0);
+  for (int g = 0; g < n_gpus; ++g) {
+    int node = virtual_gpus ? g * topo.n_nodes() / n_gpus : abm_device_numa_node(dev_of[g]);
+    if (node < 0 || node >= topo.n_nodes()) node = g % topo.n_nodes();
+    gpu_node[g] = node;
+  }
+  auto env_reads = [](const char *name, size_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<size_t>(std::atoll(e)) : dflt; };
+  if (!virtual_gpus) {
     // set-up, like the index upload: workspaces for full batches of reads as long as the input's first one, and the
     // kernels' code loaded, before the clock of the run starts (a longer read later only makes the buffers grow)
     uint32_t first_len = 100;
@@ -738,7 +880,6 @@ int cmd_map(int argc, char **argv) {
       gzclose(zf);
     }
     // (the same expression the mappers use for a full batch, rounded up to whole slices as they do)
-    auto env_reads = [](const char *name, size_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<size_t>(std::atoll(e)) : dflt; };
     const size_t slice_for_reserve = env_reads("ABM_CLI_SLICE_READS", 1u << 15);
     size_t reserve_reads = opt.batch ? opt.batch : env_reads("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23));
     reserve_reads = (reserve_reads + slice_for_reserve - 1) / slice_for_reserve * slice_for_reserve + 256;
@@ -768,37 +909,8 @@ int cmd_map(int argc, char **argv) {
   }
   const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();  // file -> host -> HBM
 
-  // ---- output file.  A slice's place is fixed in slice order; then whichever thread is free pwrite()s it.
-  // (Writes to one file take its inode lock, so they run one at a time at ~4 GB/s on tmpfs; copying into a
-  // shared mapping of the file from all threads instead was measured 3x SLOWER -- page faults on the
-  // mapping contend far worse than the lock.)
   mallopt(M_MMAP_THRESHOLD, 32 << 20);  // (the largest value the library takes: blocks below it come from its arenas ...)
   mallopt(M_TRIM_THRESHOLD, 1 << 30);   // (... and stay there)
-  const int out_fd = ::open(opt.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  if (out_fd < 0) throw std::runtime_error("failed to open output file: " + opt.out);
-  struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) ::close(fd); } } out_closer{out_fd};
-  const bool seekable = ::lseek(out_fd, 0, SEEK_CUR) >= 0;
-  auto write_all = [&](const char *p, size_t len, uint64_t at) {
-    while (len) {
-      const ssize_t w = seekable ? ::pwrite(out_fd, p, len, static_cast<off_t>(at)) : ::write(out_fd, p, len);
-      if (w < 0) { if (errno == EINTR) continue; throw std::runtime_error("failed writing output file: " + opt.out); }
-      p += w; at += static_cast<uint64_t>(w); len -= static_cast<size_t>(w);
-    }
-  };
-  uint64_t file_offset = 0;  // bytes of output whose place is fixed
-  {  // header, src/abismal.cpp:2265-2293
-    std::ostringstream h;
-    h << "@HD\tVN:1.0\n";
-    for (size_t i = 1; i + 1 < ch.names.size(); ++i) h << "@SQ\tSN:" << ch.names[i] << "\tLN:" << (ch.starts[i + 1] - ch.starts[i]) << '\n';
-    h << "@PG\tID:ABISMAL\tVN:" << kVersion << "\tCL:\"";
-    for (int i = 0; i < argc; ++i) h << argv[i] << ' ';
-    h << "\"\n";
-    std::string z;
-    if (!opt.bam) z = h.str();
-    else bgzf_compress(bam_header_bytes(h.str(), ch), z);
-    write_all(z.data(), z.size(), 0);
-    file_offset = z.size();
-  }
 
   abm_params par;
   abm_default_params(&par);
@@ -810,32 +922,35 @@ int cmd_map(int argc, char **argv) {
   const int se_mode = opt.rpbat ? ABM_SE_RANDOM : ((opt.arich || opt.pbat) ? ABM_SE_A_RICH : ABM_SE_T_RICH);
   const int pe_mode = opt.rpbat ? ABM_PE_RANDOM : (opt.pbat ? ABM_PE_PBAT : ABM_PE_NORMAL);
 
-  // Pipeline.  The unit of host work is a SLICE (32 k records, in file order); every stage runs on many
-  // slices at once and only the assignment of output offsets looks at their order:
-  //   cut      plain files: a pool counts newlines chunk by chunk (pread), one thread turns the counts into
-  //            slice byte ranges -- record j starts at line 4j, so no guessing at record boundaries;
-  //            gzip files: one thread per file inflates and cuts (inherently serial)
-  //   parse    (-t threads) pread the slice's text, apply ReadLoader's rules, lay the reads out for the C ABI
-  //   map      (-mappers per GPU) a mapper takes EVERY consecutive parsed slice that is ready, up to -batch
-  //            reads: batches start small (the GPU is busy a few ms after the first slice is cut) and grow
-  //            to the size at which the kernel is efficient once the host runs ahead
-  //   format   (-t) SAM text / BAM blocks and statistics per slice
-  //   write    a slice's place in the file is known once every earlier slice's size is; pwrite from any thread
+  // Pipeline.  The unit of host work is a SLICE (32 k records, in file order); every stage runs on many slices at
+  // once and only the assignment of output offsets looks at their order:
+  //   count    plain files: host workers count newlines chunk by chunk (pread) -- record j starts at line 4j, so there
+  //            is no guessing at record boundaries;
+  //   cut      one thread per REGION turns the counts into slice byte ranges (gzip input: one thread inflates and cuts)
+  //   parse    host workers pread the slice's text, apply ReadLoader's rules, lay the reads out for the C ABI
+  //   map      (-mappers per GPU) a mapper takes a run of consecutive parsed slices of its region, up to its batch size
+  //   format   host workers: SAM text / BAM blocks and statistics per slice
+  //   write    one writer per region: slices in order, one pwrite each
+  // A REGION is a contiguous share of the input with an output file of its own (-out-parts R: <out>.part000 ...; `cat`
+  // of the parts in order is byte for byte the file a run without parts writes).  One region (the default) is the
+  // reference's contract: one output file; its cap is what ONE file takes -- a tmpfs file 6.5 GB/s from any number of
+  // writers (they queue for its lock, profiles/r04_sink_probe.log) = 40 M reads/s of SAM text -- while files of their
+  // own scale with their number (78 GB/s from 16).  Regions share nothing but the host workers: each has its GPUs, its
+  // cutter, its queue of parsed slices, its lead-in, its writer, all on the NUMA node of its GPUs.
+  // Host workers are ONE pool (round 3 ran -t parsers plus -t formatters plus 16 counters: 275 threads on 256 at -t 128):
+  // -t threads, spread over the NUMA nodes and pinned there; a worker takes the most urgent task of its own node
+  // (format, then parse, then count) and another node's only when its own has none.  A slice's buffers are first
+  // touched, parsed and formatted on one node.
   std::mutex mu;
-  // one mutex, one condition variable per kind of waiter: an event wakes the threads it concerns, not all two hundred
-  std::condition_variable cv_flow,   // the cutter: room for more reads in flight
-                          cv_chunk,  // the cutter of plain files: a chunk's newline counts are there
-                          cv_parse,  // parsers: a slice has been cut
-                          cv_map,    // mappers: a slice has been parsed
-                          cv_work,   // formatters: a batch has been mapped
-                          cv_write;  // the writer: a slice's place in the file is fixed
-  auto wake_everyone = [&] { cv_flow.notify_all(); cv_chunk.notify_all(); cv_parse.notify_all(); cv_map.notify_all(); cv_work.notify_all(); cv_write.notify_all(); };
+  auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
   // (test hooks: ABM_CLI_SLICE_READS / ABM_CLI_CHUNK_BYTES / ABM_CLI_MARK_LINES shrink the units so that small
   // fixtures cross many slice, chunk and mark boundaries)
-  auto env_or = [](const char *name, uint64_t dflt) { const char *e = std::getenv(name); return e && std::atoll(e) > 0 ? static_cast<uint64_t>(std::atoll(e)) : dflt; };
   const size_t slice_reads = static_cast<size_t>(env_or("ABM_CLI_SLICE_READS", 1u << 15));
-  // size of the run's very first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
-  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", (opt.reads.size() == 1 && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM")) ? 1u << 19 : 1u << 21));
+  // single-end results leave the library slice by slice while the kernel runs (ABM_CLI_NO_STREAM=1: whole batches, as
+  // the paired-end path takes them); virtual GPUs hand their made-up hits over the same way
+  const bool stream_slices = !paired && !std::getenv("ABM_CLI_NO_STREAM");
+  // size of a GPU's first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
+  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", stream_slices ? 1u << 19 : 1u << 21));
   const bool plain_input = [&] {
     for (const std::string &path : opt.reads) {
       const int fd = ::open(path.c_str(), O_RDONLY);
@@ -849,41 +964,139 @@ int cmd_map(int argc, char **argv) {
     }
     return true;
   }();
+  const int n_regions = std::max(1, opt.out_parts);
+  if (n_regions > 1 && !plain_input) throw std::runtime_error("-out-parts needs plain (seekable, uncompressed) FASTQ input");
+  if (n_regions > n_gpus * per_gpu) throw std::runtime_error("-out-parts: more parts than mapper threads");
+  const int n_nodes = topo.n_nodes();
   // Batches are FULL (-batch reads) except at the end of the input: the mapping kernel's time has a floor set
   // by its costliest reads (a quarter of a second, whatever the batch), so small batches waste the GPU;
   // cutting and parsing run far ahead of it, so a full batch is ready within a fraction of a kernel's time.
   const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
-  // host threads: -t, else 64 for one GPU and 24 more per further GPU (what 10 M reads/s per GPU of cutting, parsing and
-  // formatting take on the measured busy times), never more than the box has
-  const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned n_host = opt.threads ? std::max(1u, opt.threads) : std::min(hw_threads, std::max(64u, 40u + 24u * static_cast<unsigned>(n_gpus)));
+  // host workers: -t, else 24 per GPU plus 8 (what 14 M reads/s per GPU of counting, parsing and formatting take on the
+  // measured busy times, with room to spare), never more than the box has cores (second SMT siblings add little and
+  // the mapper threads, the writers and the HIP runtime's own threads need somewhere to run)
+  const unsigned n_host = opt.threads ? std::max(1u, opt.threads)
+                                      : static_cast<unsigned>(std::min<size_t>(std::max<size_t>(topo.n_cores(), 1), 8u + 24u * static_cast<unsigned>(n_gpus)));
   const size_t max_reads_in_flight = (static_cast<size_t>(n_gpus) * per_gpu + 2) * batch_reads + 4 * slice_reads * n_host;
-  std::deque<std::unique_ptr<Slice>> q_parse;               // cut, waiting for a parser
-  std::map<uint64_t, std::unique_ptr<Slice>> parsed;        // parsed, waiting for a mapper (by slice number)
-  std::deque<Slice *> q_format;                             // mapped, waiting for a formatter
-  std::deque<Slice *> q_write;                              // formatted and placed, waiting to be written
-  std::map<uint64_t, Slice *> formatted;                    // formatted, place not yet known
-  std::map<uint64_t, uint64_t> place;                       // slice -> file offset
+
+  // which region a mapper thread serves: regions are dealt to the GPUs in blocks, a GPU's mappers take its regions in turn
+  auto region_of = [&](int g, int k) -> int {
+    if (n_regions >= n_gpus) {
+      const int lo = g * n_regions / n_gpus, hi = (g + 1) * n_regions / n_gpus;
+      return lo + k % std::max(1, hi - lo);
+    }
+    return g * n_regions / n_gpus;
+  };
+
+  struct Region {
+    int id = 0;
+    std::vector<int> nodes;                                   // NUMA nodes of its GPUs: its slices are striped over them
+    int writer_node = 0;
+    uint64_t n_slices = 0, next_to_map = 0, run_end = 0, n_parsed = 0;  // parsed[next_to_map .. run_end) are all there
+    size_t run_reads = 0;                                     // reads in that run
+    std::map<uint64_t, std::unique_ptr<Slice>> parsed;        // parsed, waiting for a mapper (by slice number)
+    bool cut_done = false;
+    int mappers_live = 0;
+    std::vector<std::string> carry[2];                        // lead-in of the region's next batch (see the mapper)
+    size_t reads_in_flight = 0, max_in_flight = 0;
+    // output
+    std::string path;
+    int fd = -1;
+    bool seekable = true;
+    uint64_t file_offset = 0;                                 // bytes of output whose place is fixed
+    std::map<uint64_t, Slice *> formatted;                    // formatted, place not yet known
+    std::deque<Slice *> q_write;                              // formatted and placed, waiting to be written
+    uint64_t next_to_place = 0, slices_written = 0;
+    std::condition_variable cv_flow,                          // its cutter: room for more reads in flight
+                            cv_map,                           // its mappers: a slice has been parsed
+                            cv_write;                         // its writer: a slice's place in the file is fixed
+    uint64_t records = 0;
+  };
+  std::vector<Region> regions(n_regions);
+  for (int r = 0; r < n_regions; ++r) {
+    Region &R = regions[r];
+    R.id = r;
+    for (int g = 0; g < n_gpus; ++g)
+      for (int k = 0; k < per_gpu; ++k)
+        if (region_of(g, k) == r) {
+          ++R.mappers_live;
+          if (std::find(R.nodes.begin(), R.nodes.end(), gpu_node[g]) == R.nodes.end()) R.nodes.push_back(gpu_node[g]);
+        }
+    if (n_regions == 1) { R.nodes.clear(); for (int n = 0; n < n_nodes; ++n) R.nodes.push_back(n); }  // one region: every node works on it
+    R.writer_node = R.nodes[0];
+    R.max_in_flight = std::max<size_t>(max_reads_in_flight / n_regions, 2 * batch_reads);
+  }
+  const uint64_t kStripe = env_or("ABM_CLI_STRIPE_SLICES", 4);  // consecutive slices of a region that share a node
+  auto node_of_slice = [&](const Region &R, uint64_t g) { return R.nodes[(g / kStripe) % R.nodes.size()]; };
+
+  // ---- output files.  A slice's place is fixed in slice order; its region's writer pwrite()s it.
+  // (Writes to one file take its inode lock, so they run one at a time; copying into a shared mapping of the file
+  // from all threads instead was measured 3x SLOWER -- page faults on the mapping contend far worse than the lock.)
+  struct FdCloser { std::vector<Region> *rs; ~FdCloser() { for (Region &R : *rs) if (R.fd >= 0) ::close(R.fd); } } out_closer{&regions};
+  for (Region &R : regions) {
+    char suffix[32];
+    std::snprintf(suffix, sizeof(suffix), ".part%03d", R.id);
+    R.path = (n_regions == 1 || opt.out == "/dev/null") ? opt.out : opt.out + suffix;
+    R.fd = ::open(R.path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (R.fd < 0) throw std::runtime_error("failed to open output file: " + R.path);
+    R.seekable = ::lseek(R.fd, 0, SEEK_CUR) >= 0;
+  }
+  auto write_all = [&](Region &R, const char *p, size_t len, uint64_t at) {
+    while (len) {
+      const ssize_t w = R.seekable ? ::pwrite(R.fd, p, len, static_cast<off_t>(at)) : ::write(R.fd, p, len);
+      if (w < 0) { if (errno == EINTR) continue; throw std::runtime_error("failed writing output file: " + R.path); }
+      p += w; at += static_cast<uint64_t>(w); len -= static_cast<size_t>(w);
+    }
+  };
+  {  // header, src/abismal.cpp:2265-2293 (the first part's)
+    std::ostringstream h;
+    h << "@HD\tVN:1.0\n";
+    for (size_t i = 1; i + 1 < ch.names.size(); ++i) h << "@SQ\tSN:" << ch.names[i] << "\tLN:" << (ch.starts[i + 1] - ch.starts[i]) << '\n';
+    h << "@PG\tID:ABISMAL\tVN:" << kVersion << "\tCL:\"";
+    for (int i = 0; i < argc; ++i) h << argv[i] << ' ';
+    h << "\"\n";
+    std::string z;
+    if (!opt.bam) z = h.str();
+    else bgzf_compress(bam_header_bytes(h.str(), ch), z);
+    write_all(regions[0], z.data(), z.size(), 0);
+    regions[0].file_offset = z.size();
+  }
+
+  // one condition variable per kind of waiter (and per node / region): an event wakes the threads it concerns
+  std::condition_variable cv_chunk;   // cutters of plain files: a chunk's newline counts are there
+  struct NodeQueues {
+    std::deque<std::unique_ptr<Slice>> parse;   // cut, waiting for a worker
+    std::deque<Slice *> format;                 // mapped, waiting for a worker
+    std::condition_variable cv;                 // this node's idle workers
+    int idle = 0;
+  };
+  std::vector<NodeQueues> nq(n_nodes);
+  auto wake_everyone = [&] {
+    cv_chunk.notify_all();
+    for (NodeQueues &q : nq) q.cv.notify_all();
+    for (Region &R : regions) { R.cv_flow.notify_all(); R.cv_map.notify_all(); R.cv_write.notify_all(); }
+  };
+  // a task for `node` has been queued (mu held): one idle worker there, or failing that anywhere, wakes up
+  auto wake_worker = [&](int node) {
+    if (nq[node].idle > 0) { nq[node].cv.notify_one(); return; }
+    for (int n = 0; n < n_nodes; ++n) if (nq[n].idle > 0) { nq[n].cv.notify_one(); return; }
+  };
   std::vector<std::unique_ptr<Batch>> live_batches;
-  std::vector<std::string> carry[2];                        // tail of the input already handed to a batch (see the mapper)
-  uint64_t n_slices = 0, next_to_map = 0, next_to_place = 0, slices_written = 0, n_batches = 0;
-  uint64_t run_end = 0, n_parsed = 0;  // parsed[next_to_map .. run_end) are all there; slices parsed so far
-  size_t run_reads = 0;                // reads in that run
-  SlicePool slice_pool;
-  BatchPool batch_pool;
-  size_t reads_in_flight = 0;
-  bool cut_done = false;
-  int parsers_live = 0, mappers_live = 0;
+  uint64_t n_batches = 0;
+  size_t max_lead = 0;  // the longest lead-in a batch carried (records)
+  int mappers_live = n_gpus * per_gpu;
+  std::vector<SlicePool> slice_pool(n_nodes);
+  std::vector<BatchPool> batch_pool(n_nodes);
   std::exception_ptr failure;
   std::vector<Stats3> gpu_stats(n_gpus);
   std::vector<uint64_t> gpu_batches(n_gpus, 0), gpu_reads(n_gpus, 0);  // what each GPU was handed
-  uint64_t total_records = 0;
+  std::vector<unsigned> workers_on(n_nodes, 0);
+  for (unsigned t = 0; t < n_host; ++t) ++workers_on[t % n_nodes];
 
   // Set-up, like the index upload and abm_ctx_reserve: the slices and batches the run will have in flight, with their
-  // buffers sized from the input's first records and their pages touched, on all host threads at once.  A run's first
-  // second otherwise touches gigabytes of fresh memory from a hundred threads that share one address space -- page
-  // faults and the allocator's calls for more memory, which stall one another (profiles/r03_host_ceiling.log: the
-  // formatting threads' busy time grew sixfold from 32 to 128 threads).
+  // buffers sized from the input's first records and their pages touched -- by threads of the node that will use them.
+  // A run's first second otherwise touches gigabytes of fresh memory from a hundred threads that share one address
+  // space: page faults and the allocator's calls for more memory, which stall one another.
   double host_prepare_s = 0;
   if (plain_input && !std::getenv("ABM_CLI_NO_PREWARM")) {
     const auto tp = std::chrono::steady_clock::now();
@@ -907,23 +1120,46 @@ int cmd_map(int argc, char **argv) {
     if (rec_bytes && read_len) {
       const uint64_t n_recs = in_bytes / rec_bytes + 1;
       const uint64_t in_flight = std::min<uint64_t>(n_recs, max_reads_in_flight);
-      const size_t want_slices = static_cast<size_t>(std::min<uint64_t>((in_flight + slice_reads - 1) / slice_reads + n_host / 4, 768));
+      const size_t want_slices = static_cast<size_t>(std::min<uint64_t>((in_flight + slice_reads - 1) / slice_reads + n_host / 4, 4096));
       const size_t batch_cap = static_cast<size_t>(std::min<uint64_t>(batch_reads, n_recs)) + 512;
-      const size_t want_batches = static_cast<size_t>(std::min<uint64_t>(static_cast<uint64_t>(n_gpus) * (per_gpu + 1), (n_recs + batch_cap - 1) / batch_cap + static_cast<uint64_t>(n_gpus)));
-      const int ends = paired ? 2 : 1;
-      std::vector<std::unique_ptr<Slice>> sl(want_slices);
-      std::vector<std::unique_ptr<Batch>> bt(want_batches);
-      for (auto &x : bt) x.reset(new Batch);
-      std::atomic<size_t> next{0};
+      // batches per GPU: its mappers' plus one, but no more than its share of the input makes
+      const size_t per_gpu_batches = static_cast<size_t>(std::min<uint64_t>(static_cast<uint64_t>(per_gpu) + 1, (n_recs / n_gpus + batch_cap - 1) / batch_cap + 1));
+      // tasks per node: slices for the regions whose slices live there (in proportion), batch pieces for the GPUs there
+      struct Task { int kind; size_t a, b; };  // 0: a slice; 1: piece b of batch a
+      std::vector<std::vector<Task>> tasks(n_nodes);
+      std::vector<std::vector<std::unique_ptr<Batch>>> bt(n_nodes);
+      {
+        std::vector<size_t> share(n_nodes, 0);
+        size_t total = 0;
+        for (const Region &R : regions) for (int n : R.nodes) { ++share[n]; ++total; }
+        for (int n = 0; n < n_nodes; ++n) {
+          const size_t k = total ? (want_slices * share[n] + total - 1) / total : 0;
+          for (size_t i = 0; i < k; ++i) tasks[n].push_back(Task{0, i, 0});
+        }
+        for (int g = 0; g < n_gpus; ++g)
+          for (size_t i = 0; i < per_gpu_batches; ++i) {
+            const int n = gpu_node[g];
+            bt[n].emplace_back(new Batch);
+            for (size_t piece = 0; piece < 8; ++piece) tasks[n].push_back(Task{1, bt[n].size() - 1, piece});
+          }
+      }
+      std::vector<std::atomic<size_t>> next(n_nodes);
+      for (auto &x : next) x = 0;
+      std::vector<std::vector<std::unique_ptr<Slice>>> made(n_nodes);
+      for (int n = 0; n < n_nodes; ++n) made[n].resize(tasks[n].size());
       auto touch = [](char *q, size_t bytes) { for (size_t i = 0; i < bytes; i += 4096) q[i] = 0; };
       std::vector<std::thread> th;
       for (unsigned t = 0; t < n_host; ++t)
-        th.emplace_back([&] {
+        th.emplace_back([&, t] {
+          const int node = static_cast<int>(t % n_nodes);
+          topo.pin(node, workers_on[node]);
           for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= want_slices + want_batches * 8) break;
-            if (k < want_slices) {
+            const size_t k = next[node].fetch_add(1);
+            if (k >= tasks[node].size()) break;
+            const Task &tk = tasks[node][k];
+            if (tk.kind == 0) {
               std::unique_ptr<Slice> x(new Slice);
+              x->node = node;
               for (int e = 0; e < ends; ++e) {
                 x->raw[e].reserve(slice_reads * rec_bytes + (1u << 16)); touch(x->raw[e].p, x->raw[e].cap);
                 x->blob[e].reserve(slice_reads * (read_len + 2)); touch(x->blob[e].p, x->blob[e].cap);
@@ -933,36 +1169,47 @@ int cmd_map(int argc, char **argv) {
                 touch(reinterpret_cast<char *>(x->off[e].data()), (slice_reads + 16) * sizeof(uint64_t));
               }
               x->text.reserve(slice_reads * ends * 330); touch(x->text.p, x->text.cap);
-              sl[k] = std::move(x);
+              if (stream_slices) {
+                x->own_se.b.reserve(slice_reads * sizeof(abm_hit)); touch(x->own_se.b.p, x->own_se.b.cap);
+                x->own_cig.b.reserve((4 * slice_reads + 64) * 4); touch(x->own_cig.b.p, x->own_cig.b.cap);
+                x->own_cig_off.b.reserve((slice_reads + 1) * 8); touch(x->own_cig_off.b.p, x->own_cig_off.b.cap);
+              }
+              made[node][k] = std::move(x);
             }
             else {  // a batch's arrays, one piece per task
-              const size_t bi = (k - want_slices) / 8, piece = (k - want_slices) % 8;
-              Batch &b = *bt[bi];
-              const size_t n = batch_cap;
+              Batch &b = *bt[node][tk.a];
+              const size_t n = batch_cap, piece = tk.b;
               const int e = static_cast<int>(piece & 1);
               if (e >= ends) continue;
               switch (piece >> 1) {
                 case 0: b.blob[e].reserve(n * (read_len + 2)); touch(b.blob[e].p, b.blob[e].cap); break;
-                case 1: b.off_bytes[e].reserve((n + 1) * 8); touch(b.off_bytes[e].p, b.off_bytes[e].cap); b.se[e].b.reserve(n * sizeof(abm_hit)); touch(b.se[e].b.p, b.se[e].b.cap); break;
-                case 2: b.cig[e].b.reserve((4 * n + 1024) * 4); touch(b.cig[e].b.p, b.cig[e].b.cap); break;
-                default: b.cig_off[e].b.reserve((n + 1) * 8); touch(b.cig_off[e].b.p, b.cig_off[e].b.cap);
+                case 1: b.off_bytes[e].reserve((n + 1) * 8); touch(b.off_bytes[e].p, b.off_bytes[e].cap);
+                        if (!stream_slices) { b.se[e].b.reserve(n * sizeof(abm_hit)); touch(b.se[e].b.p, b.se[e].b.cap); }
+                        break;
+                case 2: if (!stream_slices) { b.cig[e].b.reserve((4 * n + 1024) * 4); touch(b.cig[e].b.p, b.cig[e].b.cap); } break;
+                default: if (!stream_slices) { b.cig_off[e].b.reserve((n + 1) * 8); touch(b.cig_off[e].b.p, b.cig_off[e].b.cap); }
                          if (paired && e == 0) { b.pairs.b.reserve(n * sizeof(abm_pair)); touch(b.pairs.b.p, b.pairs.b.cap); }
               }
             }
           }
         });
       for (auto &t : th) t.join();
-      for (auto &x : sl) if (x) slice_pool.put(std::move(x));
-      for (auto &x : bt) if (x) batch_pool.put(std::move(x));
+      for (int n = 0; n < n_nodes; ++n) {
+        for (auto &x : made[n]) if (x) slice_pool[n].put(std::move(x));
+        for (auto &x : bt[n]) if (x) batch_pool[n].put(std::move(x));
+      }
     }
     host_prepare_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
   }
+  struct rusage ru0;
+  ::getrusage(RUSAGE_SELF, &ru0);
   const auto t_start = std::chrono::steady_clock::now();
 
-  double busy_split = 0, busy_parse = 0, busy_map = 0, busy_format = 0, busy_write = 0;  // seconds, summed over threads
+  // seconds of work, summed over threads (the wait for the pipeline's lock is not in them: round 3's figures included it)
+  double busy_split = 0, busy_parse = 0, busy_map = 0, busy_format = 0, busy_write = 0, lock_wait = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-  RawPool raw_pool;
+  std::vector<RawPool> raw_pool(n_nodes);
   // ABM_CLI_TRACE=1: one line per pipeline event on stderr (milliseconds since the pipeline started)
   const bool tracing = std::getenv("ABM_CLI_TRACE") != nullptr;
   auto trace = [&](const char *what, uint64_t a, uint64_t b) {
@@ -975,54 +1222,66 @@ int cmd_map(int argc, char **argv) {
     if (!failure) failure = std::current_exception();
     wake_everyone();
   };
-  // hands a cut slice to the parsers (blocks while too much is in flight)
-  auto emit_slice = [&](std::unique_ptr<Slice> sl, size_t records) -> bool {
+  // a fresh (recycled) slice for slice number g of region R, from the pool of the node it will live on
+  auto new_slice = [&](const Region &R, uint64_t g) {
+    const int node = node_of_slice(R, g);
+    std::unique_ptr<Slice> sl = slice_pool[node].get();
+    sl->node = node;
+    sl->region = R.id;
+    return sl;
+  };
+  // hands a cut slice to the workers (blocks while too much of its region is in flight)
+  auto emit_slice = [&](Region &R, std::unique_ptr<Slice> sl, size_t records) -> bool {
     std::unique_lock<std::mutex> lk(mu);
-    cv_flow.wait(lk, [&] { return failure || reads_in_flight < max_reads_in_flight; });
+    R.cv_flow.wait(lk, [&] { return failure || R.reads_in_flight < R.max_in_flight; });
     if (failure) return false;
-    sl->g = n_slices++;
+    sl->g = R.n_slices++;
     trace("cut", sl->g, records);
-    reads_in_flight += records;
-    q_parse.push_back(std::move(sl));
-    cv_parse.notify_one();
+    R.reads_in_flight += records;
+    const int node = sl->node;
+    nq[node].parse.push_back(std::move(sl));
+    wake_worker(node);
     return true;
   };
 
   // ---- cut, gzip (or non-regular) input: one inflating reader, slices carry their text
   auto cutter_stream = [&]() {
+    Region &R = regions[0];
     try {
       RawSplitter s1(opt.reads[0]);
       std::unique_ptr<RawSplitter> s2;
       if (paired) s2.reset(new RawSplitter(opt.reads[1]));
-      for (;;) {
-        std::unique_ptr<Slice> sl = slice_pool.get();
+      for (uint64_t g = 0;; ++g) {
+        std::unique_ptr<Slice> sl = new_slice(R, g);
         const auto t0 = now();
-        sl->raw[0] = raw_pool.get();
-        if (paired) sl->raw[1] = raw_pool.get();
+        if (!sl->raw[0].p) sl->raw[0] = raw_pool[sl->node].get();
+        if (paired && !sl->raw[1].p) sl->raw[1] = raw_pool[sl->node].get();
         const uint64_t l1 = s1.next(slice_reads, sl->raw[0], sl->first_line[0]);
         uint64_t l2 = 0;
         if (paired) l2 = s2->next(slice_reads, sl->raw[1], sl->first_line[1]);
         const bool last = s1.exhausted() || (paired && s2->exhausted());
         if (l1 == 0 && (!paired || l2 == 0)) break;
-        { std::lock_guard<std::mutex> lk(mu); busy_split += since(t0); }
-        if (!emit_slice(std::move(sl), (l1 + 3) / 4)) break;
+        const double dt = since(t0);
+        { std::lock_guard<std::mutex> lk(mu); busy_split += dt; }
+        if (!emit_slice(R, std::move(sl), (l1 + 3) / 4)) break;
         if (last) break;
       }
     }
     catch (...) { fail(); }
     std::lock_guard<std::mutex> lk(mu);
-    cut_done = true;
+    R.cut_done = true;
     wake_everyone();
   };
 
-  // ---- cut, plain files: newline counts per chunk (parallel), then slice byte ranges (serial, cheap)
+  // ---- cut, plain files: newline counts per chunk (host workers), then slice byte ranges (serial per region, cheap)
   struct ChunkInfo { uint64_t lines = 0; std::vector<uint32_t> marks; bool ready = false; };  // marks: offset just past every kMark-th newline
   const uint64_t kChunk = env_or("ABM_CLI_CHUNK_BYTES", 8u << 20), kMark = env_or("ABM_CLI_MARK_LINES", 1024);
   struct LineFile {
     int fd = -1;
     uint64_t size = 0, n_chunks = 0;
     std::vector<ChunkInfo> chunks;
-    uint64_t next_chunk = 0;  // next chunk a counter thread takes
+    uint64_t next_chunk = 0;  // next chunk a worker counts
+    uint64_t n_ready = 0;
     bool ends_with_newline = true;
   };
   std::vector<LineFile> lf(plain_input ? opt.reads.size() : 0);
@@ -1044,52 +1303,47 @@ int cmd_map(int argc, char **argv) {
       dst += got; lo += static_cast<uint64_t>(got);
     }
   };
-  auto counter = [&]() {  // counts the newlines of whole chunks, in file order per file, ahead of the cutter
-    try {
-      std::vector<char> buf(kChunk);
-      for (;;) {
-        size_t e = 0; uint64_t k = 0; bool got = false;
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          if (failure) break;
-          // the file whose index is least advanced (both files of a pair are cut in step)
-          size_t best = lf.size();
-          for (size_t f = 0; f < lf.size(); ++f)
-            if (lf[f].next_chunk < lf[f].n_chunks && (best == lf.size() || lf[f].next_chunk < lf[best].next_chunk)) best = f;
-          if (best != lf.size()) { e = best; k = lf[e].next_chunk++; got = true; }
-        }
-        if (!got) break;
-        const auto t0 = now();
-        const uint64_t lo = k * kChunk, hi = std::min(lf[e].size, lo + kChunk);
-        read_range(lf[e].fd, opt.reads[e], buf.data(), lo, hi);
-        ChunkInfo ci;
-        const char *p = buf.data(), *end = p + (hi - lo);
-        uint64_t until_mark = kMark;
-        while (p < end) {  // block counts vectorise; a block holding a mark is walked newline by newline
-          const size_t blk = std::min<size_t>(static_cast<size_t>(end - p), 4096);
-          uint32_t c = 0;
-          for (size_t i = 0; i < blk; ++i) c += (p[i] == '\n');
-          if (c < until_mark) { until_mark -= c; ci.lines += c; p += blk; continue; }
-          const char *q = p, *bend = p + blk;
-          while (q < bend) {
-            const char *nl = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(bend - q)));
-            if (!nl) break;
-            ++ci.lines;
-            q = nl + 1;
-            if (--until_mark == 0) { ci.marks.push_back(static_cast<uint32_t>(q - buf.data())); until_mark = kMark; }
-          }
-          p = bend;
-        }
-        ci.ready = true;
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          lf[e].chunks[k] = std::move(ci);
-          busy_split += since(t0);
-        }
-        cv_chunk.notify_all();
+  // (mu held) the next chunk to count: of the file whose counting is least advanced (both files of a pair are cut in step)
+  auto take_chunk = [&](size_t &e, uint64_t &k) -> bool {
+    size_t best = lf.size();
+    for (size_t f = 0; f < lf.size(); ++f)
+      if (lf[f].next_chunk < lf[f].n_chunks && (best == lf.size() || lf[f].next_chunk < lf[best].next_chunk)) best = f;
+    if (best == lf.size()) return false;
+    e = best; k = lf[e].next_chunk++;
+    return true;
+  };
+  auto count_chunk = [&](size_t e, uint64_t k, std::vector<char> &buf) {  // the newlines of one chunk
+    const auto t0 = now();
+    const uint64_t lo = k * kChunk, hi = std::min(lf[e].size, lo + kChunk);
+    buf.resize(kChunk);
+    read_range(lf[e].fd, opt.reads[e], buf.data(), lo, hi);
+    ChunkInfo ci;
+    const char *p = buf.data(), *end = p + (hi - lo);
+    uint64_t until_mark = kMark;
+    while (p < end) {  // block counts vectorise; a block holding a mark is walked newline by newline
+      const size_t blk = std::min<size_t>(static_cast<size_t>(end - p), 4096);
+      uint32_t c = 0;
+      for (size_t i = 0; i < blk; ++i) c += (p[i] == '\n');
+      if (c < until_mark) { until_mark -= c; ci.lines += c; p += blk; continue; }
+      const char *q = p, *bend = p + blk;
+      while (q < bend) {
+        const char *nl = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(bend - q)));
+        if (!nl) break;
+        ++ci.lines;
+        q = nl + 1;
+        if (--until_mark == 0) { ci.marks.push_back(static_cast<uint32_t>(q - buf.data())); until_mark = kMark; }
       }
+      p = bend;
     }
-    catch (...) { fail(); }
+    ci.ready = true;
+    const double dt = since(t0);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      lf[e].chunks[k] = std::move(ci);
+      ++lf[e].n_ready;
+      busy_split += dt;
+    }
+    cv_chunk.notify_all();
   };
   // byte offset just past newline number `line` (1-based count of newlines) of file e; chunks up to the one
   // holding it must be ready.  cum[k] = newlines before chunk k.
@@ -1097,6 +1351,7 @@ int cmd_map(int argc, char **argv) {
   auto offset_after_line = [&](size_t e, Cursor &cur, uint64_t line, uint64_t &off_out) -> bool {
     // returns false if the file has fewer newlines
     LineFile &F = lf[e];
+    if (line == 0) { off_out = 0; return true; }
     for (;;) {
       if (cur.chunk >= F.n_chunks) return false;
       {
@@ -1132,16 +1387,59 @@ int cmd_map(int argc, char **argv) {
     off_out = base + at;
     return true;
   };
-  auto cutter_plain = [&]() {
+  // Several regions: where each begins is known once the first file's lines have all been counted (counting is the
+  // workers' first job then, and takes a fraction of a second for tens of gigabytes): region r takes the records
+  // [records * r / R, records * (r + 1) / R), rounded down to whole slices.
+  auto region_start_record = [&](int r) -> uint64_t {
+    if (r <= 0) return 0;
+    if (r >= n_regions) return ~0ull >> 3;
+    uint64_t lines = 0;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_chunk.wait(lk, [&] { return failure || lf[0].n_ready == lf[0].n_chunks; });
+      if (failure) throw std::runtime_error("aborted");
+      for (const ChunkInfo &ci : lf[0].chunks) lines += ci.lines;
+    }
+    if (!lf[0].ends_with_newline) ++lines;
+    const uint64_t records = (lines + 3) / 4;
+    return records * static_cast<uint64_t>(r) / static_cast<uint64_t>(n_regions) / slice_reads * slice_reads;
+  };
+  // the part of the input just before a region (its last kLeadRecords records) parsed for the region's lead-in
+  constexpr uint64_t kLeadRecords = 4096;
+  auto cutter_plain = [&](int r) {
+    Region &R = regions[r];
     try {
       Cursor cur[2];
-      uint64_t lo[2] = {0, 0}, line = 0;
+      uint64_t lo[2] = {0, 0};
       bool done[2] = {false, false};
       const size_t nf = lf.size();
-      for (;;) {
-        std::unique_ptr<Slice> sl = slice_pool.get();
-        const uint64_t target = line + 4 * slice_reads;  // newlines before the next slice
-        uint64_t recs = 0;
+      const uint64_t first_rec = region_start_record(r), end_rec = region_start_record(r + 1);
+      uint64_t line = 4 * first_rec;
+      const uint64_t end_line = 4 * end_rec;
+      if (first_rec > 0) {
+        // lead-in: what a 44-46-base read at the region's start finds past its end comes from the reads before it
+        const uint64_t lead_rec = first_rec > kLeadRecords ? first_rec - kLeadRecords : 0;
+        std::vector<NameRef> names; RawBuf blob[2], raw; std::vector<uint64_t> off[2];
+        for (size_t e = 0; e < nf; ++e) {
+          uint64_t a = 0, b = 0;
+          if (!offset_after_line(e, cur[e], 4 * lead_rec, a) || !offset_after_line(e, cur[e], line, b)) { done[e] = true; lo[e] = lf[e].size; continue; }
+          raw.resize(b - a);
+          read_range(lf[e].fd, opt.reads[e], raw.p, a, b);
+          parse_raw(raw, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+          lo[e] = b;
+        }
+        std::vector<std::string> lead[2];
+        const size_t m = off[0].empty() ? 0 : off[0].size() - 1;
+        if (nf == 1 || (off[1].size() == off[0].size()))
+          for (uint32_t k : ghost_tail(off, m, ends)) for (int e = 0; e < ends; ++e) lead[e].emplace_back(blob[e].data() + off[e][k], off[e][k + 1] - off[e][k]);
+        for (int e = 0; e < ends; ++e) std::reverse(lead[e].begin(), lead[e].end());
+        std::lock_guard<std::mutex> lk(mu);
+        R.carry[0] = std::move(lead[0]);
+        R.carry[1] = std::move(lead[1]);
+      }
+      for (uint64_t g = 0; line < end_line; ++g) {
+        std::unique_ptr<Slice> sl = new_slice(R, g);
+        const uint64_t target = std::min(line + 4 * slice_reads, end_line);  // newlines before the next slice
         bool any = false;
         for (size_t e = 0; e < nf; ++e) {
           sl->first_line[e] = line;
@@ -1152,77 +1450,66 @@ int cmd_map(int argc, char **argv) {
           lo[e] = sl->byte_hi[e];
           any |= sl->byte_hi[e] > sl->byte_lo[e];
         }
-        if (!any) break;
-        recs = slice_reads;  // (the last slice may hold fewer; the figure only bounds memory in flight)
+        if (!any) { slice_pool[sl->node].put(std::move(sl)); break; }
+        // (the last slice may hold fewer records; the figure only bounds memory in flight)
         const bool last = done[0] || (nf == 2 && done[1]);
-        if (!emit_slice(std::move(sl), recs)) break;
+        if (!emit_slice(R, std::move(sl), slice_reads)) break;
         line = target;
         if (last) break;
       }
     }
     catch (...) { fail(); }
     std::lock_guard<std::mutex> lk(mu);
-    cut_done = true;
+    R.cut_done = true;
     wake_everyone();
   };
 
-  auto parser = [&]() {
-    try {
-      for (;;) {
-        std::unique_ptr<Slice> sl;
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          cv_parse.wait(lk, [&] { return failure || !q_parse.empty() || cut_done; });
-          if (failure || q_parse.empty()) break;
-          sl = std::move(q_parse.front());
-          q_parse.pop_front();
-        }
-        const auto t0 = now();
-        for (int e = 0; e < (paired ? 2 : 1); ++e) {
-          if (plain_input) {
-            if (!sl->raw[e].p) sl->raw[e] = raw_pool.get();
-            const uint64_t len = sl->byte_hi[e] - sl->byte_lo[e];
-            sl->raw[e].reserve(len + 1);
-            read_range(lf[e].fd, opt.reads[e], sl->raw[e].p, sl->byte_lo[e], sl->byte_hi[e]);
-            sl->raw[e].n = len;
-          }
-          parse_raw(sl->raw[e], sl->first_line[e], opt.reads[e], sl->names[e], sl->blob[e], sl->off[e]);
-        }
-        if (paired && sl->names[0].size() != sl->names[1].size())
-          throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(sl->names[0].size()) +
-                                   ", batch 2: " + std::to_string(sl->names[1].size()) +
-                                   ". Are you sure your paired-end inputs have the same number of reads?");
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          busy_parse += since(t0);
-          const uint64_t g = sl->g;
-          trace("parsed", g, static_cast<uint64_t>(since(t0) * 1e6));
-          parsed[g] = std::move(sl);
-          ++n_parsed;
-          for (auto it = parsed.find(run_end); it != parsed.end(); it = parsed.find(run_end)) { run_reads += it->second->n(); ++run_end; }
-        }
-        cv_map.notify_all();
+  auto parse_slice = [&](std::unique_ptr<Slice> sl) {
+    const auto t0 = now();
+    Region &R = regions[sl->region];
+    for (int e = 0; e < ends; ++e) {
+      if (plain_input) {
+        if (!sl->raw[e].p) sl->raw[e] = raw_pool[sl->node].get();
+        const uint64_t len = sl->byte_hi[e] - sl->byte_lo[e];
+        sl->raw[e].reserve(len + 1);
+        read_range(lf[e].fd, opt.reads[e], sl->raw[e].p, sl->byte_lo[e], sl->byte_hi[e]);
+        sl->raw[e].n = len;
       }
+      parse_raw(sl->raw[e], sl->first_line[e], opt.reads[e], sl->names[e], sl->blob[e], sl->off[e]);
     }
-    catch (...) { fail(); }
-    std::lock_guard<std::mutex> lk(mu);
-    --parsers_live;
-    cv_map.notify_all();
+    if (paired && sl->names[0].size() != sl->names[1].size())
+      throw std::runtime_error("paired-end batch sizes differ. Batch 1: " + std::to_string(sl->names[0].size()) +
+                               ", batch 2: " + std::to_string(sl->names[1].size()) +
+                               ". Are you sure your paired-end inputs have the same number of reads?");
+    sl->tail = ghost_tail(sl->off, sl->n(), ends);
+    const double dt = since(t0);
+    const auto tl = now();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      lock_wait += since(tl);
+      busy_parse += dt;
+      const uint64_t g = sl->g;
+      trace("parsed", g, static_cast<uint64_t>(dt * 1e6));
+      R.parsed[g] = std::move(sl);
+      ++R.n_parsed;
+      for (auto it = R.parsed.find(R.run_end); it != R.parsed.end(); it = R.parsed.find(R.run_end)) { R.run_reads += it->second->n(); ++R.run_end; }
+    }
+    R.cv_map.notify_all();
   };
 
-  // single-end results leave the library slice by slice while the kernel runs (ABM_CLI_NO_STREAM=1: whole batches, as
-  // the paired-end path takes them)
-  const bool stream_slices = !paired && !opt.host_ceiling && !std::getenv("ABM_CLI_NO_STREAM");
   auto mapper = [&](int slot) {
     const int g = slot / per_gpu;
-    abm_ctx *ctx = ctxs[slot];
+    const int node = gpu_node[g];
+    topo.pin(node, 1);  // (a handful of mapper threads per node: they sleep in the library while their kernel runs)
+    abm_ctx *ctx = virtual_gpus ? nullptr : ctxs[slot];
+    Region &R = regions[region_of(g, slot % per_gpu)];
     try {
       for (;;) {
-        std::unique_ptr<Batch> owned = batch_pool.get();
+        std::unique_ptr<Batch> owned = batch_pool[node].get();
         Batch *b = owned.get();
         {
           std::unique_lock<std::mutex> lk(mu);
-          auto all_parsed = [&] { return cut_done && n_parsed == n_slices; };
+          auto all_parsed = [&] { return R.cut_done && R.n_parsed == R.n_slices; };
           // How many reads this batch should hold.  A GPU's batches grow geometrically from the first (2 M reads, then
           // 4 M ... up to -batch): the device starts on the first million reads a few milliseconds into the run,
           // and each batch is parsed and ready by the time the one before it has been handed out on the device --
@@ -1236,78 +1523,91 @@ int cmd_map(int argc, char **argv) {
           // kernel leaves time to format and write most of its output while it still runs -- 512 k reads first, then
           // four times as many per batch up to -batch, and what is left in as few batches as possible (10 M reads:
           // 0.5 M, 2 M, 7.5 M -- 0.737-0.796 s against 0.817-0.831 s with 1 M, 3 M, 6 M on the same box,
-          // profiles/r03_exp_e2e_first_batch.log).
+          // profiles/r03_exp_e2e_first_batch.log).  Several GPUs on one region: what is left is shared among them.
           auto target = [&]() -> size_t {
             size_t cap = batch_reads;
             const uint64_t grown = std::min<uint64_t>(gpu_batches[g], 10) * (stream_slices ? 2 : 1);
-            if (first_batch_reads) cap = std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, first_batch_reads << grown));
-            if (!cut_done) return cap;
-            const size_t left = static_cast<size_t>(n_slices - next_to_map) * slice_reads;
+            if (first_batch_reads)  // (saturating: a huge first batch shifted left would wrap)
+              cap = std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, first_batch_reads >= (batch_reads >> grown) ? batch_reads : first_batch_reads << grown));
+            if (!R.cut_done) return cap;
+            const size_t left = static_cast<size_t>(R.n_slices - R.next_to_map) * slice_reads;
             size_t k = (left + cap - 1) / cap;
             if (k <= 1) k = (!stream_slices && left >= (1u << 22)) ? 2 : 1;
-            return std::max<size_t>(slice_reads, (left + k - 1) / k);
+            k = std::max<size_t>(k, std::min<size_t>(static_cast<size_t>(R.mappers_live + per_gpu - 1) / per_gpu, (left + (1u << 20) - 1) >> 20));
+            return std::max<size_t>(slice_reads, (left + k - 1) / std::max<size_t>(k, 1));
           };
-          cv_map.wait(lk, [&] { return failure || run_reads >= target() || (all_parsed() && (run_end > next_to_map || parsed.empty())); });
-          if (failure || run_end == next_to_map) {
+          R.cv_map.wait(lk, [&] { return failure || R.run_reads >= target() || (all_parsed() && (R.run_end > R.next_to_map || R.parsed.empty())); });
+          if (failure || R.run_end == R.next_to_map) {
             // (the unused batch goes back to the pool: destroying it here would free its page-locked buffers -- a
             // device-wide wait and 0.1-0.2 s of unpinning -- inside the run's clock; the trace showed the run's end
             // waiting on exactly these two threads)
             lk.unlock();
-            batch_pool.put(std::move(owned));
+            batch_pool[node].put(std::move(owned));
             break;
           }
-          const size_t want = std::min(target(), std::max<size_t>(run_reads, 1));
-          while (next_to_map < run_end) {
-            auto it = parsed.find(next_to_map);
+          const size_t want = std::min(target(), std::max<size_t>(R.run_reads, 1));
+          while (R.next_to_map < R.run_end) {
+            auto it = R.parsed.find(R.next_to_map);
             if (!b->slices.empty() && b->n + it->second->n() > want) break;
             b->n += it->second->n();
-            run_reads -= it->second->n();
+            R.run_reads -= it->second->n();
             b->slices.push_back(std::move(it->second));
-            parsed.erase(it);
-            ++next_to_map;
+            R.parsed.erase(it);
+            ++R.next_to_map;
           }
           b->seq = n_batches++;
           b->gpu = g;
+          b->node = node;
           ++gpu_batches[g];
           gpu_reads[g] += b->n;
           b->slices_left = static_cast<int>(b->slices.size());
-          // Reads of 44-46 bases see what earlier reads left in the reference's reused buffers:
-          // the mapper looks for that among the reads handed over in the same call, so a batch is led by the
-          // tail of the input before it -- from the last record whose reads are all longer than 46 bases on
-          // (nearly always just that one record) -- whose results are dropped.
-          b->carry[0] = carry[0];
-          b->carry[1] = carry[1];
+          // Reads of 44-46 bases see what earlier reads left in the reference's reused buffers: for each
+          // position past its end (up to 64 of them: 110 bases out) the nearest EARLIER read that is longer.  The mapper
+          // looks for that among the reads handed over in the same call, so a batch is led by the records of the input
+          // before it that can still be such a source: scanning backwards, every record that is longer (in either end)
+          // than everything after it, until one reaches 110 bases -- for a library of one read length just the last
+          // record, and never more than 2 x 67.  Each slice's own list was made when it was parsed (ghost_tail); here
+          // the lists are merged, newest slice first, then what the previous lead-in still contributes.
+          b->carry[0] = R.carry[0];
+          b->carry[1] = R.carry[1];
           {
             std::vector<std::string> next[2];
-            bool closed = false;
-            for (size_t si = b->slices.size(); si-- > 0 && !closed;) {
+            uint32_t reach[2] = {0, 0};
+            auto closed = [&] { return reach[0] >= kGhostReach && (!paired || reach[1] >= kGhostReach); };
+            for (size_t si = b->slices.size(); si-- > 0 && !closed();) {
               const Slice &sl = *b->slices[si];
-              for (size_t k = sl.n(); k-- > 0 && !closed;) {
-                bool all_long = true;
-                for (int e = 0; e < (paired ? 2 : 1); ++e) {
-                  const size_t len = sl.off[e][k + 1] - sl.off[e][k];
-                  next[e].emplace_back(sl.blob[e].data() + sl.off[e][k], len);
-                  all_long &= len > 46;
+              for (uint32_t k : sl.tail) {
+                if (closed()) break;
+                bool raises = false;
+                for (int e = 0; e < ends; ++e) {
+                  const uint32_t len = ghost_len(sl.off[e][k + 1] - sl.off[e][k]);
+                  if (len > reach[e]) { raises = true; reach[e] = len; }
                 }
-                closed = all_long;  // (no cap on the records: a heavily trimmed library has long runs of short ones)
+                if (raises) for (int e = 0; e < ends; ++e) next[e].emplace_back(sl.blob[e].data() + sl.off[e][k], sl.off[e][k + 1] - sl.off[e][k]);
               }
             }
-            if (!closed)  // the whole batch had no such record: keep the older tail too
-              for (int e = 0; e < (paired ? 2 : 1); ++e)
-                for (size_t k = carry[e].size(); k-- > 0;) next[e].push_back(carry[e][k]);
-            for (int e = 0; e < (paired ? 2 : 1); ++e) { std::reverse(next[e].begin(), next[e].end()); carry[e].swap(next[e]); }
+            for (size_t k = R.carry[0].size(); k-- > 0 && !closed();) {
+              bool raises = false;
+              for (int e = 0; e < ends; ++e) {
+                const uint32_t len = ghost_len(R.carry[e][k].size());
+                if (len > reach[e]) { raises = true; reach[e] = len; }
+              }
+              if (raises) for (int e = 0; e < ends; ++e) next[e].push_back(R.carry[e][k]);
+            }
+            for (int e = 0; e < ends; ++e) { std::reverse(next[e].begin(), next[e].end()); R.carry[e].swap(next[e]); }
           }
           live_batches.push_back(std::move(owned));
         }
         const size_t lead = b->carry[0].size();
         const size_t n = b->n + lead;
+        { std::lock_guard<std::mutex> lk(mu); max_lead = std::max(max_lead, lead); }
         const uint64_t seq_no = b->seq;  // (a batch whose slices were handed over during the call may be recycled before it returns)
         bool queued = false;
         const auto t0 = now();
         trace("batch formed", b->seq, n);
         // the slices' reads, concatenated as the C ABI takes them (a single slice with nothing to lead it is used in place)
         const bool one = b->slices.size() == 1 && lead == 0;
-        for (int e = 0; e < (paired ? 2 : 1); ++e) {
+        for (int e = 0; e < ends; ++e) {
           if (one) continue;
           size_t bytes = 0;
           for (const std::string &c : b->carry[e]) bytes += c.size();
@@ -1338,7 +1638,7 @@ int cmd_map(int argc, char **argv) {
               for (size_t i = 0; i < m; ++i) dst[i] = sl.off[e][i] + s_at[k];
             }
           };
-          const size_t n_copy = std::min<size_t>(std::max<size_t>(1, n_host / 4), std::max<size_t>(1, b->slices.size() / 4));
+          const size_t n_copy = std::min<size_t>(std::max<size_t>(1, std::min<size_t>(n_host / 4, 8)), std::max<size_t>(1, b->slices.size() / 4));
           std::vector<std::thread> copiers;
           for (size_t t = 1; t < n_copy; ++t) copiers.emplace_back(copy_range, b->slices.size() * t / n_copy, b->slices.size() * (t + 1) / n_copy);
           copy_range(0, b->slices.size() / n_copy);
@@ -1357,6 +1657,11 @@ int cmd_map(int argc, char **argv) {
           blob_n[e] = one ? b->slices[0]->blob[e].size() : b->blob[e].size();
         }
         trace("batch ready", b->seq, n);
+        auto queue_slice = [&](Slice &sl) {  // a slice whose results it holds itself goes to the formatters of its node
+          std::lock_guard<std::mutex> lk(mu);
+          nq[sl.node].format.push_back(&sl);
+          wake_worker(sl.node);
+        };
         if (n) {
           // a few CIGAR ops per read are typical; the worst case (read length + 2 each) is only
           // allocated if the first size turns out too small
@@ -1365,27 +1670,50 @@ int cmd_map(int argc, char **argv) {
           queued = false;
           for (;;) {
             int rc;
-            if (!paired && opt.host_ceiling) {
-              // diagnostic: what the pipeline around the mapper can carry.  Every read "maps" somewhere inside the first
-              // chromosome with one mismatch and a single-op CIGAR; nothing is sent to the GPU.
-              cap = std::max<uint64_t>(cap, n);
-              b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
+            if (virtual_gpus) {
+              // diagnostic: what the pipeline around the GPUs can carry.  Every read "maps" somewhere inside the first
+              // chromosome with one mismatch and a single-op CIGAR; nothing is sent to a GPU.  The hits are handed over
+              // the way the library hands real ones over: slice by slice into the slice's own arrays (or, with
+              // ABM_CLI_NO_STREAM, as one batch).
               const uint32_t c0 = ch.starts.size() > 2 ? ch.starts[1] : 0, c1 = ch.starts.size() > 2 ? ch.starts[2] : 0;
               const uint32_t span = c1 > c0 + 70000 ? c1 - c0 - 66000 : 1;
-              std::vector<std::thread> fill;
-              for (unsigned t = 0; t < 8; ++t)
-                fill.emplace_back([&, t] {
-                  for (size_t i = n * t / 8; i < n * (t + 1) / 8; ++i) {
-                    const uint32_t len = static_cast<uint32_t>(off_p[0][i + 1] - off_p[0][i]);
-                    abm_hit h;
-                    h.diffs = 1; h.flags = (i & 1) ? 0x10 : 0; h.pos = len ? c0 + static_cast<uint32_t>((i * 7919u) % span) : 0;
-                    b->se[0][i] = h;
-                    b->cig[0][i] = len << 4;
-                    b->cig_off[0][i] = i;
+              auto made_up = [&](size_t i) {
+                const uint32_t len = static_cast<uint32_t>(off_p[0][i + 1] - off_p[0][i]);
+                abm_hit h;
+                uint64_t key = 0;  // (a function of the read alone: the output does not depend on how batches were dealt)
+                if (len >= 8) std::memcpy(&key, blob_p[0] + off_p[0][i] + len / 2 - 4, 8);
+                key = (key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull;
+                h.diffs = 1; h.flags = (key >> 40 & 1) ? 0x10 : 0; h.pos = len ? c0 + static_cast<uint32_t>((key >> 8) % span) : 0;
+                return h;
+              };
+              if (stream_slices) {
+                size_t lo = lead;
+                for (auto &slp : b->slices) {
+                  Slice &sl = *slp;
+                  const size_t m = sl.n();
+                  sl.own_se.resize(std::max<size_t>(m, 1)); sl.own_cig.resize(m + 1); sl.own_cig_off.resize(m + 1);
+                  for (size_t i = 0; i < m; ++i) {
+                    sl.own_se[i] = made_up(lo + i);
+                    sl.own_cig[i] = static_cast<uint32_t>(off_p[0][lo + i + 1] - off_p[0][lo + i]) << 4;
+                    sl.own_cig_off[i] = i;
                   }
-                });
-              for (auto &t : fill) t.join();
-              b->cig_off[0][n] = n;
+                  sl.own_cig_off[m] = m;
+                  sl.own = true;
+                  lo += m;
+                  queue_slice(sl);
+                }
+                queued = true;
+              }
+              else {
+                cap = std::max<uint64_t>(cap, n);
+                b->se[0].resize(n); b->cig[0].resize(cap); b->cig_off[0].resize(n + 1);
+                for (size_t i = 0; i < n; ++i) {
+                  b->se[0][i] = made_up(i);
+                  b->cig[0][i] = static_cast<uint32_t>(off_p[0][i + 1] - off_p[0][i]) << 4;
+                  b->cig_off[0][i] = i;
+                }
+                b->cig_off[0][n] = n;
+              }
               rc = 0;
             }
             else if (!paired && stream_slices) {
@@ -1395,9 +1723,8 @@ int cmd_map(int argc, char **argv) {
               first[0] = lead;
               for (size_t k = 0; k < b->slices.size(); ++k) first[k + 1] = first[k] + b->slices[k]->n();
               struct Taker {
-                abm_ctx *ctx; Batch *b; const std::vector<uint64_t> *first; std::mutex *mu; std::deque<Slice *> *q;
-                std::condition_variable *cv; int rc; std::string err;
-              } taker{ctx, b, &first, &mu, &q_format, &cv_work, 0, std::string()};
+                abm_ctx *ctx; Batch *b; const std::vector<uint64_t> *first; decltype(queue_slice) *queue; int rc; std::string err;
+              } taker{ctx, b, &first, &queue_slice, 0, std::string()};
               auto on_done = [](void *user, uint32_t s) {
                 Taker &t = *static_cast<Taker *>(user);
                 Slice &sl = *t.b->slices[s];
@@ -1414,11 +1741,7 @@ int cmd_map(int argc, char **argv) {
                   t.err = abm_last_error();
                 }
                 sl.own = true;
-                {
-                  std::lock_guard<std::mutex> lk(*t.mu);
-                  t.q->push_back(&sl);
-                }
-                t.cv->notify_one();
+                (*t.queue)(sl);
               };
               rc = abm_map_se_batch_sliced(ctx, se_mode, &par, n, blob_p[0], off_p[0], static_cast<uint32_t>(b->slices.size()),
                                            first.data(), on_done, &taker);
@@ -1444,20 +1767,22 @@ int cmd_map(int argc, char **argv) {
         }
         else { b->cig_off[0].assign(1, 0); b->cig_off[1].assign(1, 0); }
         trace("batch mapped", seq_no, n);
+        const double dt = since(t0);
         {
           std::lock_guard<std::mutex> lk(mu);
-          busy_map += since(t0);
+          busy_map += dt;
           if (!queued)
-            for (auto &sl : b->slices) q_format.push_back(sl.get());
+            for (auto &sl : b->slices) { nq[sl->node].format.push_back(sl.get()); wake_worker(sl->node); }
         }
-        cv_work.notify_all();
       }
     }
     catch (...) { fail(); }
     std::lock_guard<std::mutex> lk(mu);
     --mappers_live;
-    cv_work.notify_all();
-    cv_write.notify_all();
+    --R.mappers_live;
+    for (NodeQueues &q : nq) q.cv.notify_all();
+    R.cv_map.notify_all();  // (the region's other mappers share out what is left by their number)
+    R.cv_write.notify_all();
   };
 
   auto format_slice = [&](Slice &sl) {
@@ -1511,100 +1836,125 @@ int cmd_map(int argc, char **argv) {
       }
     }
   };
+  // formats a slice; its place in its region's file is fixed once every earlier slice's size is known
+  auto format_task = [&](Slice *sl) {
+    const auto t0 = now();
+    format_slice(*sl);
+    if (opt.bam) { RawBuf z; bgzf_compress(sl->text, z); sl->text.swap(z); }
+    const double dt = since(t0);
+    Region &R = regions[sl->region];
+    const auto tl = now();
+    std::lock_guard<std::mutex> lk(mu);
+    lock_wait += since(tl);
+    busy_format += dt;
+    trace("formatted", sl->g, static_cast<uint64_t>(dt * 1e6));
+    R.formatted[sl->g] = sl;
+    bool placed = false;
+    for (auto it = R.formatted.find(R.next_to_place); it != R.formatted.end(); it = R.formatted.find(R.next_to_place)) {
+      it->second->place = R.file_offset;
+      R.file_offset += it->second->text.size();
+      R.q_write.push_back(it->second);
+      R.formatted.erase(it);
+      ++R.next_to_place;
+      placed = true;
+    }
+    if (placed) R.cv_write.notify_one();
+  };
 
-  // formats slices (any number of workers); a slice's place in the file is fixed once every earlier slice's size is known
-  auto worker = [&]() {
+  // host workers: -t of them, pinned node by node; each takes the most urgent task its node has, else another node's
+  auto worker = [&](int node) {
+    topo.pin(node, workers_on[node]);
+    std::vector<char> count_buf;
+    const bool count_first = n_regions > 1;  // (the later regions cannot start before the whole input has been counted)
     try {
       for (;;) {
+        std::unique_ptr<Slice> to_parse;
         Slice *to_format = nullptr;
+        size_t ce = 0; uint64_t ck = 0; bool to_count = false;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv_work.wait(lk, [&] { return failure || !q_format.empty() || mappers_live == 0; });
-          if (failure || q_format.empty()) break;
-          to_format = q_format.front();
-          q_format.pop_front();
+          for (;;) {
+            if (failure) return;
+            if (count_first && plain_input && take_chunk(ce, ck)) { to_count = true; break; }
+            auto take_from = [&](int n) {
+              if (!nq[n].format.empty()) { to_format = nq[n].format.front(); nq[n].format.pop_front(); return true; }
+              if (!nq[n].parse.empty()) { to_parse = std::move(nq[n].parse.front()); nq[n].parse.pop_front(); return true; }
+              return false;
+            };
+            if (take_from(node)) break;
+            if (!count_first && plain_input && take_chunk(ce, ck)) { to_count = true; break; }
+            bool got = false;
+            for (int k = 1; k < n_nodes && !got; ++k) got = take_from((node + k) % n_nodes);
+            if (got) break;
+            if (mappers_live == 0) return;  // (nothing queued and nobody left to queue anything)
+            ++nq[node].idle;
+            nq[node].cv.wait(lk);
+            --nq[node].idle;
+          }
         }
-        const auto t0 = now();
-        format_slice(*to_format);
-        if (opt.bam) { RawBuf z; bgzf_compress(to_format->text, z); to_format->text.swap(z); }
-        std::lock_guard<std::mutex> lk(mu);
-        busy_format += since(t0);
-        trace("formatted", to_format->g, static_cast<uint64_t>(since(t0) * 1e6));
-        formatted[to_format->g] = to_format;
-        // fix the place of every slice whose predecessors are all formatted
-        bool placed = false;
-        for (auto it = formatted.find(next_to_place); it != formatted.end(); it = formatted.find(next_to_place)) {
-          place[next_to_place] = file_offset;
-          file_offset += it->second->text.size();
-          q_write.push_back(it->second);
-          formatted.erase(it);
-          ++next_to_place;
-          placed = true;
-        }
-        if (placed) cv_write.notify_one();
+        if (to_count) count_chunk(ce, ck, count_buf);
+        else if (to_format) format_task(to_format);
+        else parse_slice(std::move(to_parse));
       }
     }
     catch (...) { fail(); }
   };
-  // ONE writer: slices leave in order, each with a single pwrite at its place (or write, into a pipe).  One thread
-  // writing sequentially is what a tmpfs file takes fastest -- measured on the GPU box, 2 GB in 8 MB pieces: 7.9 GB/s
-  // from one thread, 4.3 from four, 2.8 from sixteen, which contend for the file's lock (profiles/r03_write_probe.log).
-  auto writer = [&]() {
+  // ONE writer per output file: slices leave in order, each with a single pwrite at its place (or write, into a pipe).
+  // One file takes the same rate from one thread as from several (they queue for its lock: 6.5 GB/s on the GPU box's
+  // tmpfs with the source in DRAM, profiles/r04_sink_probe.log; round 2 had four writers among the formatting threads).
+  auto writer = [&](int r) {
+    Region &R = regions[r];
+    topo.pin(R.writer_node, 1);
     try {
       for (;;) {
         Slice *to_write = nullptr;
-        uint64_t at = 0;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv_write.wait(lk, [&] { return failure || !q_write.empty() || (mappers_live == 0 && cut_done && slices_written == n_slices); });
-          if (failure || q_write.empty()) break;
-          to_write = q_write.front(); q_write.pop_front(); at = place[to_write->g]; place.erase(to_write->g);
+          R.cv_write.wait(lk, [&] { return failure || !R.q_write.empty() || (R.mappers_live == 0 && R.cut_done && R.slices_written == R.n_slices); });
+          if (failure || R.q_write.empty()) break;
+          to_write = R.q_write.front(); R.q_write.pop_front();
         }
         const auto t0 = now();
-        write_all(to_write->text.data(), to_write->text.size(), at);
+        write_all(R, to_write->text.data(), to_write->text.size(), to_write->place);
+        const double dt = since(t0);
         std::unique_ptr<Batch> done_batch;
+        std::vector<std::unique_ptr<Slice>> done_slices;
         {
           std::lock_guard<std::mutex> lk(mu);
-          busy_write += since(t0);
-          trace("written", to_write->g, static_cast<uint64_t>(since(t0) * 1e6));
+          busy_write += dt;
+          trace("written", to_write->g, static_cast<uint64_t>(dt * 1e6));
           Batch *b = to_write->batch;
-          total_records += to_write->n();
+          R.records += to_write->n();
           for (int k = 0; k < 3; ++k)
             for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += to_write->stats.s[k].v[j];
-          reads_in_flight -= std::min<size_t>(reads_in_flight, slice_reads);
-          ++slices_written;
+          R.reads_in_flight -= std::min<size_t>(R.reads_in_flight, slice_reads);
+          ++R.slices_written;
           // the batch goes when its last slice is written; its slices and its own buffers are recycled
           if (--b->slices_left == 0) {
             for (auto it = live_batches.begin(); it != live_batches.end(); ++it)
               if (it->get() == b) {
-                for (auto &sl : (*it)->slices) slice_pool.put(std::move(sl));
+                done_slices.swap((*it)->slices);
                 done_batch = std::move(*it);
                 live_batches.erase(it);
                 break;
               }
           }
-          cv_flow.notify_one();
-          if (slices_written == n_slices) cv_write.notify_all();
+          R.cv_flow.notify_one();
+          if (R.slices_written == R.n_slices) R.cv_write.notify_all();
         }
-        if (done_batch) batch_pool.put(std::move(done_batch));
+        for (auto &sl : done_slices) { const int n = sl->node; slice_pool[n].put(std::move(sl)); }
+        if (done_batch) { const int n = done_batch->node; batch_pool[n].put(std::move(done_batch)); }
       }
     }
     catch (...) { fail(); }
   };
 
   std::vector<std::thread> threads;
-  parsers_live = static_cast<int>(n_host);
-  mappers_live = n_gpus * per_gpu;
-  if (plain_input) {
-    const unsigned n_count = std::max(1u, std::min(n_host, 16u));
-    for (unsigned t = 0; t < n_count; ++t) threads.emplace_back(counter);
-    threads.emplace_back(cutter_plain);
-  }
+  if (plain_input) for (int r = 0; r < n_regions; ++r) threads.emplace_back(cutter_plain, r);
   else threads.emplace_back(cutter_stream);
-  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(parser);
+  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(worker, static_cast<int>(t % n_nodes));
   for (int slot = 0; slot < n_gpus * per_gpu; ++slot) threads.emplace_back(mapper, slot);
-  for (unsigned t = 0; t < n_host; ++t) threads.emplace_back(worker);
-  threads.emplace_back(writer);
+  for (int r = 0; r < n_regions; ++r) threads.emplace_back(writer, r);
   {
     size_t k = 0;
     for (auto &t : threads) {  // (a join that has to wait shows in the trace: which thread the run's end hung on)
@@ -1617,15 +1967,25 @@ int cmd_map(int argc, char **argv) {
   trace("threads joined", threads.size(), 0);
   for (LineFile &F : lf) if (F.fd >= 0) ::close(F.fd);
   if (failure) std::rethrow_exception(failure);
-  if (opt.bam) {  // BGZF end-of-file marker
+  if (opt.bam) {  // BGZF end-of-file marker (closes the last part)
     static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    write_all(reinterpret_cast<const char *>(eof_block), 28, file_offset);
-    file_offset += 28;
+    Region &R = regions.back();
+    write_all(R, reinterpret_cast<const char *>(eof_block), 28, R.file_offset);
+    R.file_offset += 28;
   }
-  out_closer.fd = -1;
-  if (::close(out_fd) != 0) throw std::runtime_error("failed writing output file: " + opt.out);
-  trace("output closed", file_offset, 0);
+  uint64_t out_bytes = 0;
+  for (Region &R : regions) {
+    const int fd = R.fd;
+    R.fd = -1;
+    out_bytes += R.file_offset;
+    if (::close(fd) != 0) throw std::runtime_error("failed writing output file: " + R.path);
+  }
+  trace("output closed", out_bytes, 0);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  struct rusage ru1;
+  ::getrusage(RUSAGE_SELF, &ru1);
+  auto tv = [](const timeval &a, const timeval &b) { return static_cast<double>(a.tv_sec - b.tv_sec) + 1e-6 * static_cast<double>(a.tv_usec - b.tv_usec); };
+  const double cpu_user = tv(ru1.ru_utime, ru0.ru_utime), cpu_sys = tv(ru1.ru_stime, ru0.ru_stime);
 
   // statistics (6 counters x 3 structs, src/abismal.cpp:865-895, :1034-1037).  Every GPU's counters
   // already sit in this process, so the total is a host sum; with more than one GPU the same sum is
@@ -1634,10 +1994,12 @@ int cmd_map(int argc, char **argv) {
   // warning, never the statistics file of a finished run.
   static_assert(sizeof(Stats3) == 18 * sizeof(uint64_t), "18 counters");
   Stats3 tot;
+  uint64_t total_records = 0;
+  for (const Region &R : regions) total_records += R.records;
   for (const Stats3 &g : gpu_stats)
     for (int k = 0; k < 3; ++k)
       for (int j = 0; j < 6; ++j) tot.s[k].v[j] += g.s[k].v[j];
-  if (n_gpus > 1 && !std::getenv("ABM_CLI_NO_RCCL")) {
+  if (n_gpus > 1 && !virtual_gpus && !std::getenv("ABM_CLI_NO_RCCL")) {
     std::vector<Stats3> reduced(gpu_stats);
     std::vector<uint64_t *> ptrs;
     for (auto &s : reduced) ptrs.push_back(&s.s[0].v[0]);
@@ -1649,7 +2011,9 @@ int cmd_map(int argc, char **argv) {
       for (int g = 0; g < n_gpus; ++g)
         if (std::memcmp(&reduced[g], &tot, sizeof(Stats3)) != 0)
           throw std::runtime_error("statistics all-reduce disagrees with the host sum on GPU " + std::to_string(g));
-      if (opt.verbose) std::cerr << "[abismal-amd] statistics summed over " << n_gpus << " GPUs with one RCCL all-reduce\n";
+      if (opt.verbose)
+        std::cerr << "[abismal-amd] statistics summed over " << n_gpus << " GPUs with "
+                  << (shared_device ? "a host sum inside abm_stats_allreduce (replicas share a device)\n" : "one RCCL all-reduce\n");
     }
   }
   if (!opt.stats.empty()) {
@@ -1668,24 +2032,26 @@ int cmd_map(int argc, char **argv) {
     std::ofstream tj(opt.timing);
     tj << "{\"records\": " << total_records << ", \"reads\": " << (paired ? 2 : 1) * total_records << ", \"seconds\": " << secs
        << ", \"index_load_s\": " << index_load_s << ", \"host_prepare_s\": " << host_prepare_s << ", \"gpus\": " << n_gpus << ", \"mappers_per_gpu\": " << per_gpu
-       << ", \"host_threads\": " << n_host << ", \"batch_reads\": " << batch_reads << ", \"host_ceiling\": " << (opt.host_ceiling ? "true" : "false")
+       << ", \"host_threads\": " << n_host << ", \"numa_nodes\": " << n_nodes << ", \"pinned\": " << (topo.pinning ? "true" : "false")
+       << ", \"out_parts\": " << n_regions << ", \"out_bytes\": " << out_bytes << ", \"batches\": " << n_batches << ", \"max_lead_in_records\": " << max_lead
+       << ", \"batch_reads\": " << batch_reads << ", \"host_ceiling\": " << (virtual_gpus ? "true" : "false")
        << ", \"batches_per_gpu\": [";
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_batches[g];
     tj << "], \"reads_per_gpu\": [";
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_reads[g];
-    tj << "], \"busy_s\": {\"split\": " << busy_split
+    tj << "], \"cpu_s\": {\"user\": " << cpu_user << ", \"sys\": " << cpu_sys << "}, \"busy_s\": {\"split\": " << busy_split
        << ", \"parse\": " << busy_parse << ", \"map\": " << busy_map << ", \"format\": " << busy_format << ", \"write\": "
-       << busy_write << "}}\n";
+       << busy_write << ", \"lock_wait\": " << lock_wait << "}}\n";
   }
   if (opt.verbose)
     std::cerr << "[abismal-amd] " << total_records << (paired ? " pairs" : " reads") << " on " << n_gpus << " GPU(s) in "
               << secs << " s (" << (paired ? 2 : 1) * total_records / secs << " reads/s incl. host I/O)\n"
-              << "[abismal-amd] busy seconds: split " << busy_split << ", parse " << busy_parse << " (" << n_host
-              << " threads), map " << busy_map << " (" << n_gpus * per_gpu << " threads), format " << busy_format << " ("
-              << n_host << " threads), write " << busy_write << "\n";
+              << "[abismal-amd] busy seconds: count " << busy_split << ", parse " << busy_parse << ", format " << busy_format << " ("
+              << n_host << " host workers on " << n_nodes << " NUMA node(s)), map " << busy_map << " (" << n_gpus * per_gpu
+              << " threads), write " << busy_write << " (" << n_regions << " file(s)); process CPU " << cpu_user << " s user + " << cpu_sys << " s system\n";
   if (opt.verbose)
     for (int g = 0; g < n_gpus; ++g)
-      std::cerr << "[abismal-amd] GPU " << g << ": " << gpu_batches[g] << " batches, " << gpu_reads[g] << (paired ? " pairs\n" : " reads\n");
+      std::cerr << "[abismal-amd] GPU " << g << (virtual_gpus ? " (virtual)" : "") << ": " << gpu_batches[g] << " batches, " << gpu_reads[g] << (paired ? " pairs\n" : " reads\n");
   // Single-end reads of any length the reference takes are mapped (longer ones stop the run while the input is parsed,
   // with the reference's message).  Pairs: the paired-end kernels take ends of up to 1024 bases; a pair with a longer end
   // was written unmapped, which the reference would not have done -- so the run fails unless -skip-long accepts it.

@@ -44,6 +44,9 @@ enum { ABM_PE_NORMAL = 0, ABM_PE_PBAT = 1, ABM_PE_RANDOM = 2 };   /* :1950-2002,
 
 const char *abm_last_error(void);
 int abm_device_count(void); /* HIP devices visible to the process (0 = none: every abm_ctx_create will fail) */
+/* NUMA node of the host memory nearest to `device` (from its PCI address; -1 = unknown): where a host driver places
+ * the threads and buffers that feed that GPU (no reference counterpart: its worker threads are not placed). */
+int abm_device_numa_node(int device);
 /* Page-locked host memory, usable from every device (hipHostMalloc, portable): batches whose seq_blob / seq_off lie
  * in it are uploaded by the DMA engines at the link's rate instead of through the runtime's staging buffers (the
  * reference has no counterpart: its batches never leave the host). */
@@ -241,7 +244,9 @@ int abm_ctx_take_kernel_times(abm_ctx *ctx, double *ms_out, uint64_t capacity, u
 /* Mapping statistics are six counters per struct (src/abismal.cpp:865-895) in
  * up to three structs (pairs, read1, read2: :1034-1037) = 18 x u64.  Sums them
  * over every context in ctxs[] with one RCCL all-reduce (ncclSum over xGMI);
- * counters[k] points at the 18 host values of context k and receives the sum. */
+ * counters[k] points at the 18 host values of context k and receives the sum.
+ * Contexts that share a device (two replicas on one GPU) are summed on the host instead: a communicator takes a
+ * device once. */
 int abm_stats_allreduce(abm_ctx *const *ctxs, int n_ctx, uint64_t *const *counters);
 
 #ifdef __cplusplus

@@ -1,0 +1,90 @@
+"""CPU: the host pipeline of `abismal-amd map` around N GPUs, run with virtual GPUs (-virtual-gpus N: no device, every
+read gets a made-up hit that depends on the read alone).  What is checked is everything the multi-GPU CLI path does on
+the host: counting / cutting / parsing, the dealing of batches to per-GPU mapper threads, the lead-in a batch carries
+for 44-46-base reads, results handed over slice by slice, the ordered merge, per-region output files (-out-parts) whose
+concatenation is the one-file output, and the statistics sum."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "abismal_amd", "abismal-amd")
+SMALL = dict(ABM_CLI_SLICE_READS="1024", ABM_CLI_FIRST_BATCH="1024", ABM_CLI_CHUNK_BYTES="65536", ABM_CLI_MARK_LINES="64")
+
+
+def run(args, env=None, **kw):
+    r = subprocess.run([CLI, "map"] + [str(a) for a in args], env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600, **kw)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def body(paths):
+    out = []
+    for p in paths:
+        out += [ln for ln in open(p) if not ln.startswith("@PG")]
+    return out
+
+
+@pytest.fixture(scope="module")
+def reads(oracle, tmp_path_factory):
+    d = tmp_path_factory.mktemp("vgpu")
+    oracle.simulate(os.path.join(ROOT, "tests", "golden", "tRex1.fa"), str(d / "r"), 60000, single_end=True, seed=21)
+    return str(d / "r_1.fq"), d
+
+
+def test_virtual_gpus_write_what_one_gpu_writes(reads, trex_index):
+    fq, d = reads
+    run(["-virtual-gpus", 1, "-t", 3, "-i", trex_index, "-o", d / "one.sam", "-s", d / "one.st", fq])
+    ref = body([d / "one.sam"])
+    assert len(ref) > 50000
+    for gpus, parts, extra in ((4, 1, []), (4, 4, []), (8, 8, ["-mappers", 1]), (2, 4, []), (3, 1, ["-batch", 5000])):
+        out = d / f"g{gpus}p{parts}.sam"
+        run(["-virtual-gpus", gpus, "-out-parts", parts, "-batch", 4096, "-t", 6, "-timing", d / "t.json", "-i", trex_index, "-o", out,
+             "-s", d / "x.st", fq] + extra, env=SMALL)
+        files = [out] if parts == 1 else [f"{out}.part{k:03d}" for k in range(parts)]
+        assert body(files) == ref, (gpus, parts)
+        assert open(d / "x.st").read() == open(d / "one.st").read()
+        t = json.load(open(d / "t.json"))
+        assert t["out_parts"] == parts and t["gpus"] == gpus and sum(t["reads_per_gpu"]) == 60000
+        assert min(t["batches_per_gpu"]) >= 1, t  # every "GPU" was dealt batches
+        for f in files:
+            os.remove(f)
+
+
+def test_whole_batches_equal_slices(reads, trex_index):
+    fq, d = reads
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", d / "s.sam", fq], env=SMALL)
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", d / "w.sam", fq], env=dict(SMALL, ABM_CLI_NO_STREAM="1"))
+    assert body([d / "s.sam"]) == body([d / "w.sam"])
+
+
+def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):
+    # a library of uniformly short reads (45 bases: every read could be a ghost-bit source for the next
+    # batch) made each batch carry every read seen so far.  The lead-in holds only records that are longer than
+    # everything after them: for one read length, one record.
+    fq, d = reads
+    lines = open(fq).read().split("\n")
+    for k in range(0, len(lines) - 3, 4):
+        lines[k + 1], lines[k + 3] = lines[k + 1][:45], lines[k + 3][:45]
+    open(d / "short.fq", "w").write("\n".join(lines))
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 2048, "-timing", d / "t.json", "-i", trex_index, "-o", d / "short.sam", d / "short.fq"], env=SMALL)
+    t = json.load(open(d / "t.json"))
+    assert t["batches"] >= 20 and t["max_lead_in_records"] <= 2, t
+    # mixed lengths 44..120: at most one record per length step up to 110 bases
+    for k in range(0, len(lines) - 3, 4):
+        cut = 44 + (k // 4 * 7919) % 77
+        lines[k + 1], lines[k + 3] = lines[k + 1][:cut], lines[k + 3][:cut]
+    open(d / "mixed.fq", "w").write("\n".join(lines))
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 2048, "-timing", d / "t.json", "-i", trex_index, "-o", d / "mixed.sam", d / "mixed.fq"], env=SMALL)
+    t = json.load(open(d / "t.json"))
+    assert t["batches"] >= 20 and 1 <= t["max_lead_in_records"] <= 67, t
+
+
+def test_more_parts_than_mappers_is_refused(reads, trex_index):
+    fq, d = reads
+    r = subprocess.run([CLI, "map", "-virtual-gpus", "1", "-out-parts", "3", "-i", trex_index, "-o", str(d / "x.sam"), fq],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "out-parts" in r.stderr

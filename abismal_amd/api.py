@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "abm_index_chrom_starts", "abm_index_bytes", "abm_index_build", "abm_index_build_targets", "abm_index_build_opts", "abm_index_window", "abm_ctx_create", "abm_ctx_reserve", "abm_ctx_destroy",
     "abm_map_se_batch", "abm_map_se_batch_sliced", "abm_ctx_slice_results", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
-    "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_index_set_direct_narrowing", "abm_ctx_seed_extension",
+    "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_index_set_direct_narrowing", "abm_ctx_seed_extension", "abm_ctx_rebuild_seed_extension", "abm_device_numa_node",
 ]
 
 
@@ -186,6 +186,11 @@ class Context:
         a, b, n = C.c_uint32(), C.c_uint32(), C.c_uint64()
         _check(self._lib.abm_ctx_seed_extension(self.handle, C.byref(a), C.byref(b), C.byref(n)))
         return int(a.value), int(b.value), int(n.value)
+
+    def rebuild_seed_extension(self, max_candidates=0):
+        """abm_ctx_rebuild_seed_extension: the device's tables rebuilt for another max_candidates (set-up call)"""
+        self._lib.abm_ctx_rebuild_seed_extension.argtypes = [C.c_void_p, C.c_uint32]
+        _check(self._lib.abm_ctx_rebuild_seed_extension(self.handle, max_candidates))
 
     def map_se(self, reads, mode=SE_T_RICH, params=None):
         """abm_map_se_batch.  Returns (hits[HIT_DTYPE], cigar_blob[u32], cigar_off[u64])."""

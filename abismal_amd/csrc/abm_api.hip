@@ -251,9 +251,8 @@ void build_ext(DeviceReplica &rep, const abm_index &ix, abm::u32 maxc) {
   rep.ext_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// the index as a launch sees it: the context's arrays plus the replica's seed-extension tables.  Tables built for
-// another max_candidates are rebuilt if this context is the device's only one (its previous launches are waited
-// for); beside other contexts the call goes without tables (the kernels then bisect from the counters).
+// the index as a launch sees it: the context's arrays plus the replica's seed-extension tables -- if they were built
+// for the call's max_candidates; otherwise the call goes without tables (the kernels then bisect from the counters).
 abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc);
 
 abm::u32 words_for(abm::u32 max_len) { return std::max(1u, (max_len + 15) / 16); }
@@ -645,10 +644,9 @@ abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
   { std::lock_guard<std::mutex> lk(ctx->ix->mu); d.direct_min = d.planes[0] != nullptr ? ctx->ix->direct_min : 0u; }
   DeviceReplica &rep = *ctx->rep;
   std::lock_guard<std::mutex> lk(rep.mu);
-  if (rep.dix.ext_maxc != maxc && rep.ext_tried != maxc && rep.refs == 1 && !ctx->ix->h.multibit_genome) {
-    HIPCHK(hipDeviceSynchronize());
-    build_ext(rep, *ctx->ix, maxc);
-  }
+  // (never rebuilt here: a rebuild waits for the whole device, frees and allocates tens of gigabytes and runs for
+  // seconds -- inside an asynchronous entry point, and once per call for a caller that alternates two values.  Tables
+  // follow abm_index_set_max_candidates at context creation, or abm_ctx_rebuild_seed_extension.)
   if (rep.dix.ext2 != nullptr && rep.dix.ext_maxc == maxc) {
     d.ext2 = rep.dix.ext2; d.ext3t = rep.dix.ext3t; d.ext3a = rep.dix.ext3a;
     d.e2 = rep.dix.e2; d.e3 = rep.dix.e3; d.ext_maxc = maxc;
@@ -753,6 +751,21 @@ int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates) {
     if (!ix) throw std::invalid_argument("index is null");
     std::lock_guard<std::mutex> lk(ix->mu);
     ix->want_maxc = max_candidates;
+  });
+}
+
+int abm_ctx_rebuild_seed_extension(abm_ctx *ctx, uint32_t max_candidates) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("context is null");
+    const abm::u32 maxc = max_candidates ? max_candidates : ctx->ix->h.max_candidates;
+    DeviceReplica &rep = *ctx->rep;
+    std::lock_guard<std::mutex> lk(rep.mu);
+    if (rep.dix.ext_maxc == maxc) return;
+    if (rep.refs != 1) throw std::runtime_error("seed-extension tables are rebuilt only while the context is the only one on its device");
+    if (ctx->ix->h.multibit_genome) return;  // (such genomes get no tables)
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    build_ext(rep, *ctx->ix, maxc);
   });
 }
 
@@ -1148,15 +1161,20 @@ int abm_map_se_batch_sliced(abm_ctx *ctx, int mode, const abm_params *params, ui
         uint32_t first_open = 0;
         for (;;) {
           const bool running = hipStreamQuery(st) == hipErrorNotReady;
-          if (turn.owns_lock() && (!running || __atomic_load_n(ctx->drained, __ATOMIC_RELAXED) != 0u)) {
-            turn.unlock();
-            t2.mark("  map: drained");
-          }
+          // (the turn is passed on before any callback runs and looked at again before each one: a slow callback --
+          // result copies, the caller's queue locks -- must not hold up the other context's kernel launch)
+          auto pass_turn = [&](bool now) {
+            if (turn.owns_lock() && (now || __atomic_load_n(ctx->drained, __ATOMIC_RELAXED) != 0u)) {
+              turn.unlock();
+              t2.mark("  map: drained");
+            }
+          };
+          pass_turn(!running);
           bool any = false;
           if (stream) {
             while (first_open < n_slices && delivered[first_open]) ++first_open;
             for (uint32_t s = first_open; s < n_slices; ++s)
-              if (!delivered[s] && __atomic_load_n(&ctx->h_slice_done.p[s], __ATOMIC_ACQUIRE) != 0u) { deliver(s); any = true; }
+              if (!delivered[s] && __atomic_load_n(&ctx->h_slice_done.p[s], __ATOMIC_ACQUIRE) != 0u) { pass_turn(false); deliver(s); any = true; }
           }
           if (!running) break;
           if (!any) std::this_thread::sleep_for(std::chrono::microseconds(100));

@@ -10,6 +10,7 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -171,6 +172,7 @@ struct Slice {
   // single-end batches hand their results over slice by slice while the kernel runs (abm_map_se_batch_sliced): the
   // slice then holds its own copy -- hits and a compact CIGAR blob with n() + 1 offsets
   bool own = false;
+  bool virt = false;                 // virtual GPUs: own_* are filled in by the formatter (made-up hits)
   PodVec<abm_hit> own_se;
   PodVec<uint32_t> own_cig;
   PodVec<uint64_t> own_cig_off;
@@ -198,6 +200,7 @@ struct SlicePool {
     s->batch = nullptr;
     s->base = 0;
     s->own = false;
+    s->virt = false;
     s->tail.clear();
     std::lock_guard<std::mutex> lk(mu);
     if (free_list.size() < 1024) free_list.push_back(std::move(s));
@@ -351,13 +354,13 @@ struct RawSplitter {
   bool exhausted() const { return eof && carry.empty(); }
 };
 
-void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, std::vector<NameRef> &names,
+void parse_raw(const char *text, size_t text_n, uint64_t first_line, const std::string &path, std::vector<NameRef> &names,
                RawBuf &blob, std::vector<uint64_t> &off) {
   names.clear(); blob.clear(); off.assign(1, 0);
-  blob.reserve(raw.n / 2);
-  names.reserve(raw.n / 200 + 16);
-  off.reserve(raw.n / 200 + 16);
-  const char *p = raw.p, *end = p + raw.n;
+  blob.reserve(text_n / 2);
+  names.reserve(text_n / 200 + 16);
+  off.reserve(text_n / 200 + 16);
+  const char *p = text, *end = p + text_n;
   std::string line;
   for (uint64_t k = 0; p < end; ++k) {
     const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
@@ -390,6 +393,10 @@ void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, 
     p = nl + 1;
   }
   names.resize(off.size() - 1);  // a trailing name line without its sequence is not a record
+}
+void parse_raw(const RawBuf &raw, uint64_t first_line, const std::string &path, std::vector<NameRef> &names,
+               RawBuf &blob, std::vector<uint64_t> &off) {
+  parse_raw(raw.p, raw.n, first_line, path, names, blob, off);
 }
 
 // ---- SAM text (format_se / format_pe, src/abismal.cpp:481-545, :648-773) -------
@@ -529,26 +536,43 @@ template <class S> void put_bam_record(S &o, const Record &r) {
 }
 // raw bytes -> BGZF blocks (each an independent gzip member with the BC extra field)
 int g_bgzf_level = 1;  // deflate level of BAM output (-z): decoded content is the same at every level
+// One deflate state and one block buffer per thread, reset per block: deflateInit2 allocates a quarter of a megabyte,
+// and a hundred formatter threads doing that once per 64 KB block spent six times their compression time waiting on
+// the allocator (profiles/r04_host_ceiling.log: -B busy 384 s for 60 s of CPU).
+struct BgzfDeflater {
+  z_stream zs;
+  bool live = false;
+  int level = -2;
+  std::vector<unsigned char> buf;
+  ~BgzfDeflater() { if (live) deflateEnd(&zs); }
+  void prepare(int want_level) {
+    if (live && level == want_level) { deflateReset(&zs); return; }
+    if (live) deflateEnd(&zs);
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, want_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    live = true;
+    level = want_level;
+  }
+};
 template <class A, class B> void bgzf_compress(const A &raw, B &out) {
   constexpr size_t kBlock = 0xff00;
-  std::vector<unsigned char> buf(compressBound(kBlock) + 64);
+  thread_local BgzfDeflater d;
+  if (d.buf.empty()) d.buf.resize(compressBound(kBlock) + 64);
   for (size_t at = 0; at < raw.size(); at += kBlock) {
     const size_t len = std::min(kBlock, raw.size() - at);
-    z_stream zs;
-    std::memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, g_bgzf_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    d.prepare(g_bgzf_level);
+    z_stream &zs = d.zs;
     zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(raw.data() + at));
     zs.avail_in = static_cast<uInt>(len);
-    zs.next_out = buf.data();
-    zs.avail_out = static_cast<uInt>(buf.size());
-    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("deflate failed"); }
+    zs.next_out = d.buf.data();
+    zs.avail_out = static_cast<uInt>(d.buf.size());
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate failed");
     const size_t clen = zs.total_out;
-    deflateEnd(&zs);
     const uint32_t crc = static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(raw.data() + at), static_cast<uInt>(len)));
     static const unsigned char head[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
     out.append(reinterpret_cast<const char *>(head), 12);
     out.append("BC", 2); put_le16(out, 2); put_le16(out, static_cast<uint16_t>(clen + 25));
-    out.append(reinterpret_cast<const char *>(buf.data()), clen);
+    out.append(reinterpret_cast<const char *>(d.buf.data()), clen);
     put_le32(out, crc); put_le32(out, static_cast<uint32_t>(len));
   }
 }
@@ -789,6 +813,82 @@ struct Topology {
   }
 };
 
+// a mapped input file that shrinks under the run (truncated, a network file system losing it) faults with SIGBUS
+void install_sigbus_handler() {
+  struct sigaction sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = [](int) {
+    static const char msg[] = "abismal-amd: an input file changed or became unreadable while it was being read (SIGBUS on its mapping)\n";
+    (void)!::write(2, msg, sizeof(msg) - 1);
+    ::_exit(EXIT_FAILURE);
+  };
+  ::sigaction(SIGBUS, &sa, nullptr);
+}
+
+// The CPU time the container gives this process (CFS bandwidth control: cgroup v2 cpu.max, v1 cpu.cfs_quota_us): a pod
+// of an 8-GPU node typically gets its share of the cores (16 of 128 on the box this was measured on) although it sees
+// all 256 hardware threads.  More runnable threads than that do not run more: they burn the period's quota in its first
+// milliseconds and the whole process is frozen for the rest of it (profiles/r04_trace_parts8_t64.log: every thread
+// stalled 77 of every 100 ms) -- which is what made round 3's host pipeline "anti-scale" with its thread count.
+struct CpuQuota {
+  double cpus = 0;          // 0 = unlimited / unknown
+  std::string stat_path;    // cpu.stat of the same cgroup
+  bool v2 = false;
+  static bool read_file(const std::string &path, std::string &out) {
+    std::ifstream f(path);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+  }
+  CpuQuota() {
+    std::string own, v1_path, v2_path;
+    if (read_file("/proc/self/cgroup", own)) {
+      std::istringstream is(own);
+      std::string line;
+      while (std::getline(is, line)) {
+        const size_t a = line.find(':'), b = line.find(':', a + 1);
+        if (a == std::string::npos || b == std::string::npos) continue;
+        const std::string ctl = line.substr(a + 1, b - a - 1), path = line.substr(b + 1);
+        if (ctl.empty()) v2_path = path;
+        else if (("," + ctl + ",").find(",cpu,") != std::string::npos) v1_path = path;
+      }
+    }
+    std::string s;
+    for (const std::string &dir : {std::string("/sys/fs/cgroup") + v2_path, std::string("/sys/fs/cgroup")})
+      if (cpus == 0 && read_file(dir + "/cpu.max", s)) {
+        long long q = 0, per = 0;
+        if (std::sscanf(s.c_str(), "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) { cpus = static_cast<double>(q) / per; stat_path = dir + "/cpu.stat"; v2 = true; }
+        else if (s.compare(0, 3, "max") == 0) { stat_path = dir + "/cpu.stat"; v2 = true; break; }
+      }
+    if (stat_path.empty())
+      for (const std::string &dir : {std::string("/sys/fs/cgroup/cpu") + v1_path, std::string("/sys/fs/cgroup/cpu")}) {
+        std::string qs, ps;
+        if (read_file(dir + "/cpu.cfs_quota_us", qs) && read_file(dir + "/cpu.cfs_period_us", ps)) {
+          const long long q = std::atoll(qs.c_str()), per = std::atoll(ps.c_str());
+          if (q > 0 && per > 0) cpus = static_cast<double>(q) / per;
+          stat_path = dir + "/cpu.stat";
+          break;
+        }
+      }
+  }
+  // periods in which the cgroup was throttled so far, and for how long (seconds)
+  void throttled(uint64_t &periods, double &seconds) const {
+    periods = 0; seconds = 0;
+    std::string s;
+    if (stat_path.empty() || !read_file(stat_path, s)) return;
+    std::istringstream is(s);
+    std::string key;
+    unsigned long long v = 0;
+    while (is >> key >> v) {
+      if (key == "nr_throttled") periods = v;
+      else if (key == "throttled_usec") seconds = static_cast<double>(v) * 1e-6;
+      else if (key == "throttled_time") seconds = static_cast<double>(v) * 1e-9;
+    }
+  }
+};
+
 int cmd_map(int argc, char **argv) {
   const Options opt = parse_map(argc, argv);
   if (opt.out.empty()) { std::cerr << "Missing required argument\n-o, -outfile\n"; return EXIT_SUCCESS; }
@@ -972,11 +1072,24 @@ int cmd_map(int argc, char **argv) {
   // by its costliest reads (a quarter of a second, whatever the batch), so small batches waste the GPU;
   // cutting and parsing run far ahead of it, so a full batch is ready within a fraction of a kernel's time.
   const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
-  // host workers: -t, else 24 per GPU plus 8 (what 14 M reads/s per GPU of counting, parsing and formatting take on the
-  // measured busy times, with room to spare), never more than the box has cores (second SMT siblings add little and
-  // the mapper threads, the writers and the HIP runtime's own threads need somewhere to run)
-  const unsigned n_host = opt.threads ? std::max(1u, opt.threads)
-                                      : static_cast<unsigned>(std::min<size_t>(std::max<size_t>(topo.n_cores(), 1), 8u + 24u * static_cast<unsigned>(n_gpus)));
+  // host workers: -t, else 8 plus 8 per GPU (what 14 M reads/s per GPU of counting, parsing and formatting take, twice
+  // over: 0.2 us of CPU per read), never more than the box has cores (second SMT siblings add little, and the mapper
+  // threads, the writers and the HIP runtime's own threads need somewhere to run) -- and never more than the CPU time
+  // the container's quota gives the process (see CpuQuota), whatever -t says: threads beyond it do not run more, they
+  // get the whole process frozen for most of every scheduling period (ABM_CLI_NO_QUOTA_CLAMP=1 to measure just that).
+  const CpuQuota quota;
+  unsigned n_host = opt.threads ? std::max(1u, opt.threads)
+                                : static_cast<unsigned>(std::min<size_t>(std::max<size_t>(topo.n_cores(), 1), 8u + 8u * static_cast<unsigned>(n_gpus)));
+  n_host = std::min<unsigned>(n_host, static_cast<unsigned>(std::max<size_t>(1, topo.n_cores() * 2)));
+  if (quota.cpus > 0 && !std::getenv("ABM_CLI_NO_QUOTA_CLAMP")) {
+    const unsigned cap = std::max(1u, static_cast<unsigned>(quota.cpus + 0.5));
+    if (n_host > cap) {
+      if (opt.verbose || opt.threads) std::cerr << "[abismal-amd] " << n_host << " host workers asked for, " << cap << " started: the container's CPU quota is " << quota.cpus << " CPUs\n";
+      n_host = cap;
+    }
+  }
+  uint64_t throttled0 = 0; double throttled_s0 = 0;
+  quota.throttled(throttled0, throttled_s0);
   const size_t max_reads_in_flight = (static_cast<size_t>(n_gpus) * per_gpu + 2) * batch_reads + 4 * slice_reads * n_host;
 
   // which region a mapper thread serves: regions are dealt to the GPUs in blocks, a GPU's mappers take its regions in turn
@@ -1161,7 +1274,7 @@ int cmd_map(int argc, char **argv) {
               std::unique_ptr<Slice> x(new Slice);
               x->node = node;
               for (int e = 0; e < ends; ++e) {
-                x->raw[e].reserve(slice_reads * rec_bytes + (1u << 16)); touch(x->raw[e].p, x->raw[e].cap);
+                if (std::getenv("ABM_CLI_NO_MMAP")) { x->raw[e].reserve(slice_reads * rec_bytes + (1u << 16)); touch(x->raw[e].p, x->raw[e].cap); }  // (mapped input is parsed in place)
                 x->blob[e].reserve(slice_reads * (read_len + 2)); touch(x->blob[e].p, x->blob[e].cap);
                 x->names[e].reserve(slice_reads + 16);
                 x->off[e].reserve(slice_reads + 16);
@@ -1283,6 +1396,10 @@ int cmd_map(int argc, char **argv) {
     uint64_t next_chunk = 0;  // next chunk a worker counts
     uint64_t n_ready = 0;
     bool ends_with_newline = true;
+    // The file mapped read-only: counting and parsing read the page cache in place (names stay views into the mapping)
+    // instead of copying the whole input out of it twice with pread -- a fifth of the pipeline's CPU time per read
+    // (profiles/r04_host_ceiling.log).  nullptr (mapping refused, ABM_CLI_NO_MMAP=1): pread into per-slice buffers.
+    const char *map = nullptr;
   };
   std::vector<LineFile> lf(plain_input ? opt.reads.size() : 0);
   for (size_t e = 0; e < lf.size(); ++e) {
@@ -1294,7 +1411,14 @@ int cmd_map(int argc, char **argv) {
     lf[e].n_chunks = (lf[e].size + kChunk - 1) / kChunk;
     lf[e].chunks.resize(lf[e].n_chunks);
     if (lf[e].size) { char c = 0; if (::pread(lf[e].fd, &c, 1, static_cast<off_t>(lf[e].size - 1)) == 1) lf[e].ends_with_newline = c == '\n'; }
+    if (lf[e].size && !std::getenv("ABM_CLI_NO_MMAP")) {
+      void *m = ::mmap(nullptr, lf[e].size, PROT_READ, MAP_SHARED, lf[e].fd, 0);
+      if (m != MAP_FAILED) lf[e].map = static_cast<const char *>(m);
+    }
   }
+  struct Unmapper { std::vector<LineFile> *v; ~Unmapper() { for (LineFile &F : *v) if (F.map) ::munmap(const_cast<char *>(F.map), F.size); } } unmapper{&lf};
+  const bool mapped_input = !lf.empty() && std::all_of(lf.begin(), lf.end(), [](const LineFile &F) { return F.map != nullptr || F.size == 0; });
+  if (mapped_input) install_sigbus_handler();
   auto read_range = [&](int fd, const std::string &path, char *dst, uint64_t lo, uint64_t hi) {
     while (lo < hi) {
       const ssize_t got = ::pread(fd, dst, hi - lo, static_cast<off_t>(lo));
@@ -1315,10 +1439,14 @@ int cmd_map(int argc, char **argv) {
   auto count_chunk = [&](size_t e, uint64_t k, std::vector<char> &buf) {  // the newlines of one chunk
     const auto t0 = now();
     const uint64_t lo = k * kChunk, hi = std::min(lf[e].size, lo + kChunk);
-    buf.resize(kChunk);
-    read_range(lf[e].fd, opt.reads[e], buf.data(), lo, hi);
+    const char *base = lf[e].map ? lf[e].map + lo : nullptr;
+    if (!base) {
+      buf.resize(kChunk);
+      read_range(lf[e].fd, opt.reads[e], buf.data(), lo, hi);
+      base = buf.data();
+    }
     ChunkInfo ci;
-    const char *p = buf.data(), *end = p + (hi - lo);
+    const char *p = base, *end = p + (hi - lo);
     uint64_t until_mark = kMark;
     while (p < end) {  // block counts vectorise; a block holding a mark is walked newline by newline
       const size_t blk = std::min<size_t>(static_cast<size_t>(end - p), 4096);
@@ -1331,7 +1459,7 @@ int cmd_map(int argc, char **argv) {
         if (!nl) break;
         ++ci.lines;
         q = nl + 1;
-        if (--until_mark == 0) { ci.marks.push_back(static_cast<uint32_t>(q - buf.data())); until_mark = kMark; }
+        if (--until_mark == 0) { ci.marks.push_back(static_cast<uint32_t>(q - base)); until_mark = kMark; }
       }
       p = bend;
     }
@@ -1373,16 +1501,20 @@ int cmd_map(int argc, char **argv) {
     while (seen < local) {  // walk the <= kMark lines after the mark
       const uint64_t want = std::min<uint64_t>(hi - (base + at), 1u << 16);
       if (want == 0) return false;
-      buf.resize(want);
-      read_range(F.fd, opt.reads[e], buf.data(), base + at, base + at + want);
-      const char *p = buf.data(), *end = p + want;
+      const char *text = F.map ? F.map + base + at : nullptr;
+      if (!text) {
+        buf.resize(want);
+        read_range(F.fd, opt.reads[e], buf.data(), base + at, base + at + want);
+        text = buf.data();
+      }
+      const char *p = text, *end = p + want;
       while (p < end && seen < local) {
         const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
         if (!nl) { p = end; break; }
         ++seen;
         p = nl + 1;
       }
-      at += static_cast<uint64_t>(p - buf.data());
+      at += static_cast<uint64_t>(p - text);
     }
     off_out = base + at;
     return true;
@@ -1423,9 +1555,12 @@ int cmd_map(int argc, char **argv) {
         for (size_t e = 0; e < nf; ++e) {
           uint64_t a = 0, b = 0;
           if (!offset_after_line(e, cur[e], 4 * lead_rec, a) || !offset_after_line(e, cur[e], line, b)) { done[e] = true; lo[e] = lf[e].size; continue; }
-          raw.resize(b - a);
-          read_range(lf[e].fd, opt.reads[e], raw.p, a, b);
-          parse_raw(raw, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+          if (lf[e].map) parse_raw(lf[e].map + a, b - a, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+          else {
+            raw.resize(b - a);
+            read_range(lf[e].fd, opt.reads[e], raw.p, a, b);
+            parse_raw(raw, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+          }
           lo[e] = b;
         }
         std::vector<std::string> lead[2];
@@ -1468,6 +1603,10 @@ int cmd_map(int argc, char **argv) {
     const auto t0 = now();
     Region &R = regions[sl->region];
     for (int e = 0; e < ends; ++e) {
+      if (plain_input && lf[e].map) {  // parsed in place: the names are views into the mapping
+        parse_raw(lf[e].map + sl->byte_lo[e], sl->byte_hi[e] - sl->byte_lo[e], sl->first_line[e], opt.reads[e], sl->names[e], sl->blob[e], sl->off[e]);
+        continue;
+      }
       if (plain_input) {
         if (!sl->raw[e].p) sl->raw[e] = raw_pool[sl->node].get();
         const uint64_t len = sl->byte_hi[e] - sl->byte_lo[e];
@@ -1687,19 +1826,15 @@ int cmd_map(int argc, char **argv) {
                 return h;
               };
               if (stream_slices) {
-                size_t lo = lead;
+                // (an infinitely fast GPU: the slice's made-up hits are written by whichever worker formats it, from
+                // its own reads -- filled in here, 8 M reads of a batch took this one thread 0.25 s, which a run of
+                // 0.6 s then waited for at its end)
                 for (auto &slp : b->slices) {
                   Slice &sl = *slp;
                   const size_t m = sl.n();
                   sl.own_se.resize(std::max<size_t>(m, 1)); sl.own_cig.resize(m + 1); sl.own_cig_off.resize(m + 1);
-                  for (size_t i = 0; i < m; ++i) {
-                    sl.own_se[i] = made_up(lo + i);
-                    sl.own_cig[i] = static_cast<uint32_t>(off_p[0][lo + i + 1] - off_p[0][lo + i]) << 4;
-                    sl.own_cig_off[i] = i;
-                  }
-                  sl.own_cig_off[m] = m;
                   sl.own = true;
-                  lo += m;
+                  sl.virt = true;
                   queue_slice(sl);
                 }
                 queued = true;
@@ -1785,9 +1920,27 @@ int cmd_map(int argc, char **argv) {
     R.cv_write.notify_all();
   };
 
+  auto fill_virtual = [&](Slice &sl) {  // a virtual GPU's results for one slice: a function of each read alone
+    const uint32_t c0 = ch.starts.size() > 2 ? ch.starts[1] : 0, c1 = ch.starts.size() > 2 ? ch.starts[2] : 0;
+    const uint32_t span = c1 > c0 + 70000 ? c1 - c0 - 66000 : 1;
+    const size_t m = sl.n();
+    for (size_t i = 0; i < m; ++i) {
+      const uint32_t len = static_cast<uint32_t>(sl.off[0][i + 1] - sl.off[0][i]);
+      abm_hit h;
+      uint64_t key = 0;
+      if (len >= 8) std::memcpy(&key, sl.blob[0].data() + sl.off[0][i] + len / 2 - 4, 8);
+      key = (key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull;
+      h.diffs = 1; h.flags = (key >> 40 & 1) ? 0x10 : 0; h.pos = len ? c0 + static_cast<uint32_t>((key >> 8) % span) : 0;
+      sl.own_se[i] = h;
+      sl.own_cig[i] = len << 4;
+      sl.own_cig_off[i] = i;
+    }
+    sl.own_cig_off[m] = m;
+  };
   auto format_slice = [&](Slice &sl) {
     const Batch *b = sl.batch;
     t_bam = opt.bam;
+    if (sl.virt) fill_virtual(sl);
     RawBuf &sam = sl.text;
     Stats3 &st = sl.stats;
     const size_t m = sl.n(), base = sl.base;
@@ -1840,7 +1993,13 @@ int cmd_map(int argc, char **argv) {
   auto format_task = [&](Slice *sl) {
     const auto t0 = now();
     format_slice(*sl);
-    if (opt.bam) { RawBuf z; bgzf_compress(sl->text, z); sl->text.swap(z); }
+    if (opt.bam) {  // (the block stream is built in a buffer the thread keeps, then trades places with the slice's text)
+      thread_local RawBuf z;
+      z.clear();
+      z.reserve(sl->text.size() / 2 + (1u << 16));
+      bgzf_compress(sl->text, z);
+      sl->text.swap(z);
+    }
     const double dt = since(t0);
     Region &R = regions[sl->region];
     const auto tl = now();
@@ -1986,6 +2145,8 @@ int cmd_map(int argc, char **argv) {
   ::getrusage(RUSAGE_SELF, &ru1);
   auto tv = [](const timeval &a, const timeval &b) { return static_cast<double>(a.tv_sec - b.tv_sec) + 1e-6 * static_cast<double>(a.tv_usec - b.tv_usec); };
   const double cpu_user = tv(ru1.ru_utime, ru0.ru_utime), cpu_sys = tv(ru1.ru_stime, ru0.ru_stime);
+  uint64_t throttled1 = 0; double throttled_s1 = 0;
+  quota.throttled(throttled1, throttled_s1);
 
   // statistics (6 counters x 3 structs, src/abismal.cpp:865-895, :1034-1037).  Every GPU's counters
   // already sit in this process, so the total is a host sum; with more than one GPU the same sum is
@@ -2039,7 +2200,8 @@ int cmd_map(int argc, char **argv) {
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_batches[g];
     tj << "], \"reads_per_gpu\": [";
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_reads[g];
-    tj << "], \"cpu_s\": {\"user\": " << cpu_user << ", \"sys\": " << cpu_sys << "}, \"busy_s\": {\"split\": " << busy_split
+    tj << "], \"cpu_quota_cpus\": " << quota.cpus << ", \"throttled_periods\": " << (throttled1 - throttled0) << ", \"throttled_s\": " << (throttled_s1 - throttled_s0)
+       << ", \"cpu_s\": {\"user\": " << cpu_user << ", \"sys\": " << cpu_sys << "}, \"busy_s\": {\"split\": " << busy_split
        << ", \"parse\": " << busy_parse << ", \"map\": " << busy_map << ", \"format\": " << busy_format << ", \"write\": "
        << busy_write << ", \"lock_wait\": " << lock_wait << "}}\n";
   }
@@ -2048,7 +2210,8 @@ int cmd_map(int argc, char **argv) {
               << secs << " s (" << (paired ? 2 : 1) * total_records / secs << " reads/s incl. host I/O)\n"
               << "[abismal-amd] busy seconds: count " << busy_split << ", parse " << busy_parse << ", format " << busy_format << " ("
               << n_host << " host workers on " << n_nodes << " NUMA node(s)), map " << busy_map << " (" << n_gpus * per_gpu
-              << " threads), write " << busy_write << " (" << n_regions << " file(s)); process CPU " << cpu_user << " s user + " << cpu_sys << " s system\n";
+              << " threads), write " << busy_write << " (" << n_regions << " file(s)); process CPU " << cpu_user << " s user + " << cpu_sys << " s system"
+              << "; CPU quota " << quota.cpus << " CPUs (0 = none), throttled in " << (throttled1 - throttled0) << " periods for " << (throttled_s1 - throttled_s0) << " s\n";
   if (opt.verbose)
     for (int g = 0; g < n_gpus; ++g)
       std::cerr << "[abismal-amd] GPU " << g << (virtual_gpus ? " (virtual)" : "") << ": " << gpu_batches[g] << " batches, " << gpu_reads[g] << (paired ? " pairs\n" : " reads\n");

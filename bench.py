@@ -47,6 +47,21 @@ HG38_FRACTIONS = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 11
                   64, 47, 51, 156, 57]  # chr1..22, X, Y in Mbp
 
 
+def physical_cores():
+    """cores of the box (first SMT sibling of each), from sysfs; falls back to the thread count"""
+    try:
+        seen = set()
+        base = "/sys/devices/system/cpu"
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                p = os.path.join(base, d, "topology", "thread_siblings_list")
+                if os.path.exists(p):
+                    seen.add(open(p).read().strip())
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -251,6 +266,24 @@ def sample_reads(genome_words, starts, n, L, seed, device, mut=0.01, bis=0.98, c
     return out.reshape(-1), n_skipped
 
 
+def lookup_traffic(kind, genome_mbp, n, L):
+    """L2->fabric read requests per launch (step) from a separate rocprofv3 --pmc pass over this same command
+    (profiles/r*_traffic*.json, newest round first); reported only when the workload matches -- kind ("se_trich",
+    "se_random", "pe"), genome size, reads (pairs) per step and read length."""
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None, None
+    for tf in sorted((f for f in os.listdir(pdir) if "_traffic" in f and f.endswith(".json")), reverse=True):
+        t = json.load(open(os.path.join(pdir, tf)))
+        wl = t.get("workload", {})
+        if (wl.get("kind", "se_trich"), wl.get("genome_mbp"), wl.get("reads"), wl.get("read_len")) == (kind, genome_mbp, n, L):
+            return t["hbm_read_bytes_per_launch"], (
+                f"profiles/{tf}: NOT measured in this run -- a separate rocprofv3 --pmc pass of the same command "
+                f"(build {t.get('build', 'n/a')}); TCC_EA0_RDREQ_sum x 128 B = read requests the L2s sent to the "
+                "fabric, Infinity-Cache hits included, so an upper bound on HBM bytes")
+    return None, None
+
+
 def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier):
     """Paired-end measurement (abm_map_pe_device); same timing protocol as the SE path."""
     import torch
@@ -384,7 +417,9 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
             compare_pe(slots[0].ctx.map_pe(h1, h2, mode=A.PE_NORMAL), orc, "bench sample")
         except AssertionError as e:
             full = str(e)[:300]
+        phys = physical_cores()
         cpu = {"value": round(2 * ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "physical_cores": phys, "per_thread": round(2 * ns / t_cpu / cores, 1), "per_core": round(2 * ns / t_cpu / phys, 1),
                "sample": f"first {ns} pairs, oracle restatement (-O3 -DNDEBUG), {cores} threads, {t_cpu:.1f}s",
                "pair_positions_identical_to_gpu": f"{same}/{ns}",
                "pairs_hits_fallbacks_cigars_vs_oracle": full}
@@ -411,6 +446,7 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                              strict["aligns"] + strict["aligns_tb"])
     use = s_bytes if s_bytes is not None else k_bytes
     achieved = use * done_pairs / elapsed / 1e9
+    pe_traffic, pe_traffic_source = lookup_traffic("pe", int(args.genome_mbp), n, L)  # per step: tier 1 + tier 2 launches
     roofline = {"bound": "hbm", "kernel": "map_pe_kernel (tier 1 + tier 2)", "achieved": round(achieved, 2), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "basis": "strict" if s_bytes is not None else "kernel_tally",
                 "alg_bytes_per_pair_strict": round(s_bytes, 1) if s_bytes is not None else None,
@@ -419,10 +455,32 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                 "denominator": "wall time of the timed region (kernels of %d slots overlap)" % len(slots),
                 "tier1_ms_per_launch": round(sum(tier_ms[0]) / max(1, len(tier_ms[0])), 2),
                 "tier2_ms_per_launch": round(sum(tier_ms[1]) / max(1, len(tier_ms[1])), 2),
-                "traffic": None,
+                "traffic": pe_traffic, "traffic_source": pe_traffic_source,
+                "traffic_over_algorithmic": round(pe_traffic / (use * n), 2) if pe_traffic else None,
                 "work_per_pair": {k: round(v / done_pairs, 2) for k, v in tw.items() if not k.startswith("cyc_")},
                 "tier2_share_of_candidates": round(tier_work[1].get("candidates", 0) / max(1, tw["candidates"]), 3),
                 "strict_counts_per_pair": {k: round(v, 2) for k, v in strict.items()} if cpu is not None else None}
+    n_slots = len(slots)
+    e2e = None
+    if not args.no_e2e:
+        # SURVEY 8(d)'s window for config 3: product sim (2 x L, fragments 150-500) -> two FASTQ files -> abismal-amd map ->
+        # SAM on tmpfs; this process lets go of the GPU first (every slot's tier-2 workspaces are ~10 GB)
+        kstat, n_pairs, n_conc, n_single = int(status.item()), int(stats[0]), int(stats[1]), int(stats[2])
+        for z in slots[1:]:
+            z.ctx.close()
+        del slots, pairs, se1, se2, status, b1, b2
+        ctx.close()
+        index.close()
+        torch.cuda.empty_cache()
+        tag = f"g{int(args.genome_mbp)}"
+        try:
+            e2e = run_e2e(args, os.path.join(args.workdir, tag + ".idx"), os.path.join(args.workdir, tag + ".fa"), L, gpus=world, kind="pe")
+        except Exception as exc:
+            e2e = {"error": f"{type(exc).__name__}: {exc}"[:1500]}
+        log(f"e2e (paired-end): {e2e}")
+    else:
+        kstat, n_pairs, n_conc, n_single = int(status.item()), int(stats[0]), int(stats[1]), int(stats[2])
+    pe_value = 2 * n * args.steps * world / elapsed
     print(json.dumps({
         "metric": "mapped reads/sec (whole node), paired-end", "value": round(2 * n * args.steps * world / elapsed, 1),
         "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen, "per_rank_reads_per_s": rank_rates,
@@ -430,21 +488,28 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step",
-                   "streams": len(slots)},
-        "roofline": roofline, "cpu_baseline": cpu, "kernel_status": int(status.item()), "phase_stamps": diag,
-        "mapping": {"pairs": int(stats[0]), "concordant": int(stats[1]), "ends_mapped_single": int(stats[2])}}), flush=True)
+                   "streams": n_slots},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "e2e_reads_per_s": e2e.get("value") if isinstance(e2e, dict) else None,
+        "e2e_over_kernel": round(e2e["value"] / pe_value, 4) if isinstance(e2e, dict) and e2e.get("value") else None,
+        "e2e": e2e, "kernel_status": kstat, "phase_stamps": diag,
+        "mapping": {"pairs": n_pairs, "concordant": n_conc, "ends_mapped_single": n_single}}), flush=True)
 
 
 
 # ---------------------------------------------------------------------------------- e2e
-def run_e2e(args, idx, fasta, L, gpus=1):
+def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
     """SURVEY.md section 8(d)'s window on `gpus` GPUs: FASTQ on disk -> SAM on disk through the product CLI
     (`abismal-amd map -gpus N`, a fresh child process), timed from the first batch submitted to the last SAM byte
     written (index load/upload excluded and reported).  The FASTQ comes from the product's own `sim` (md5-pinned
-    restatement of `abismal sim`) on the bench genome -- --e2e-reads reads, N times over for N GPUs; the MEDIAN of
-    three runs is the value.  A prefix of the input also goes through the oracle's CLI and the SAM bodies must be
-    identical.  The same input once more with -host-ceiling (no mapping call: every read gets a made-up hit) says
-    what the host pipeline around the mapper can carry on this box."""
+    restatement of `abismal sim`) on the bench genome with section 8(d)'s flags for the configuration -- kind "se":
+    config 2/4 (100 bp single-end), "random": config 5 (`sim -single -R`, 150 bp, fragments 150-500; `map -R`), "pe":
+    config 3 (2 x 150, fragments 150-500) -- --e2e-reads reads (pairs), N times over for N GPUs; the MEDIAN of three
+    runs is the value.  With N > 1 the run writes N ordered part files (-out-parts N: one tmpfs file takes 6.5 GB/s =
+    40 M reads/s of SAM text from any number of writers, profiles/r04_sink_probe.log).  A prefix of the input also goes
+    through the oracle's CLI and the SAM bodies must be identical.  Single-end, config 2: the same input once more
+    with -virtual-gpus N (no mapping call: every read gets a made-up hit) says what the host pipeline around the
+    mapper can carry on this box, and a gzip-compressed copy of a prefix says what compressed input costs."""
     import hashlib
     import shutil
     import statistics
@@ -460,12 +525,16 @@ def run_e2e(args, idx, fasta, L, gpus=1):
     try:
         n = args.e2e_reads
         t0 = time.time()
-        subprocess.run([cli, "sim", "-single", "-seed", "1", "-n", str(n), "-l", str(L), "-m", "0.01", "-b", "0.98",
+        sim_flags = {"se": ["-single"], "random": ["-single", "-R", "-min-fraglen", "150", "-max-fraglen", "500"],
+                     "pe": ["-min-fraglen", "150", "-max-fraglen", "500"]}[kind]
+        map_flags = ["-R"] if kind == "random" else []
+        subprocess.run([cli, "sim"] + sim_flags + ["-seed", "1", "-n", str(n), "-l", str(L), "-m", "0.01", "-b", "0.98",
                         "-o", os.path.join(wd, "reads"), fasta], check=True, stdout=subprocess.DEVNULL)
         t_sim = time.time() - t0
         fq1 = os.path.join(wd, "reads_1.fq")
+        fqs1 = [fq1] + ([os.path.join(wd, "reads_2.fq")] if kind == "pe" else [])
         fq, copies = fq1, 1
-        if gpus > 1:
+        if gpus > 1 and kind != "pe":
             # N GPUs map N times the reads: the same FASTQ N times over (fewer if the tmpfs cannot hold input + SAM)
             per_copy = os.path.getsize(fq1) * 1.8
             room = shutil.disk_usage(wd).free * 0.8
@@ -476,34 +545,71 @@ def run_e2e(args, idx, fasta, L, gpus=1):
                     for _ in range(copies):
                         with open(fq1, "rb") as fi:
                             shutil.copyfileobj(fi, fo, 1 << 24)
+        fqs = [fq] + fqs1[1:]
         sam, tj = os.path.join(wd, "out.sam"), os.path.join(wd, "timing.json")
-        gflag = ["-gpus", str(gpus)]
+        gflag = ["-gpus", str(gpus)] + map_flags
+        parts = gpus if gpus > 1 else 1
+        pflag = ["-out-parts", str(parts)] if parts > 1 else []
+        sam_files = [sam] if parts == 1 else [f"{sam}.part{k:03d}" for k in range(parts)]
         runs = []
         for rep in range(3):
-            r = subprocess.run([cli, "map"] + gflag + ["-i", idx, "-o", sam, "-s", os.path.join(wd, "out.stats"), "-timing", tj, fq],
+            r = subprocess.run([cli, "map"] + gflag + pflag + ["-i", idx, "-o", sam, "-s", os.path.join(wd, "out.stats"), "-timing", tj] + fqs,
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if r.returncode != 0:
                 return {"error": r.stderr[-2000:]}
             runs.append(json.load(open(tj)))
         secs = sorted(t["seconds"] for t in runs)
         med = [t for t in runs if t["seconds"] == secs[1]][0]
-        # what the host side alone can carry: the same command without the mapping call, at several thread counts
+        # what the host side alone can carry around `gpus` GPUs: the same command with virtual GPUs (no device, no mapping
+        # call), into the same kind of sink and into /dev/null, at several host-thread counts
         ceiling = []
-        for sink in (os.path.join(wd, "ceil.sam"), "/dev/null"):
-            for th in sorted({32, med["host_threads"], min(os.cpu_count() or 1, 128)}):
-                r = subprocess.run([cli, "map"] + gflag + ["-host-ceiling", "-seed-ext", "0,0", "-t", str(th), "-i", idx, "-o", sink, "-timing", tj, fq],
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-                if r.returncode == 0:
-                    t = json.load(open(tj))
-                    ceiling.append({"sink": "tmpfs file" if sink != "/dev/null" else "/dev/null", "host_threads": th,
-                                    "reads_per_s": round(t["reads"] / t["seconds"], 1), "seconds": round(t["seconds"], 3),
-                                    "busy_s": {k: round(v, 3) for k, v in t["busy_s"].items()}})
-                if sink != "/dev/null" and os.path.exists(sink):
-                    os.remove(sink)
+        if kind == "se":
+            for sink in (os.path.join(wd, "ceil.sam"), "/dev/null"):
+                for th in sorted({32, med["host_threads"], min(os.cpu_count() or 1, 128)}):
+                    r = subprocess.run([cli, "map", "-virtual-gpus", str(gpus)] + pflag + ["-t", str(th), "-i", idx, "-o", sink, "-timing", tj, fq],
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                    if r.returncode == 0:
+                        t = json.load(open(tj))
+                        ceiling.append({"sink": (f"{parts} tmpfs part files" if parts > 1 else "tmpfs file") if sink != "/dev/null" else "/dev/null", "host_threads": th,
+                                        "reads_per_s": round(t["reads"] / t["seconds"], 1), "seconds": round(t["seconds"], 3),
+                                        "busy_s": {k: round(v, 3) for k, v in t["busy_s"].items()}, "cpu_s": t.get("cpu_s")})
+                    for f in [sink] + [f"{sink}.part{k:03d}" for k in range(parts)]:
+                        if f != "/dev/null" and os.path.exists(f):
+                            os.remove(f)
+        # compressed input (single-end, one GPU): a prefix of the FASTQ as one gzip member (what `gzip` writes: inflated by
+        # one thread, as the reference's reader does, src/abismal.cpp:150-209) 
+        gz = None
+        if kind == "se" and gpus == 1 and args.e2e_gz_reads > 0:
+            import zlib
+            ngz = min(n, args.e2e_gz_reads)
+            gzp = os.path.join(wd, "prefix.fq.gz")
+            t0 = time.time()
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(fq1, "rb") as fi, open(gzp, "wb") as fo:
+                left = 4 * ngz
+                for line in fi:
+                    if left == 0:
+                        break
+                    fo.write(co.compress(line))
+                    left -= 1
+                fo.write(co.flush())
+            t_gz = time.time() - t0
+            r = subprocess.run([cli, "map", "-gpus", "1", "-i", idx, "-o", os.path.join(wd, "gz.sam"), "-timing", tj, gzp],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if r.returncode == 0:
+                t = json.load(open(tj))
+                gz = {"value": round(t["reads"] / t["seconds"], 1), "unit": "reads/s", "reads": t["reads"], "seconds": round(t["seconds"], 3),
+                      "input": f"the first {ngz} reads as ONE gzip member (level 1, {os.path.getsize(gzp)} bytes, written in {t_gz:.0f}s)",
+                      "note": "single-member gzip is inflated by one thread per file (zlib), as in the reference"}
+            else:
+                gz = {"error": r.stderr[-500:]}
+            for f in (gzp, os.path.join(wd, "gz.sam")):
+                if os.path.exists(f):
+                    os.remove(f)
         # one GPU: the same pipeline on a longer input (the FASTQ four times over) -- a 10 M-read run is a few batches
         # long, so it mostly measures how well the first batch's start and the last batch's output are hidden
         sustained = None
-        if args.e2e_copies > 1 and gpus == 1:
+        if args.e2e_copies > 1 and gpus == 1 and kind == "se":
             big = os.path.join(wd, "reads_x.fq")
             with open(big, "wb") as fo:
                 for _ in range(args.e2e_copies):
@@ -520,31 +626,37 @@ def run_e2e(args, idx, fasta, L, gpus=1):
                 if os.path.exists(f):
                     os.remove(f)
         out = {"value": round(med["reads"] / med["seconds"], 1), "unit": "reads/s", "gpus": gpus, "statistic": "median of three runs",
-               "sustained": sustained,
-               "window": "first batch submitted -> last SAM byte written (abismal-amd map -gpus N, plain FASTQ in, SAM text out, tmpfs)",
-               "reads": med["reads"], "input": f"{n} product-sim reads" + (f", {copies} times over" if copies > 1 else ""),
+               "sustained": sustained, "gzip_input": gz,
+               "window": "first batch submitted -> last SAM byte written (abismal-amd map -gpus N" + (f" -out-parts {parts}" if parts > 1 else "") +
+                         (" -R" if kind == "random" else "") + ", plain FASTQ in, SAM text out, tmpfs)",
+               "reads": med["reads"], "input": f"{n} product-sim " + ("pairs" if kind == "pe" else "reads") + (f", {copies} times over" if copies > 1 else "") +
+                                               " (sim " + " ".join(sim_flags) + f" -l {L})",
                "seconds": round(med["seconds"], 3), "seconds_of_each_run": [round(t["seconds"], 3) for t in runs],
                "index_load_s": round(med["index_load_s"], 2), "host_prepare_s": round(med.get("host_prepare_s", 0.0), 2),
-               "fastq_bytes": os.path.getsize(fq), "sam_bytes": os.path.getsize(sam), "sim_s": round(t_sim, 1),
-               "cli": {k: med[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "batch_reads", "batches_per_gpu", "reads_per_gpu") if k in med},
-               "busy_s": {k: round(v, 3) for k, v in med["busy_s"].items()},
-               "host_ceiling": ceiling,
-               "host_ceiling_reads_per_s": max([c["reads_per_s"] for c in ceiling if c["sink"] == "tmpfs file"], default=None),
+               "fastq_bytes": sum(os.path.getsize(f) for f in fqs), "sam_bytes": sum(os.path.getsize(f) for f in sam_files), "sim_s": round(t_sim, 1),
+               "cli": {k: med[k] for k in ("gpus", "mappers_per_gpu", "host_threads", "numa_nodes", "pinned", "out_parts", "batch_reads", "batches_per_gpu", "reads_per_gpu") if k in med},
+               "busy_s": {k: round(v, 3) for k, v in med["busy_s"].items()}, "cpu_s": med.get("cpu_s"),
+               "host_ceiling": ceiling or None,
+               "host_ceiling_reads_per_s": max([c["reads_per_s"] for c in ceiling if c["sink"] != "/dev/null"], default=None),
                "host_ceiling_reads_per_s_dev_null": max([c["reads_per_s"] for c in ceiling if c["sink"] == "/dev/null"], default=None),
-               "host_ceiling_note": "abismal-amd map -host-ceiling on the same input: cut, parse, format and write at full rate, every "
-                                    "read given a made-up hit instead of the mapping call; SAM to a tmpfs file and to /dev/null, at 32 / default / 128 host threads"}
+               "host_ceiling_note": ("abismal-amd map -virtual-gpus N on the same input: count, cut, parse, deal, format and write at full rate, every "
+                                     "read given a made-up hit instead of the mapping call; SAM into the run's kind of sink and into /dev/null, at 32 / "
+                                     "default / 128 host threads; scripts/r04_host_ceiling.py sweeps 40 M-read runs (profiles/r04_host_ceiling.log)") if ceiling else None}
         # parity on a prefix: product CLI vs oracle CLI, SAM body (everything but the @PG line) byte for byte
         nchk = min(n, args.e2e_check)
         if nchk > 0:
             from tests import oracle_binding as ob
             if not os.path.exists(ob.CLI):
                 ob.build_oracle()
-            pfq = os.path.join(wd, "prefix.fq")
-            with open(fq, "rb") as fi, open(pfq, "wb") as fo:
-                for k, line in enumerate(fi):
-                    if k >= 4 * nchk:
-                        break
-                    fo.write(line)
+            pfqs = []
+            for k, src in enumerate(fqs):
+                pfq = os.path.join(wd, f"prefix_{k + 1}.fq")
+                with open(src, "rb") as fi, open(pfq, "wb") as fo:
+                    for j, line in enumerate(fi):
+                        if j >= 4 * nchk:
+                            break
+                        fo.write(line)
+                pfqs.append(pfq)
 
             def body_md5(path, limit=None):
                 h, k = hashlib.md5(), 0
@@ -558,16 +670,16 @@ def run_e2e(args, idx, fasta, L, gpus=1):
                         k += 1
                 return h.hexdigest(), k
 
-            subprocess.run([cli, "map", "-i", idx, "-o", os.path.join(wd, "p_gpu.sam"), pfq], check=True,
+            subprocess.run([cli, "map"] + map_flags + ["-i", idx, "-o", os.path.join(wd, "p_gpu.sam")] + pfqs, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             t0 = time.time()
-            subprocess.run([ob.CLI, "map", "-t", str(os.cpu_count() or 1), "-i", idx, "-o", os.path.join(wd, "p_oracle.sam"), pfq],
+            subprocess.run([ob.CLI, "map"] + map_flags + ["-t", str(os.cpu_count() or 1), "-i", idx, "-o", os.path.join(wd, "p_oracle.sam")] + pfqs,
                            check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             t_or = time.time() - t0
             m_g, k_g = body_md5(os.path.join(wd, "p_gpu.sam"))
             m_o, k_o = body_md5(os.path.join(wd, "p_oracle.sam"))
-            m_f, _ = body_md5(sam, limit=k_g)  # the full run starts with the very same records
-            out["parity"] = {"prefix_reads": nchk, "sam_lines": k_g, "md5_product": m_g, "md5_oracle_cli": m_o,
+            m_f, _ = body_md5(sam_files[0], limit=k_g)  # the full run starts with the very same records
+            out["parity"] = {"prefix_" + ("pairs" if kind == "pe" else "reads"): nchk, "sam_lines": k_g, "md5_product": m_g, "md5_oracle_cli": m_o,
                              "md5_full_run_prefix": m_f, "identical": bool(m_g == m_o == m_f and k_g == k_o),
                              "oracle_cli_s": round(t_or, 1)}
     finally:
@@ -674,6 +786,8 @@ def main():
                     help="also time the CLI on the e2e FASTQ concatenated this many times (0/1 = skip)")
     ap.add_argument("--e2e-check", type=int, default=int(os.environ.get("ABM_BENCH_E2E_CHECK", 1_000_000)),
                     help="reads of the FASTQ prefix mapped by the oracle CLI too (SAM body md5 must agree)")
+    ap.add_argument("--e2e-gz-reads", type=int, default=int(os.environ.get("ABM_BENCH_E2E_GZ_READS", 2_000_000)),
+                    help="reads of the e2e FASTQ's prefix that also run as gzip-compressed input (0 = skip)")
     ap.add_argument("--seed-ext", default=os.environ.get("ABM_BENCH_SEED_EXT", ""),
                     help="letters of the seed-extension tables as 'a,b' (default: the library's choice from the index's size)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -727,7 +841,7 @@ def main():
         os.replace(idx + ".tmp", idx)  # atomic: a waiting rank never sees a partial file
         t_build = time.time() - t0
         log(f"index built in {t_build:.1f}s ({os.path.getsize(idx) / 1e9:.2f} GB)")
-        if (args.no_e2e or args.pe) and not os.environ.get("ABM_BENCH_KEEP_FASTA"):
+        if args.no_e2e and not os.environ.get("ABM_BENCH_KEEP_FASTA"):
             os.remove(fasta)  # (the end-to-end leg simulates its FASTQ from this file)
     t_wait = time.time()
     while not os.path.exists(idx):
@@ -891,17 +1005,7 @@ def main():
     avg_ms = kernel_ms / max(1, launches)
     # L2->fabric read requests per launch come from a separate rocprofv3 --pmc pass over this same command
     # (profiles/r*_traffic.json, newest round first); reported only when the workload matches
-    traffic, traffic_source = None, None
-    for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True) \
-            if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        t = json.load(open(os.path.join(ROOT, "profiles", tf)))
-        wl = t.get("workload", {})
-        if (wl.get("genome_mbp"), wl.get("reads"), wl.get("read_len")) == (int(args.genome_mbp), n, L):
-            traffic = t["hbm_read_bytes_per_launch"]
-            traffic_source = (f"profiles/{tf}: NOT measured in this run -- a separate rocprofv3 --pmc pass of the same command "
-                              f"(build {t.get('build', 'n/a')}); TCC_EA0_RDREQ_sum x 128 B = read requests the L2s sent to the "
-                              "fabric, Infinity-Cache hits included, so an upper bound on HBM bytes")
-            break
+    traffic, traffic_source = lookup_traffic("se_" + args.mode, int(args.genome_mbp), n, L)
 
     cpu, strict = None, None
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
@@ -916,7 +1020,6 @@ def main():
         t0 = time.perf_counter()
         o_res, o_cig, o_cn, o_work = o.map_se(oix, seqs, mode=int(se_mode), threads=cores, cig_stride=L + 2)
         t_cpu = time.perf_counter() - t0
-        o.index_free(oix)
         # full comparison on the sample: position, then diffs + flags, then the CIGAR op for op
         g_res = res[:ns].cpu().numpy().view(np.uint32)
         g_cn = cig_n[:ns].cpu().numpy().view(np.uint32)
@@ -938,7 +1041,21 @@ def main():
             good = bool(same_df[i]) and full == o_cig[i, :int(o_cn[i])].tolist()
             same_cig[i] = good
             long_ok += int(good)
+        # the same restatement on fewer threads (a fifth of the sample each): whether all hardware threads of a
+        # two-socket box are the fairest stand-in for `abismal -t <all cores>`; per-thread and per-core rates beside
+        phys = physical_cores()
+        sweep = [{"threads": cores, "reads_per_s": round(ns / t_cpu, 1), "per_thread": round(ns / t_cpu / cores, 1), "sample_reads": ns}]
+        ns_sw = max(1, ns // 5)
+        for th in sorted({max(1, phys // 2), phys} - {cores}):
+            t0 = time.perf_counter()
+            o.map_se(oix, seqs[:ns_sw], mode=int(se_mode), threads=th, cig_stride=L + 2)
+            dt = time.perf_counter() - t0
+            sweep.append({"threads": th, "reads_per_s": round(ns_sw / dt, 1), "per_thread": round(ns_sw / dt / th, 1), "sample_reads": ns_sw})
+        best = max(sweep, key=lambda s: s["reads_per_s"])
+        o.index_free(oix)
         cpu = {"value": round(ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "physical_cores": phys, "per_thread": round(ns / t_cpu / cores, 1), "per_core": round(ns / t_cpu / phys, 1),
+               "thread_sweep": sorted(sweep, key=lambda s: s["threads"]), "best_of_sweep": best,
                "sample": f"first {ns} reads of rank 0's batch, oracle restatement (-O3 -DNDEBUG), {cores} threads, {t_cpu:.1f}s",
                "positions_identical_to_gpu": f"{int(same_pos.sum())}/{ns}",
                "pos_diffs_flags_identical_to_gpu": f"{int(same_df.sum())}/{ns}",
@@ -990,14 +1107,14 @@ def main():
                                         per_launch["search_probes"] * 2) / (avg_ms * 1e-3), 0)}
 
     e2e = None
-    if not args.no_e2e and args.mode == "trich":  # (the other ranks have left by now: the CLI child drives all `world` GPUs itself)
+    if not args.no_e2e and args.mode in ("trich", "random"):  # (the other ranks have left by now: the CLI child drives all `world` GPUs itself)
         # free this process's HBM first: the CLI is a process of its own on the same GPU
         del blobs, blob, res, cig, cig_n
         ctx.close()
         index.close()
         torch.cuda.empty_cache()
         try:
-            e2e = run_e2e(args, idx, fasta, L, gpus=world)
+            e2e = run_e2e(args, idx, fasta, L, gpus=world, kind="random" if args.mode == "random" else "se")
         except Exception as exc:  # the line's `value` has been measured: a failing end-to-end leg must not lose it
             e2e = {"error": f"{type(exc).__name__}: {exc}"[:1500]}
         log(f"e2e: {e2e}")
@@ -1014,11 +1131,13 @@ def main():
             index.close()
             torch.cuda.empty_cache()
         other = {}
-        common = [sys.executable, os.path.abspath(__file__), "--no-e2e", "--no-other-configs", "--genome-mbp", str(args.genome_mbp),
-                  "--workdir", args.workdir]
-        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "16", "--warmup", "16", "--cpu-sample", "200000"]),
+        common = [sys.executable, os.path.abspath(__file__), "--no-other-configs", "--genome-mbp", str(args.genome_mbp),
+                  "--workdir", args.workdir] + (["--no-e2e"] if args.no_e2e else [])
+        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "16", "--warmup", "16", "--cpu-sample", "200000",
+                                                         "--e2e-reads", "2000000", "--e2e-check", "50000"]),
                            ("config5_random_pbat_150", ["--mode", "random", "--read-len", "150", "--reads", "4000000", "--steps", "3", "--warmup", "1",
-                                                        "--cpu-sample", "200000"])):
+                                                        "--cpu-sample", "200000", "--e2e-reads", "4000000", "--e2e-check", "200000", "--e2e-copies", "1",
+                                                        "--e2e-gz-reads", "0"])):
             t0 = time.time()
             r = subprocess.run(common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1040,7 +1159,13 @@ def main():
                                f"{n} sim-like reads x {L} bp SE per GPU per step, {mode_name}",
                    "reads_per_step_per_gpu": n, "read_len": L, "index_gb": index_gb,
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated"},
-        "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "other_configs": other,
+        "roofline": roofline, "cpu_baseline": cpu,
+        # SURVEY 8(d)'s metric proper -- FASTQ on disk -> SAM on disk through `abismal-amd map -gpus N` -- beside `value`
+        # (the HBM-resident kernel-loop rate the measurement contract defines; at N > 1 `value` is N independent loops
+        # added up, e2e is ONE process driving N GPUs through the host pipeline)
+        "e2e_reads_per_s": e2e.get("value") if isinstance(e2e, dict) else None,
+        "e2e_over_kernel": round(e2e["value"] / value, 4) if isinstance(e2e, dict) and e2e.get("value") else None,
+        "e2e": e2e, "other_configs": other,
         "mapping": {"total": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                     "unseedable": int(stats[3]), "edits": int(stats[4]), "bases": int(stats[5])},
         "work_per_read": {k: round(v / n, 2) for k, v in per_launch.items()},

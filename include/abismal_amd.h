@@ -85,8 +85,9 @@ uint32_t abm_index_window(const abm_index *ix);
  * letters plus letters2 more (2-letter table, at most 7) / letters3 more (3-letter tables, at most 4).  By default
  * the letters are chosen from the genome's length (none below 33 Mbp; 7 and 4 = 90 GB at hg38 scale, fewer if that
  * exceeds half of the free device memory); this call fixes them (0, 0 = no tables) and must precede the first
- * abm_ctx_create on the index.  The tables are built for the index's max_candidates; a call with another value
- * rebuilds them when its context is the only one on the device and otherwise runs without them. */
+ * abm_ctx_create on the index.  The tables are built for the index's max_candidates (or the value given to
+ * abm_index_set_max_candidates before the context was created); a call with another value runs without them --
+ * nothing is ever rebuilt inside a mapping call.  abm_ctx_rebuild_seed_extension rebuilds them explicitly. */
 int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3);
 /* the max_candidates (-c, src/abismal.cpp:2329) the calls on this index will pass, when it is not the value stored
  * in the index file: the tables of contexts created afterwards are built for it (0 = the file's value) */
@@ -97,6 +98,10 @@ int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates);
  * sorted by those letters, src/AbismalIndex.cpp:857-978).  Results are unaffected.  min_entries: the smallest range
  * taken that way (default 128; 0 = never); takes effect with the next call on any context of the index. */
 int abm_index_set_direct_narrowing(abm_index *ix, uint32_t min_entries);
+/* Rebuilds the tables of the context's device for another max_candidates (0 = the index file's).  Waits for the device,
+ * frees and allocates the tables' memory and runs for seconds at hg38 scale: a set-up call, allowed only while the
+ * context is the only one on its device. */
+int abm_ctx_rebuild_seed_extension(abm_ctx *ctx, uint32_t max_candidates);
 /* what the context's device holds: letters per table (0 = no tables) and their bytes */
 int abm_ctx_seed_extension(const abm_ctx *ctx, uint32_t *letters2, uint32_t *letters3, uint64_t *bytes);
 

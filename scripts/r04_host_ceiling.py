@@ -62,15 +62,19 @@ def one(label, args, env=None, sink="tmpfs"):
         rates.append(t["reads"] / t["seconds"] / 1e6)
         busy, cpu = t["busy_s"], t["cpu_s"]
     row = {"label": label, "args": args, "env": env or {}, "sink": sink, "reads": n_reads, "M_reads_per_s_median": round(statistics.median(rates), 2),
-           "runs": [round(x, 2) for x in rates], "host_threads": t["host_threads"], "gpus": t["gpus"], "out_parts": t["out_parts"],
+           "runs": [round(x, 2) for x in rates], "host_threads": t["host_threads"], "cpu_quota_cpus": t.get("cpu_quota_cpus"),
+           "throttled_periods_last": t.get("throttled_periods"), "throttled_s_last": t.get("throttled_s"), "gpus": t["gpus"], "out_parts": t["out_parts"],
            "out_GB": round(t["out_bytes"] / 1e9, 2), "busy_s_last": {k: round(v, 2) for k, v in busy.items()},
            "cpu_s_last": {k: round(v, 2) for k, v in cpu.items()}}
     rows.append(row)
-    print(f"{label:58s} {row['M_reads_per_s_median']:7.2f} M reads/s  runs {row['runs']}  busy {row['busy_s_last']} cpu {row['cpu_s_last']}", flush=True)
+    print(f"{label:58s} {row['M_reads_per_s_median']:7.2f} M reads/s  runs {row['runs']}  workers {row['host_threads']}  throttled {row['throttled_periods_last']} periods {row['throttled_s_last']:.2f} s  busy {row['busy_s_last']} cpu {row['cpu_s_last']}", flush=True)
     json.dump(rows, open(a.out, "w"), indent=1)
 
 
-threads = [32, 64, 128] if a.quick else [32, 64, 128, 256]
+for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
+    if os.path.exists(f):
+        print(f, open(f).read().strip(), flush=True)
+threads = [8, 16, 32, 64, 128, 256]
 for th in threads:
     one(f"8 vGPUs, 8 parts on tmpfs, -t {th}", ["-virtual-gpus", "8", "-out-parts", "8", "-t", str(th)])
 for th in threads:
@@ -85,10 +89,14 @@ one("1 vGPU, one tmpfs file, default -t", ["-virtual-gpus", "1"])
 one("1 vGPU, /dev/null, default -t", ["-virtual-gpus", "1"], sink="null")
 one("2 vGPUs, 2 parts on tmpfs, default -t", ["-virtual-gpus", "2", "-out-parts", "2"])
 one("4 vGPUs, 4 parts on tmpfs, default -t", ["-virtual-gpus", "4", "-out-parts", "4"])
-one("8 vGPUs, 8 parts, -t 128, not pinned", ["-virtual-gpus", "8", "-out-parts", "8", "-t", "128"], env={"ABM_CLI_PIN": "0"})
-one("8 vGPUs, one tmpfs file, -t 128, not pinned", ["-virtual-gpus", "8", "-t", "128"], env={"ABM_CLI_PIN": "0"})
-one("8 vGPUs, 8 parts BAM (-B) on tmpfs, -t 128", ["-virtual-gpus", "8", "-out-parts", "8", "-t", "128", "-B"])
-one("8 vGPUs, one BAM (-B) on tmpfs, -t 128", ["-virtual-gpus", "8", "-t", "128", "-B"])
+# what the container's CPU quota does to a process with more runnable threads than it pays for (the clamp off)
+for th in (32, 64, 128):
+    one(f"8 vGPUs, 8 parts, -t {th}, quota clamp OFF", ["-virtual-gpus", "8", "-out-parts", "8", "-t", str(th)], env={"ABM_CLI_NO_QUOTA_CLAMP": "1"})
+one("8 vGPUs, 8 parts, -t 64, clamp OFF, not pinned", ["-virtual-gpus", "8", "-out-parts", "8", "-t", "64"], env={"ABM_CLI_NO_QUOTA_CLAMP": "1", "ABM_CLI_PIN": "0"})
+one("8 vGPUs, 8 parts, default -t, not pinned", ["-virtual-gpus", "8", "-out-parts", "8"], env={"ABM_CLI_PIN": "0"})
+one("8 vGPUs, 8 parts, default -t, input through pread (no mapping)", ["-virtual-gpus", "8", "-out-parts", "8"], env={"ABM_CLI_NO_MMAP": "1"})
+one("8 vGPUs, 8 parts BAM (-B) on tmpfs, default -t", ["-virtual-gpus", "8", "-out-parts", "8", "-B"])
+one("8 vGPUs, one BAM (-B) on tmpfs, default -t", ["-virtual-gpus", "8", "-B"])
 for f in os.listdir(a.wd):
     if f.startswith("out.sam"):
         os.remove(os.path.join(a.wd, f))

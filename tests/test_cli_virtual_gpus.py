@@ -61,6 +61,15 @@ def test_whole_batches_equal_slices(reads, trex_index):
     assert body([d / "s.sam"]) == body([d / "w.sam"])
 
 
+def test_pread_path_equals_mapped_input(reads, trex_index):
+    # plain files are parsed in place from a read-only mapping; ABM_CLI_NO_MMAP=1 (and any file that cannot be mapped)
+    # takes the pread path with per-slice text buffers
+    fq, d = reads
+    run(["-virtual-gpus", 2, "-out-parts", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", d / "m.sam", fq], env=SMALL)
+    run(["-virtual-gpus", 2, "-out-parts", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", d / "p.sam", fq], env=dict(SMALL, ABM_CLI_NO_MMAP="1"))
+    assert body([f"{d}/m.sam.part000", f"{d}/m.sam.part001"]) == body([f"{d}/p.sam.part000", f"{d}/p.sam.part001"])
+
+
 def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):
     # a library of uniformly short reads (45 bases: every read could be a ghost-bit source for the next
     # batch) made each batch carry every read seen so far.  The lead-in holds only records that are longer than

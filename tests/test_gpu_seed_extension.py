@@ -2,7 +2,7 @@
 (bisection from the counters, the reference's find_candidates / find_candidates_three, src/abismal.cpp:1163-1259),
 a few, or the hg38-scale maximum of the 2-letter table -- results equal the oracle's, read for read, on the
 repeat-rich genome whose buckets need narrowing; and a call whose max_candidates differs from the one the tables
-were built for rebuilds them (single context) instead of using stale answers."""
+were built for runs without them (never stale answers, never a rebuild inside a mapping call); the explicit rebuild."""
 import os
 
 import pytest
@@ -55,11 +55,15 @@ def test_max_candidates_other_than_the_tables(oracle, rep):
     ctx = A.Context(ix, 0)
     try:
         reads = synth.trim_like_readloader(synth.mutated_reads(fa, 4000, 100, seed=99))
-        for c in (20, 500, 100, 5):
+        for c, rebuild in ((20, False), (500, True), (100, False), (5, True), (20, False)):
+            # (a call never rebuilds the tables itself; with tables built for another value it bisects from
+            # the counters, and abm_ctx_rebuild_seed_extension is the set-up call that rebuilds them)
+            if rebuild:
+                ctx.rebuild_seed_extension(c)
             p = A.Params(max_candidates=c)
             o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, mode=0, threads=8, max_candidates=c)
             res, cig, off = ctx.map_se(reads, mode=0, params=p)
-            compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"tables rebuilt for -c {c}")
+            compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"-c {c}, tables {'rebuilt' if rebuild else 'of another value: bypassed'}")
         # a second context on the device: a differing max_candidates now runs without tables (nothing is rebuilt under it)
         ctx2 = A.Context(ix, 0)
         try:
@@ -67,6 +71,8 @@ def test_max_candidates_other_than_the_tables(oracle, rep):
             o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, mode=0, threads=8, max_candidates=33)
             res, cig, off = ctx2.map_se(reads, mode=0, params=p)
             compare_se(res, cig, off, o_res, o_cig, o_n, reads, "second context, -c 33, no tables")
+            with pytest.raises(Exception):
+                ctx2.rebuild_seed_extension(33)  # not beside another context
         finally:
             ctx2.close()
     finally:

@@ -148,7 +148,7 @@ struct abm_ctx {
   DevBuf<abm::u64> off2;
   DevBuf<abm::u32> lens, order, class33;
   DevBuf<abm::u32> long_list, long_count, long_ctmp;  // the long-read launch (se_long_reads): listed reads, per-wave scratch
-  DevBuf<abm::u64> packed_long;
+  DevBuf<abm::u64> packed_long, packed_long2, long_q;  // (long_q, packed_long2: the paired-end long-end launch, pe_long_pairs)
   DevBuf<abm::u8> long_tb;
   DevBuf<abm::u8> cls;
   DevBuf<unsigned long long> work;
@@ -525,6 +525,69 @@ void assemble_cigars(uint64_t n, uint32_t stride, const uint32_t *cn, const uint
   parallel_ranges(n, fill);
 }
 
+// The launch for a batch's pairs with an end of kLdsReadLen + 1 .. kMaxReadLen bases (map_pe_kernel<.., LONG>), after
+// tiers 1 and 2 (which treat such a pair as empty): the pairs are listed on the device, the list's length is fetched
+// (the one place the paired-end device entry point waits for the device -- only when the caller announced such ends
+// through max_len), and the list is mapped in rounds, both ends packed into encodings of their own, by one wave per CU
+// with its read data, traceback table, CIGAR scratch and tier 2's lists in global memory.  `main` = tier 2's arguments.
+void pe_long_pairs(abm_ctx *ctx, const abm::PeArgs &main, uint64_t n, const char *d_blob1, const uint64_t *d_off1,
+                   const char *d_blob2, const uint64_t *d_off2, abm::u32 max_len, double valid_frac, hipStream_t st) {
+  ctx->long_list.reserve(n);
+  ctx->long_count.reserve(2);
+  HIPCHK(hipMemsetAsync(ctx->long_count.p, 0, 8, st));
+  HIPCHK(abm::launch_collect_long_pairs(ctx->lens.p, ctx->lens2.p, n, ctx->long_list.p, ctx->long_count.p, st));
+  abm::u32 count = 0;
+  HIPCHK(hipMemcpyAsync(&count, ctx->long_count.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (count == 0) return;
+  const abm::u32 W = words_for(max_len), WB = bitwords_for(max_len);
+  const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : valid_frac;
+  const abm::u32 GW = abm::se_window_words(max_len, size_frac);
+  const abm::u32 cap2 = (max_len + 2 + 1) & ~1u;
+  const int waves = abm::pe_long_resident_waves(GW);
+  if (waves <= 0) throw HipFail("the paired-end long-end launch does not fit on this device (LDS)");
+  const abm::u32 round = 256;  // (a round's packed encodings: 2 x 256 x 4 W words = 32 MB at the longest reads)
+  for (abm::u32 at = 0; at < count; at += round) {
+    const abm::u32 m = std::min(round, count - at);
+    const abm::u32 grid = std::min<abm::u32>(m, static_cast<abm::u32>(waves));
+    const size_t cap = abm::kPeCapLarge;
+    ctx->packed_long.reserve(static_cast<size_t>(m) * 4 * W);
+    ctx->packed_long2.reserve(static_cast<size_t>(m) * 4 * W);
+    ctx->long_q.reserve(static_cast<size_t>(grid) * abm::pe_long_q_words(W, WB));
+    ctx->long_tb.reserve(static_cast<size_t>(grid) * abm::se_long_tb_bytes(max_len));
+    ctx->long_ctmp.reserve(static_cast<size_t>(grid) * cap2);
+    ctx->payload2.reserve(static_cast<size_t>(grid) * cap);
+    ctx->list2.reserve(static_cast<size_t>(grid) * 4 * cap);
+    ctx->heap2.reserve(static_cast<size_t>(grid) * cap);
+    ctx->log2.reserve(static_cast<size_t>(grid) * (32 + 12 * cap));
+    HIPCHK(abm::launch_pack_listed(d_blob1, reinterpret_cast<const abm::u64 *>(d_off1), ctx->long_list.p + at, m, W, ctx->packed_long.p, st));
+    HIPCHK(abm::launch_pack_listed(d_blob2, reinterpret_cast<const abm::u64 *>(d_off2), ctx->long_list.p + at, m, W, ctx->packed_long2.p, st));
+    abm::PeArgs a = main;
+    a.packed1 = ctx->packed_long.p; a.packed2 = ctx->packed_long2.p;
+    a.order = nullptr;
+    a.subset = ctx->long_list.p + at;
+    HIPCHK(hipMemcpyAsync(ctx->long_count.p + 1, &m, 4, hipMemcpyHostToDevice, st));  // (pageable source: copied before the call returns)
+    a.subset_count = ctx->long_count.p + 1;
+    a.W = W; a.WB = WB; a.GW = GW;
+    a.max_len = max_len;
+    a.tb_extra = 0;
+    a.G = 0;
+    a.ctmp_cap = max_len + 2;
+    a.cap = static_cast<abm::u32>(cap);
+    a.log_ws = ctx->log2.p; a.heap_ws = ctx->heap2.p; a.payload_ws = ctx->payload2.p; a.list_ws = ctx->list2.p;
+    a.long_q = ctx->long_q.p;
+    a.long_tb = ctx->long_tb.p;
+    a.long_ctmp = ctx->long_ctmp.p;
+    a.long_tb_bytes = abm::se_long_tb_bytes(max_len);
+    a.pair_diag = nullptr;
+    unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    a.next_read = counter;
+    HIPCHK(abm::launch_map_pe_long(a, grid, st));
+    HIPCHK(hipStreamSynchronize(st));  // (the next round reuses the packed encodings and the count word)
+  }
+}
+
 void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, const char *d_blob1,
                const uint64_t *d_off1, const char *d_blob2, const uint64_t *d_off2, uint32_t max_len,
                abm_pair *d_pair, abm_hit *d_se1, abm_hit *d_se2, uint32_t *d_cig1, uint32_t *d_cig2,
@@ -632,6 +695,8 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, ctx->phase_stamps, wps, st));
     if (e1) HIPCHK(hipEventRecord(e1, st));
   }
+  if (max_len > abm::kLdsReadLen)
+    pe_long_pairs(ctx, a, n, d_blob1, d_off1, d_blob2, d_off2, std::min<abm::u32>(max_len, abm::kMaxReadLen), params->valid_frac, st);
   HIPCHK(hipEventRecord(ctx->last_done, st));
 }
 
@@ -900,7 +965,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->rep->arena = nullptr;
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -1252,9 +1317,9 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
     const hipStream_t st = ctx->stream;
     const OffsetScan scan1 = scan_offsets(seq_off1, n, ctx->h_rel), scan2 = scan_offsets(seq_off2, n, ctx->h_rel2);
     const uint32_t max_len = std::max(scan1.max_len, scan2.max_len);
-    if (max_len > abm::kLdsReadLen) {  // (pairs with an end beyond the paired-end kernels' cap: counted once; rare, so a plain pass)
+    if (max_len > abm::kMaxReadLen) {  // (pairs with an end beyond what is mapped at all: counted once; rare, so a plain pass)
       for (uint64_t i = 0; i < n; ++i)
-        ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kLdsReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kLdsReadLen;
+        ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kMaxReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kMaxReadLen;
     }
     abm_pair *d_pair = nullptr;
     abm_hit *d_se1 = nullptr, *d_se2 = nullptr;

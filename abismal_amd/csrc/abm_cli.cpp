@@ -668,7 +668,7 @@ struct Options {
   size_t batch = 0;  // reads (pairs) per batch; 0 = default for the input type
   int mappers = 0;  // mapper threads (contexts) per GPU; 0 = 2 for single-end, 3 for paired-end input
   int ext2 = -1, ext3 = -1;  // -seed-ext a,b: letters of the seed-extension tables (default: chosen from the index's size)
-  bool skip_long = false;     // -skip-long: pairs with an end beyond the paired-end kernels' 1024 bases are written unmapped
+  bool skip_long = false;     // -skip-long: reads the library reports as beyond its supported length are written unmapped
                               // (and counted in the warning) instead of failing the run
   bool host_ceiling = false;  // -host-ceiling / -virtual-gpus N (diagnostic): no device and no mapping call; every "GPU" hands
                               // back made-up hits at once, so that count -> cut -> parse -> deal -> format -> write run at the
@@ -2215,15 +2215,14 @@ int cmd_map(int argc, char **argv) {
   if (opt.verbose)
     for (int g = 0; g < n_gpus; ++g)
       std::cerr << "[abismal-amd] GPU " << g << (virtual_gpus ? " (virtual)" : "") << ": " << gpu_batches[g] << " batches, " << gpu_reads[g] << (paired ? " pairs\n" : " reads\n");
-  // Single-end reads of any length the reference takes are mapped (longer ones stop the run while the input is parsed,
-  // with the reference's message).  Pairs: the paired-end kernels take ends of up to 1024 bases; a pair with a longer end
-  // was written unmapped, which the reference would not have done -- so the run fails unless -skip-long accepts it.
+  // Reads (and ends of pairs) of any length the reference takes are mapped; longer ones stop the run while the input is
+  // parsed, with the reference's message -- so the library's count of reads beyond its supported length stays zero here
+  // (kept as a safeguard: a non-zero count fails the run unless -skip-long accepts it).
   uint64_t too_long = 0;
   for (abm_ctx *c : ctxs) too_long += abm_ctx_reads_too_long(c);
   if (too_long)
-    std::cerr << "[abismal-amd] " << (opt.skip_long ? "warning: " : "error: ") << too_long << (paired ? " pairs with an end longer than 1024 bases"
-                                                                                                       : " reads beyond the supported length")
-              << " were not mapped (written as unmapped" << (opt.skip_long ? ")\n" : "); -skip-long accepts this\n");
+    std::cerr << "[abismal-amd] " << (opt.skip_long ? "warning: " : "error: ") << too_long << (paired ? " pairs" : " reads")
+              << " beyond the supported read length were not mapped (written as unmapped" << (opt.skip_long ? ")\n" : "); -skip-long accepts this\n");
   for (abm_ctx *c : ctxs) abm_ctx_destroy(c);
   abm_index_close(ix);
   return too_long && !opt.skip_long ? EXIT_FAILURE : EXIT_SUCCESS;

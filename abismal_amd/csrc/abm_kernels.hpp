@@ -80,6 +80,13 @@ struct PeArgs {
   u32 *log_ws;                   // tier 2: [grid][32 + 12 cap] lists kept for a deferred best_single
   u32 cap;
   u32 *pair_diag;                // optional [n], diagnostic kernel only: largest set << 16 | shader cycles >> 20
+  // the long-end launch only (pairs with an end of kLdsReadLen + 1 .. kMaxReadLen bases, listed in `subset`, packed by
+  // list position): per wave, both ends' encodings and bit strings (pe_long_q_words u64), a traceback table
+  // (long_tb_bytes) and CIGAR scratch (ctmp_cap rounded up to even), all in global memory
+  u64 *long_q;
+  u8 *long_tb;
+  u32 *long_ctmp;
+  u64 long_tb_bytes;
 };
 
 // bytes the traceback table needs beyond the LDS it overlays (genome-window slots 1.. and the
@@ -89,6 +96,11 @@ size_t pe_lds_bytes(u32 W, u32 WB, u32 GW, u32 cig_stride, u32 max_len, double v
 int pe_waves_per_simd(size_t lds, bool timed, bool coop);  // which build of the pair kernels a launch with this much LDS per wave takes
 int pe_resident_waves(size_t lds, bool big, int wps);
 hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, int wps, hipStream_t st);
+hipError_t launch_collect_long_pairs(const u32 *d_lens1, const u32 *d_lens2, u64 n, u32 *d_list, u32 *d_count, hipStream_t st);
+size_t pe_long_lds_bytes(u32 GW);
+size_t pe_long_q_words(u32 W, u32 WB);
+int pe_long_resident_waves(u32 GW);
+hipError_t launch_map_pe_long(const PeArgs &a, u32 grid, hipStream_t st);
 hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *class33, u32 *subset, u32 *count,
                               hipStream_t st);
 #ifndef ABM_PE_TIER1_CAP

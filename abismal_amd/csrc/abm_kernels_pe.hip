@@ -52,7 +52,12 @@ struct PairBest {
 
 // COOP: the seed passes filter on the genome's bit planes with cooperative window loads (hamming_planes), as the
 // single-end kernel does; otherwise one lane per window on the nibble array (genomes with IUPAC letters, reads > 448)
-template <bool BIG, bool COOP> struct PeWave {
+// LONG: the launch for pairs with an end beyond kLdsReadLen bases (up to kMaxReadLen), as map_se_long_kernel is for
+// single-end reads: both ends' packed encodings and bit strings lie in a per-wave piece of global memory (two ends of
+// 32766 bases are 164 KB: more than a CU's LDS), so do every traceback table ((L + 61) x 61 bytes) and the CIGAR scratch;
+// bands are up to 61 lanes wide (two window slots), the filter runs on the nibble array, scores wrap at 16 bits like the
+// reference's score_t, and the lists are tier 2's (global memory).
+template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
   const PeArgs &a;
   WaveLds lds;      // qpk/qbits point at end 0; end 1 follows at +4W / +4WB
   PeLds pl;
@@ -184,7 +189,7 @@ template <bool BIG, bool COOP> struct PeWave {
       // window slots and the window cache are idle here); only distances >= C touch global memory.
       u32 *blk = reinterpret_cast<u32 *>(lds.gwin);
       int C = 256;
-      while (2 * C <= static_cast<int>(2 * (kMaxJobs * lds.GW + (1u << kPosCacheBits))) && 2 * C <= m) C <<= 1;
+      while (2 * C <= static_cast<int>(2 * (lds.max_jobs * lds.GW + (1u << kPosCacheBits))) && 2 * C <= m) C <<= 1;
       if (C > m) C = m;
       auto local = [&](int k_from, int k_to, int j_top) {  // stages k_from..k_to, distances j_top..1, block by block
         for (int b = 0; b < m; b += C) {
@@ -289,7 +294,7 @@ template <bool BIG, bool COOP> struct PeWave {
         if (n_jobs == 0) break;
         for (int s = 0; s < n_jobs;) {  // rounds of side-by-side bands
           const int first = s;
-          s = score_jobs(a.ix, lds, first, n_jobs, static_cast<int>(len_of(end)), md, static_cast<int>(end * 4 * lds.W));
+          s = score_jobs<LONG>(a.ix, lds, first, n_jobs, static_cast<int>(len_of(end)), md, static_cast<int>(end * 4 * lds.W));
           if (lane < s - first) pl.lsc[which][pl.jidx[first + lane]] = static_cast<i16>(lds.lbest[lane]);
           n_aln += static_cast<u32>(s - first);
           wave_sync();
@@ -326,8 +331,8 @@ template <bool BIG, bool COOP> struct PeWave {
       stage_windows(a.ix, lds, 0, 1, md);
       wave_sync();
       int bv, brow;
-      if constexpr (kTracebackByRows) wavefront_rows<true>(lds, job, Ln, bw, bv, brow);
-      else wavefront<true>(lds, job, Ln, bw, bw, bv, brow);
+      if constexpr (LONG || !kTracebackByRows) wavefront<true, LONG>(lds, job, Ln, bw, bw, bv, brow);
+      else wavefront_rows<true>(lds, job, Ln, bw, bv, brow);
       const u64 k64 = (static_cast<u64>(static_cast<u32>(bv)) << 32) |
                       (static_cast<u64>(0xFFFFu - static_cast<u32>(brow)) << 8) |
                       static_cast<u64>(0xFFu - static_cast<u32>(lane));
@@ -570,23 +575,41 @@ template <bool BIG, bool COOP> struct PeWave {
   }
 };
 
-template <bool BIG, bool TIMED, bool COOP, int WPS>
+template <bool BIG, bool TIMED, bool COOP, int WPS, bool LONG = false>
 __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
+  static_assert(!LONG || (BIG && !COOP && !TIMED), "the long-end launch: tier 2's lists, nibble filter, no stamps");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  PeWave<BIG, COOP> w{a};
+  PeWave<BIG, COOP, LONG> w{a};
   WaveLds &lds = w.lds;
   lds.W = a.W; lds.WB = a.WB; lds.GW = a.GW;
-  lds.qpk = reinterpret_cast<u64 *>(smem);
-  lds.qbits = lds.qpk + 8 * a.W;
-  lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
-  lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
-  lds.gwin = lds.qmask + 8 * lds.MB * 4;
-  lds.pcache = lds.gwin + kMaxJobs * a.GW;
-  // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
-  lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
-  lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
-  lds.jpos = lds.ctmp + a.ctmp_cap;
+  if constexpr (LONG) {
+    // read data in this wave's piece of global memory; LDS holds the two window slots, the cache and the job lists
+    u64 *q = a.long_q + static_cast<u64>(blockIdx.x) * (8ull * a.W + 8ull * a.WB);
+    lds.qpk = q;
+    lds.qbits = q + 8 * a.W;
+    lds.MB = 0;
+    lds.qmask = nullptr;
+    lds.gwin = reinterpret_cast<u64 *>(smem);
+    lds.max_jobs = 2;
+    lds.pcache = lds.gwin + 2 * a.GW;
+    lds.tb = a.long_tb + static_cast<u64>(blockIdx.x) * a.long_tb_bytes;
+    lds.ctmp = a.long_ctmp + static_cast<u64>(blockIdx.x) * ((a.ctmp_cap + 1) & ~1u);
+    lds.jpos = reinterpret_cast<u32 *>(lds.pcache + (1u << kPosCacheBits));
+  }
+  else {
+    lds.qpk = reinterpret_cast<u64 *>(smem);
+    lds.qbits = lds.qpk + 8 * a.W;
+    lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
+    lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
+    lds.gwin = lds.qmask + 8 * lds.MB * 4;
+    lds.max_jobs = kMaxJobs;
+    lds.pcache = lds.gwin + kMaxJobs * a.GW;
+    // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
+    lds.tb = reinterpret_cast<u8 *>(lds.gwin + a.GW);
+    lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
+    lds.jpos = lds.ctmp + a.ctmp_cap;
+  }
   lds.jdf = lds.jpos + kSeCap;
   w.pl.jidx = lds.jdf + kSeCap;
   lds.lbest = reinterpret_cast<int *>(w.pl.jidx + kSeCap);
@@ -613,7 +636,6 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   lds.mark = reinterpret_cast<u16 *>(after_heap + 256);
   lds.hres = reinterpret_cast<u16 *>(lds.lbest);
   lds.G = a.G;
-  lds.max_jobs = kMaxJobs;
   lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
   w.seg_epoch = 0;
 
@@ -645,11 +667,13 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     const u64 r = BIG ? static_cast<u64>(a.subset[it]) : (a.order ? static_cast<u64>(a.order[it]) : it);
     w.L[0] = a.lens1[r];
     w.L[1] = a.lens2[r];
-    if (w.L[0] > kLdsReadLen || w.L[1] > kLdsReadLen) { too_long = true; w.L[0] = w.L[1] = 0; }  // (pairs: no long-read launch)
-    // stage both ends' four encodings and their 2-letter bit strings
+    if (w.L[0] > kMaxReadLen || w.L[1] > kMaxReadLen) { too_long = true; w.L[0] = w.L[1] = 0; }
+    // (a pair with an end beyond this launch's length is the long-end launch's: it overwrites what is stored for it here)
+    if (!LONG && (w.L[0] > kLdsReadLen || w.L[1] > kLdsReadLen)) w.L[0] = w.L[1] = 0;
+    // stage both ends' four encodings and their 2-letter bit strings (LONG: packed by list position)
     #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const u64 *src = (e ? a.packed2 : a.packed1) + r * 4 * a.W;
+      const u64 *src = (e ? a.packed2 : a.packed1) + (LONG ? it : r) * 4 * a.W;
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[e * 4 * a.W + k] = src[k];
     }
     wave_sync();
@@ -720,8 +744,8 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
         u32 nops = 0;
         Hit &h = e ? h2 : h1;
         u32 n_single = 0;
-        choose_se(a.ix, we, w.L[e], a.valid_frac / 2, w.se[e], h, w.cig_of(e, r), w.sink(), nops,
-                  w.overflow, w.n_aln, n_single);
+        choose_se<LONG>(a.ix, we, w.L[e], a.valid_frac / 2, w.se[e], h, w.cig_of(e, r), w.sink(), nops,
+                        w.overflow, w.n_aln, n_single);
         if (nops != 0) w.n_ops[e] = nops;  // whatever traceback ran last owns the slot (A.10)
       }
       ABM_STAMP(tf1);
@@ -855,6 +879,38 @@ hipError_t launch_map_pe(const PeArgs &a, size_t lds, u32 grid, bool big, bool t
   else if (big) launch_pe_variant<true, false>(a, lds, grid, wps, st);
   else if (timed) launch_pe_variant<false, true>(a, lds, grid, wps, st);
   else launch_pe_variant<false, false>(a, lds, grid, wps, st);
+  return hipGetLastError();
+}
+
+// ---- the long-end launch --------------------------------------------------------------------------------------
+// pairs of this batch with an end of kLdsReadLen + 1 .. kMaxReadLen bases
+__global__ __launch_bounds__(256) void collect_long_pairs_kernel(const u32 *__restrict__ lens1, const u32 *__restrict__ lens2, u64 n,
+                                                                 u32 *__restrict__ list, u32 *__restrict__ count) {
+  const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const u32 a = lens1[r], b = lens2[r];
+  if ((a > kLdsReadLen || b > kLdsReadLen) && a <= kMaxReadLen && b <= kMaxReadLen) list[atomicAdd(count, 1u)] = static_cast<u32>(r);
+}
+hipError_t launch_collect_long_pairs(const u32 *d_lens1, const u32 *d_lens2, u64 n, u32 *d_list, u32 *d_count, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(collect_long_pairs_kernel, dim3(static_cast<u32>((n + 255) / 256)), dim3(256), 0, st, d_lens1, d_lens2, n, d_list, d_count);
+  return hipGetLastError();
+}
+size_t pe_long_lds_bytes(u32 GW) {
+  const size_t b = static_cast<size_t>(2) * GW * 8 + (static_cast<size_t>(8) << kPosCacheBits) + 3 * kSeCap * 4 + 64 * 4 + 2 * 128 * 4 + 64 * 2;
+  return (b + 15) & ~static_cast<size_t>(15);
+}
+size_t pe_long_q_words(u32 W, u32 WB) { return 8ull * W + 8ull * WB; }
+int pe_long_resident_waves(u32 GW) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_pe_kernel<true, false, false, 1, true>, 64, pe_long_lds_bytes(GW)) != hipSuccess) return 0;
+  return std::min(per_cu, 1) * prop.multiProcessorCount;  // (one wave per CU: each has megabytes of workspace in global memory)
+}
+hipError_t launch_map_pe_long(const PeArgs &a, u32 grid, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL((map_pe_kernel<true, false, false, 1, true>), dim3(grid), dim3(64), pe_long_lds_bytes(a.GW), st, a);
   return hipGetLastError();
 }
 

@@ -199,16 +199,17 @@ int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint
 
 enum {
   ABM_STATUS_CIGAR_OVERFLOW = 1u, /* the arena for CIGARs longer than a slot ran out */
-  ABM_STATUS_READ_TOO_LONG = 2u,  /* a read exceeded abm_max_read_length() (a pair's end: 1024 bases) */
+  ABM_STATUS_READ_TOO_LONG = 2u,  /* a read (or an end of a pair) exceeded abm_max_read_length() */
   ABM_STATUS_SET_OVERFLOW = 4u    /* PE candidate set outgrew its workspace */
 };
-/* Longest single-end read that is mapped: 32766 bases, the reference's own limit (ReadLoader refuses reads of 32767
- * bases or more, src/abismal.cpp:179-185).  Reads of up to 1024 bases are mapped by a batch's main launch; longer ones
- * by a launch of their own (traceback table in global memory; the device entry point then waits once for the device,
- * to learn how many there are).  Paired-end batches take ends of up to 1024 bases. */
+/* Longest read (single-end, or end of a pair) that is mapped: 32766 bases, the reference's own limit (ReadLoader refuses
+ * reads of 32767 bases or more, src/abismal.cpp:179-185).  Reads of up to 1024 bases are mapped by a batch's main
+ * launch; longer ones -- and pairs with such an end -- by a launch of their own afterwards (traceback tables, and for
+ * pairs the read data too, in global memory; the device entry point then waits once for the device, to learn how many
+ * there are). */
 uint32_t abm_max_read_length(void);
-/* Reads beyond abm_max_read_length() -- and pairs with an end beyond 1024 bases -- handed to this context's host entry
- * points so far: they come back without a hit, everything else in their batch is mapped as usual. */
+/* Reads (pairs with an end) beyond abm_max_read_length() handed to this context's host entry points so far: they come
+ * back without a hit, everything else in their batch is mapped as usual. */
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx);
 
 /* Which form of the genome the Hamming filter of this context's device reads for batches of reads up to 448 bases:

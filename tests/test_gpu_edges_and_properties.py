@@ -123,17 +123,50 @@ def test_reads_beyond_16383_bases(ctx, oracle, trex_index):
     assert ctx.reads_too_long() - before == 1 and res["pos"][1] == 0 and res["pos"][0] == res["pos"][2] != 0
 
 
-def test_pairs_with_a_long_end(ctx, oracle, trex_index):
-    """The paired-end kernels take ends of up to 1024 bases; a pair with a longer end comes back unmapped and counted
-    (the CLI then exits non-zero unless told -skip-long), the rest of its batch is unaffected."""
-    reads = _reads_from_genome(trex_index, [150, 150, 1500, 150], seed=11)
+def _pairs_from_genome(trex_index, shapes, seed, indel_every=2500):
+    """(len1, len2, fragment) triples -> (reads1, reads2): read 1 = the first len1 bases of a converted, mutated fragment,
+    read 2 = the reverse complement of its last len2 bases (what `sim` makes, src/simreads.cpp:113-133)."""
     comp = bytes.maketrans(b"ACGT", b"TGCA")
-    r1 = reads
-    r2 = [r.encode().translate(comp)[::-1].decode() for r in reads]
+    frags = _reads_from_genome(trex_index, [f for _, _, f in shapes], seed=seed, indel_every=indel_every)
+    r1 = [fr[:a] for fr, (a, _, _) in zip(frags, shapes)]
+    r2 = [fr[len(fr) - b:].encode().translate(comp)[::-1].decode() for fr, (_, b, _) in zip(frags, shapes)]
+    return r1, r2
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_pairs_with_a_long_end(ctx, oracle, trex_index, mode):
+    """Pairs whose ends are longer than the pair kernels' 1024 bases (up to the reference's own limit, 32766,
+    src/abismal.cpp:179-185) map like any other -- in a launch of their own after the batch's two tiers, with the read
+    data and the traceback tables in global memory and 16-bit scores like the reference's (src/AbismalAlign.hpp:35) --
+    mixed freely with ordinary pairs: pair, both fallback hits and both CIGARs equal the oracle's in the three
+    paired-end modes (normal, PBAT, random PBAT)."""
+    import abismal_amd as A
+    from tests.test_gpu_pe_parity import compare_pe
+    shapes = [(150, 150, 400), (1500, 150, 1700), (150, 1500, 1650), (100, 100, 300), (1025, 1025, 1300), (5000, 5000, 6000),
+              (2000, 3000, 4000), (150, 150, 500), (20000, 300, 20400), (17000, 17000, 18000), (1024, 1024, 1500), (10000, 64, 10100)]
+    r1, r2 = _pairs_from_genome(trex_index, shapes, seed=31)
+    if mode == 1:    # PBAT: read 1 is the A-rich one
+        r1, r2 = r2, r1
+    elif mode == 2:  # random PBAT: either
+        r1, r2 = [a if k % 2 else b for k, (a, b) in enumerate(zip(r1, r2))], [b if k % 2 else a for k, (a, b) in enumerate(zip(r1, r2))]
+    p = A.Params(max_frag=40000)
     before = ctx.reads_too_long()
-    pairs, se1, se2, _, _ = ctx.map_pe(r1, r2)
-    assert ctx.reads_too_long() - before == 1
-    assert pairs["r1"]["pos"][2] == 0 and se1["pos"][2] == 0 and se2["pos"][2] == 0
+    gpu = ctx.map_pe(r1, r2, mode=mode, params=p)
+    assert ctx.reads_too_long() == before
+    oix = oracle.index_load(trex_index)
+    try:
+        orc = oracle.map_pe(oix, r1, r2, mode=mode, max_frag=40000, threads=8)
+    finally:
+        oracle.index_free(oix)
+    compare_pe(gpu, orc, f"pairs with long ends, mode {mode}")
+    mapped = gpu[0]["r1"]["pos"] != 0
+    long_ones = [k for k, (a, b, _) in enumerate(shapes) if max(a, b) > 1024]
+    assert sum(bool(mapped[k]) for k in long_ones) >= len(long_ones) - 2, "the fixture's long pairs must map concordantly"
+    # an end beyond the reference's limit: unmapped, counted, the rest of the batch unaffected
+    too = ["ACGT" * 8192 + "AC"]  # 32770 bases
+    gpu2 = ctx.map_pe(r1[:2] + too, r2[:2] + [r2[0]], mode=mode, params=p)
+    assert ctx.reads_too_long() == before + 1 and gpu2[0]["r1"]["pos"][2] == 0
+    assert gpu2[0]["r1"]["pos"][0] == gpu[0]["r1"]["pos"][0] and gpu2[0]["r1"]["pos"][1] == gpu[0]["r1"]["pos"][1]
 
 
 def test_unseedable_and_ragged_inputs(ctx, oracle, trex_index, reads):

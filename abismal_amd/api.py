@@ -325,7 +325,7 @@ class Context:
         """paired-end tallies per tier (see include/abismal_amd.h)"""
         out = (C.c_uint64 * 32)()
         _check(self._lib.abm_ctx_take_work_tiers(self.handle, out))
-        keys = ["seed_offsets", "search_probes", "candidates", "read_words", "set_updates", "alignments",
+        keys = ["seed_offsets", "search_probes", "candidates", "index_run_lines", "set_updates", "alignments",
                 "cyc_probe_narrow", "cyc_gather_hamming", "cyc_replay", "cyc_se_fallback", "cyc_total",
                 "window_cache_hits", "cyc_sort_unique", "cyc_score_pairable", "cyc_mate", "cyc_best_single"]
         return [dict(zip(keys, [int(x) for x in out[16 * t:16 * t + 16]])) for t in range(2)]

@@ -908,6 +908,12 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     sg.nb = chk3 ? hi3 - lo3 : 0u;
     sg.lo2 = lo2;
     sg.lo3 = lo3;
+    if constexpr (TALLY && Set::kAppend) {
+      // pair kernels: the 128-byte lines the checked buckets' index-entry runs span (32 entries a line) -- their share of a
+      // pair's line requests (DESIGN 4.3's table); the words of the fetched windows follow from the candidate count
+      if (sg.na) wt.words += ((lo2 + sg.na - 1) >> 5) - (lo2 >> 5) + 1;
+      if (sg.nb) wt.words += ((lo3 + sg.nb - 1) >> 5) - (lo3 >> 5) + 1;
+    }
     u32 total;
     sg.start_a = wave_excl_sum(sg.na + sg.nb, total);
     ABM_STAMP(tb_);
@@ -1013,7 +1019,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       // 8-byte words fetched per window: the read's words on the nibble array; on the bit planes a group of four
       // lanes fetches four 16-byte blocks, a group of eight the blocks its window has (at most L / 64 + 2)
       const u32 fetched = COOP ? (lds.G == 2 ? 6u : (lds.G == 4 ? 8u : 2u * ((L + kPlaneBlock - 1) / kPlaneBlock + 1))) : nwords;
-      wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * fetched;
+      if constexpr (!Set::kAppend) wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * fetched;
       wt.cache_hits += (hit_a ? 1u : 0u) + (hit_b ? 1u : 0u);
       }
       ABM_STAMP(td);

@@ -447,6 +447,27 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     use = s_bytes if s_bytes is not None else k_bytes
     achieved = use * done_pairs / elapsed / 1e9
     pe_traffic, pe_traffic_source = lookup_traffic("pe", int(args.genome_mbp), n, L)  # per step: tier 1 + tier 2 launches
+    # 128-byte lines a pair asks for, by source, from the kernels' own tallies (both tiers; a pair redone by tier 2 counts
+    # in both): what each item costs at line granularity -- a fetched candidate window is one line (two copies of the bit
+    # planes keep it inside one), a seed offset two (its two seed-extension entries, or two counter pairs), a narrowing
+    # probe two (index entry + genome letter), the index-entry runs what they span, an alignment its window
+    # ((L + band) / 2 bytes at a random offset) -- against the counters' total when a PMC pass is on file
+    per_aln = ((L + bw_band) / 2 + 127) // 128 + 1
+    lines_by_source = {"candidate_windows": fetched / done_pairs, "seed_offset_lookups": 2 * tw["seed_offsets"] / done_pairs,
+                       "narrowing_probes": 2 * tw["search_probes"] / done_pairs, "index_entry_runs": tw["index_run_lines"] / done_pairs,
+                       "alignment_windows": per_aln * tw["alignments"] / done_pairs, "reads_in_results_out": 2 * ((4 * nw * 8 + 127) // 128) + 2}
+    lines_by_source = {k: round(v, 1) for k, v in lines_by_source.items()}
+    lines_by_source["accounted"] = round(sum(lines_by_source.values()), 1)
+    if pe_traffic:
+        lines_by_source["counters_total"] = round(pe_traffic / 128 / n, 1)
+        lines_by_source["not_accounted"] = round(lines_by_source["counters_total"] - lines_by_source["accounted"], 1)
+        lines_by_source["not_accounted_is"] = ("tier 2's lists, heap, sort buffer and best_single log in global memory (per-wave, touched by one wave), the "
+                                               "hand-off arrays, second lines of windows / entry pairs that straddle one, minus whatever the L2s served")
+    tier_lines = [{k: round(v / done_pairs, 1) for k, v in (("candidate_windows", tier_work[t].get("candidates", 0) - tier_work[t].get("window_cache_hits", 0)),
+                                                            ("seed_offset_lookups", 2 * tier_work[t].get("seed_offsets", 0)),
+                                                            ("narrowing_probes", 2 * tier_work[t].get("search_probes", 0)),
+                                                            ("index_entry_runs", tier_work[t].get("index_run_lines", 0)),
+                                                            ("alignment_windows", per_aln * tier_work[t].get("alignments", 0)))} for t in range(2)]
     roofline = {"bound": "hbm", "kernel": "map_pe_kernel (tier 1 + tier 2)", "achieved": round(achieved, 2), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "basis": "strict" if s_bytes is not None else "kernel_tally",
                 "alg_bytes_per_pair_strict": round(s_bytes, 1) if s_bytes is not None else None,
@@ -455,6 +476,8 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                 "denominator": "wall time of the timed region (kernels of %d slots overlap)" % len(slots),
                 "tier1_ms_per_launch": round(sum(tier_ms[0]) / max(1, len(tier_ms[0])), 2),
                 "tier2_ms_per_launch": round(sum(tier_ms[1]) / max(1, len(tier_ms[1])), 2),
+                "lines_per_pair_by_source": lines_by_source, "lines_per_pair_by_source_tier1": tier_lines[0],
+                "lines_per_pair_by_source_tier2": tier_lines[1],
                 "traffic": pe_traffic, "traffic_source": pe_traffic_source,
                 "traffic_over_algorithmic": round(pe_traffic / (use * n), 2) if pe_traffic else None,
                 "work_per_pair": {k: round(v / done_pairs, 2) for k, v in tw.items() if not k.startswith("cyc_")},

@@ -231,7 +231,8 @@ int abm_ctx_take_work(abm_ctx *ctx, uint64_t out[16]);
 int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable);
 /* Paired-end runs keep separate tallies per tier: out[0..15] tier 1 (sets of up
  * up to 256 entries), out[16..31] tier 2 (the pairs redone with 32768-entry
- * sets); take_work returns their sum.  With phase stamps the paired-end kernel
+ * sets); take_work returns their sum.  In the paired-end tallies [3] is the number of 128-byte lines the checked
+ * buckets' index-entry runs span (the fetched windows' words follow from [2] and [11]).  With phase stamps the paired-end kernel
  * fills [6] probe+narrow, [7] gather+Hamming, [8] replay, [9] single-end
  * fallback, [10] total, [12] sort+unique, [13] pairable-entry alignments,
  * [14] mating + tracebacks, [15] best_single replay. */

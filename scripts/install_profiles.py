@@ -3,6 +3,14 @@ import csv, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst, rnd = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles"), int(sys.argv[1]) if len(sys.argv) > 1 else 1
 tag = f"r{rnd:02d}"
+# the build the profile was taken on (scripts/r04_profile.sh copies BUILD_ID, written when the call was launched) must be
+# HEAD's as far as the kernels and the bench go: a README generated from an older build misleads whoever reads it
+build = "n/a"
+bpath = os.path.join(src, "build.txt")
+if os.path.exists(bpath):
+    build = open(bpath).read().strip()
+    if os.system(f"git -C {root} diff --quiet {build} HEAD -- abismal_amd/csrc bench.py") != 0 and "--force" not in sys.argv:
+        raise SystemExit(f"profile was taken on build {build}, HEAD differs in abismal_amd/csrc or bench.py: profile again (or --force)")
 def json_line(path):
     for ln in open(path):
         if ln.startswith('{"metric"'):
@@ -26,15 +34,63 @@ pmc_line = json_line(os.path.join(src, "bench_line_under_pmc.log"))
 wl = line["config"]
 nbytes = cnt["TCC_EA0_RDREQ_128B_sum"] * 128 + cnt["TCC_EA0_RDREQ_64B_sum"] * 64 + cnt["TCC_EA0_RDREQ_32B_sum"] * 32
 traffic = {"round": rnd, "kernel": "map_se_kernel",
-           "workload": {"genome_mbp": 3100, "reads": wl["reads_per_step_per_gpu"], "read_len": wl["read_len"]},
+           "workload": {"kind": "se_trich", "genome_mbp": 3100, "reads": wl["reads_per_step_per_gpu"], "read_len": wl["read_len"]},
            "counters": cnt, "hbm_read_bytes_per_launch": nbytes, "kernel_seconds_under_pmc": secs,
-           "build": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % root).read().strip() or "n/a",
+           "build": build,
            "note": "rocprofv3 --pmc TCC_EA0_RDREQ_{,32B,64B,128B}_sum in a pass of its own over `python3 bench.py --steps 1 "
                    "--warmup 0 --no-cpu-baseline` (scripts/profile_round.sh; rows in %s_pmc_rdreq_map_se.csv). Essentially every "
                    "L2->HBM read request of this kernel is a 128-B line; an earlier FETCH_SIZE pass reported requests x 64 B, "
                    "i.e. exactly half, as MI355X_MICROARCH.md says for gfx950. Write traffic is negligible (8 B + CIGAR slot "
                    "per read).  TCC_EA0_RDREQ counts Infinity-Cache hits as well: fabric-side requests, an upper bound on HBM bytes." % tag}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+# the other configurations' passes (scripts/r04_profile.sh): paired-end (both tiers of one step) and 150 bp random PBAT
+def sum_rows(path, want):
+    acc, secs, seen = {}, 0.0, set()
+    for row in csv.reader(open(path)):
+        r = dict(zip(hdr, row))
+        if not want(r["Kernel_Name"]):
+            continue
+        acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0) + int(float(r["Counter_Value"]))
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            secs += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    return acc, secs
+extra = {}
+pe_csv = os.path.join(src, "pmc_rdreq_map_pe.csv")
+if os.path.exists(pe_csv):
+    shutil.copy(pe_csv, os.path.join(dst, f"{tag}_pmc_rdreq_map_pe.csv"))
+    tiers = {}
+    for name, want in (("tier1", lambda k: "map_pe_kernel<false" in k), ("tier2", lambda k: "map_pe_kernel<true" in k)):
+        acc, secs_t = sum_rows(pe_csv, want)
+        tiers[name] = {"counters": acc, "kernel_seconds_under_pmc": round(secs_t, 4),
+                       "bytes": acc.get("TCC_EA0_RDREQ_128B_sum", 0) * 128 + acc.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + acc.get("TCC_EA0_RDREQ_32B_sum", 0) * 32}
+    wr_csv = os.path.join(src, "pmc_wrreq_map_pe.csv")
+    if os.path.exists(wr_csv):
+        shutil.copy(wr_csv, os.path.join(dst, f"{tag}_pmc_wrreq_map_pe.csv"))
+        for name, want in (("tier1", lambda k: "map_pe_kernel<false" in k), ("tier2", lambda k: "map_pe_kernel<true" in k)):
+            tiers[name]["write_side_counters"] = sum_rows(wr_csv, want)[0]
+    pe_bytes = tiers["tier1"]["bytes"] + tiers["tier2"]["bytes"]
+    extra["pe"] = {"round": rnd, "kernel": "map_pe_kernel (tier 1 + tier 2, one step)",
+                   "workload": {"kind": "pe", "genome_mbp": 3100, "reads": 1000000, "read_len": 150}, "tiers": tiers,
+                   "hbm_read_bytes_per_launch": pe_bytes, "lines_per_pair": pe_bytes / 128 / 1e6, "build": build,
+                   "note": "rocprofv3 --pmc TCC_EA0_RDREQ_* in a pass of its own over `python3 bench.py --pe --reads 1000000 --read-len 150 --steps 1 "
+                           "--warmup 0 --streams 1` (scripts/r04_profile.sh); per step = one tier-1 launch + one tier-2 launch"}
+    json.dump(extra["pe"], open(os.path.join(dst, f"{tag}_traffic_pe.json"), "w"), indent=1)
+r_csv = os.path.join(src, "pmc_rdreq_map_se_r150.csv")
+if os.path.exists(r_csv):
+    shutil.copy(r_csv, os.path.join(dst, f"{tag}_pmc_rdreq_map_se_r150.csv"))
+    acc, secs_r = {}, None
+    for row in csv.reader(open(r_csv)):
+        r = dict(zip(hdr, row))
+        if "map_se_kernel<false" not in r["Kernel_Name"] or r["Counter_Name"] in acc:
+            continue
+        acc[r["Counter_Name"]] = int(float(r["Counter_Value"]))
+        secs_r = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    rb = acc["TCC_EA0_RDREQ_128B_sum"] * 128 + acc["TCC_EA0_RDREQ_64B_sum"] * 64 + acc["TCC_EA0_RDREQ_32B_sum"] * 32
+    extra["r150"] = {"round": rnd, "kernel": "map_se_kernel", "workload": {"kind": "se_random", "genome_mbp": 3100, "reads": 4000000, "read_len": 150},
+                     "counters": acc, "hbm_read_bytes_per_launch": rb, "kernel_seconds_under_pmc": secs_r, "build": build,
+                     "note": "as the single-end pass, over `python3 bench.py --mode random --read-len 150 --reads 4000000 --steps 1 --warmup 0`"}
+    json.dump(extra["r150"], open(os.path.join(dst, f"{tag}_traffic_rpbat150.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv"))))[:6]
 calls_note = ""
 cpath = os.path.join(src, "map_se_calls.csv")
@@ -88,4 +144,12 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
             f"(MI355X_MICROARCH.md, HBM).  It is {nbytes / (rf['alg_bytes_per_read_kernel_tally'] * n_reads):.1f}x the kernel-tally bytes and "
             f"{nbytes / (rf['alg_bytes_per_read_strict'] * n_reads):.1f}x the strict bytes: every 8-64-byte gather costs a whole 128-byte line.\n\n")
     f.write("Work per read in that run: " + ", ".join(f"{k} {v}" for k, v in line["work_per_read"].items()) + ".\n")
+    if "pe" in extra:
+        t = extra["pe"]["tiers"]
+        f.write(f"\nPaired-end (config 3, `{tag}_traffic_pe.json`): tier 1 {t['tier1']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G + tier 2 "
+                f"{t['tier2']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G read requests per step of 1 M pairs = {extra['pe']['lines_per_pair'] * 1e6 / 1e3:.1f} k lines per pair.\n")
+    if "r150" in extra:
+        f.write(f"\n150 bp random PBAT (config 5, `{tag}_traffic_rpbat150.json`): {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 1e9:.2f} G read requests per launch of 4 M reads "
+                f"= {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 4e6:.0f} lines per read.\n")
+    f.write(f"\nBuild: {build}.\n")
 print(open(os.path.join(dst, f"{tag}_README.md")).read())

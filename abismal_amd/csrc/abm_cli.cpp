@@ -813,6 +813,72 @@ struct Topology {
   }
 };
 
+// ---- BGZF input (bgzip-compressed FASTQ): blocks are independent gzip members that say how long they are ----------
+// header: 1f 8b 08 04 | mtime(4) xfl os | xlen(2) | subfields ... 'B' 'C' 02 00 BSIZE(2) ... | deflate data | crc32 isize
+// (SAM spec 4.1).  bsize_at returns the block's whole length (BSIZE + 1) or 0 if `p` does not start a BGZF block.
+inline uint32_t le16(const unsigned char *p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8); }
+inline uint32_t le32(const unsigned char *p) { return le16(p) | (le16(p + 2) << 16); }
+uint32_t bgzf_block_length(const unsigned char *p, uint64_t avail, uint32_t &data_off) {
+  if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+  const uint32_t xlen = le16(p + 10);
+  if (12ull + xlen > avail) return 0;
+  for (uint32_t at = 0; at + 4 <= xlen;) {
+    const unsigned char *sf = p + 12 + at;
+    const uint32_t slen = le16(sf + 2);
+    if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && at + 6 <= xlen) {
+      const uint32_t total = le16(sf + 4) + 1;
+      data_off = 12 + xlen;
+      return total >= data_off + 8 && total <= avail ? total : 0;
+    }
+    at += 4 + slen;
+  }
+  return 0;
+}
+bool looks_like_bgzf(const std::string &path) {
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  unsigned char head[512];
+  const ssize_t got = ::pread(fd, head, sizeof(head), 0);
+  struct stat sb;
+  const bool regular = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+  ::close(fd);
+  uint32_t data_off = 0;
+  if (!regular || got < 18) return false;
+  // (the first block's length may exceed what was read: only its header is checked here, the scan checks every block)
+  if (head[0] != 0x1f || head[1] != 0x8b || head[2] != 8 || !(head[3] & 4)) return false;
+  const uint32_t xlen = le16(head + 10);
+  for (uint32_t at = 0; at + 6 <= xlen && 12 + at + 6 <= static_cast<uint32_t>(got);) {
+    const unsigned char *sf = head + 12 + at;
+    if (sf[0] == 'B' && sf[1] == 'C' && le16(sf + 2) == 2) return true;
+    at += 4 + le16(sf + 2);
+  }
+  (void)data_off;
+  return false;
+}
+// one thread's inflate state, reset per block
+struct BgzfInflater {
+  z_stream zs;
+  bool live = false;
+  ~BgzfInflater() { if (live) inflateEnd(&zs); }
+  // block at `p` (whole length `len`, deflate data from `data_off`) -> dst (room for isize bytes); checks size and CRC
+  void block(const unsigned char *p, uint32_t len, uint32_t data_off, char *dst, uint32_t isize) {
+    if (!live) {
+      std::memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+      live = true;
+    }
+    else inflateReset(&zs);
+    zs.next_in = const_cast<Bytef *>(p + data_off);
+    zs.avail_in = len - data_off - 8;
+    zs.next_out = reinterpret_cast<Bytef *>(dst);
+    zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    if (rc != Z_STREAM_END || zs.total_out != isize) throw std::runtime_error("corrupt BGZF block in the reads file");
+    if (static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(dst), isize)) != le32(p + len - 8))
+      throw std::runtime_error("BGZF block with a wrong checksum in the reads file");
+  }
+};
+
 // a mapped input file that shrinks under the run (truncated, a network file system losing it) faults with SIGBUS
 void install_sigbus_handler() {
   struct sigaction sa;
@@ -922,7 +988,11 @@ int cmd_map(int argc, char **argv) {
   std::vector<int> dev_of = opt.devices;
   int n_gpus = dev_of.empty() ? opt.gpus : static_cast<int>(dev_of.size());
   const bool virtual_gpus = opt.host_ceiling;
-  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 3 : 2);
+  // (paired-end: a batch ends in a tail of a few pairs with huge candidate sets that keep single waves busy for a second or
+  // two after the rest is done -- DESIGN 4.3 -- so many smaller batches are kept in flight, each on a context of its own,
+  // and their tails overlap: bench.py's kernel loop runs 16; with 3 batches of 2 M pairs an end-to-end run of 2 M pairs
+  // took 3.8 s for 0.9 s of kernel work, profiles/r04_bench_pe_e2e_before.json)
+  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 8 : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
@@ -981,7 +1051,7 @@ int cmd_map(int argc, char **argv) {
     }
     // (the same expression the mappers use for a full batch, rounded up to whole slices as they do)
     const size_t slice_for_reserve = env_reads("ABM_CLI_SLICE_READS", 1u << 15);
-    size_t reserve_reads = opt.batch ? opt.batch : env_reads("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23));
+    size_t reserve_reads = opt.batch ? opt.batch : env_reads("ABM_CLI_BATCH_READS", paired ? (1u << 20) : (1u << 23));
     reserve_reads = (reserve_reads + slice_for_reserve - 1) / slice_for_reserve * slice_for_reserve + 256;
     {  // (no more than the input can hold: a record is at least two sequence-length lines)
       struct stat sb;
@@ -1050,8 +1120,12 @@ int cmd_map(int argc, char **argv) {
   // the paired-end path takes them); virtual GPUs hand their made-up hits over the same way
   const bool stream_slices = !paired && !std::getenv("ABM_CLI_NO_STREAM");
   // size of a GPU's first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
-  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", stream_slices ? 1u << 19 : 1u << 21));
-  const bool plain_input = [&] {
+  const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", stream_slices ? 1u << 19 : (paired ? 1u << 17 : 1u << 21)));
+  // BGZF-compressed input (bgzip): its blocks are independent, so the workers inflate them side by side into one
+  // anonymous mapping that then IS the input as far as counting, cutting and parsing go (a single-member .gz, what plain
+  // gzip writes, has no such structure: one thread inflates it, as in the reference, src/abismal.cpp:150-209)
+  const bool bgzf_input = !std::getenv("ABM_CLI_NO_BGZF") && std::all_of(opt.reads.begin(), opt.reads.end(), looks_like_bgzf);
+  const bool plain_input = bgzf_input || [&] {
     for (const std::string &path : opt.reads) {
       const int fd = ::open(path.c_str(), O_RDONLY);
       if (fd < 0) throw std::runtime_error("cannot open reads file: " + path);
@@ -1065,13 +1139,13 @@ int cmd_map(int argc, char **argv) {
     return true;
   }();
   const int n_regions = std::max(1, opt.out_parts);
-  if (n_regions > 1 && !plain_input) throw std::runtime_error("-out-parts needs plain (seekable, uncompressed) FASTQ input");
+  if (n_regions > 1 && (!plain_input || bgzf_input)) throw std::runtime_error("-out-parts needs plain (seekable, uncompressed) FASTQ input");
   if (n_regions > n_gpus * per_gpu) throw std::runtime_error("-out-parts: more parts than mapper threads");
   const int n_nodes = topo.n_nodes();
   // Batches are FULL (-batch reads) except at the end of the input: the mapping kernel's time has a floor set
   // by its costliest reads (a quarter of a second, whatever the batch), so small batches waste the GPU;
   // cutting and parsing run far ahead of it, so a full batch is ready within a fraction of a kernel's time.
-  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 21) : (1u << 23)));
+  const size_t batch_reads = opt.batch ? opt.batch : static_cast<size_t>(env_or("ABM_CLI_BATCH_READS", paired ? (1u << 20) : (1u << 23)));
   // host workers: -t, else 8 plus 8 per GPU (what 14 M reads/s per GPU of counting, parsing and formatting take, twice
   // over: 0.2 us of CPU per read), never more than the box has cores (second SMT siblings add little, and the mapper
   // threads, the writers and the HIP runtime's own threads need somewhere to run) -- and never more than the CPU time
@@ -1211,7 +1285,7 @@ int cmd_map(int argc, char **argv) {
   // A run's first second otherwise touches gigabytes of fresh memory from a hundred threads that share one address
   // space: page faults and the allocator's calls for more memory, which stall one another.
   double host_prepare_s = 0;
-  if (plain_input && !std::getenv("ABM_CLI_NO_PREWARM")) {
+  if (plain_input && !bgzf_input && !std::getenv("ABM_CLI_NO_PREWARM")) {
     const auto tp = std::chrono::steady_clock::now();
     uint64_t in_bytes = 0, rec_bytes = 0, read_len = 0;
     {
@@ -1400,7 +1474,19 @@ int cmd_map(int argc, char **argv) {
     // instead of copying the whole input out of it twice with pread -- a fifth of the pipeline's CPU time per read
     // (profiles/r04_host_ceiling.log).  nullptr (mapping refused, ABM_CLI_NO_MMAP=1): pread into per-slice buffers.
     const char *map = nullptr;
+    std::vector<uint64_t> chunk_begin;  // [n_chunks + 1] where each chunk begins in the text (plain files: multiples of kChunk)
+    // BGZF: the compressed file mapped, its blocks (offset and length in the file, offset in the text), the blocks of
+    // each chunk, and how far the text has been handed back to the system (everything before the oldest unwritten slice)
+    const unsigned char *cmap = nullptr;
+    uint64_t csize = 0;
+    std::vector<uint64_t> block_at, block_text;
+    std::vector<uint32_t> chunk_first_block;
+    uint64_t released_upto = 0;
   };
+  // BGZF input: how much inflated text may exist beyond the oldest unwritten slice (what the pipeline may hold in flight,
+  // generously: a record of 100-base reads is ~250 bytes, twice that for long names and reads)
+  const uint64_t inflate_ahead_bytes = env_or("ABM_CLI_INFLATE_AHEAD", std::max<uint64_t>(4ull << 30, static_cast<uint64_t>(max_reads_in_flight) * 512));
+  bool count_gated = false;  // BGZF: inflating further ahead is on hold until slices have been written
   std::vector<LineFile> lf(plain_input ? opt.reads.size() : 0);
   for (size_t e = 0; e < lf.size(); ++e) {
     lf[e].fd = ::open(opt.reads[e].c_str(), O_RDONLY);
@@ -1408,15 +1494,64 @@ int cmd_map(int argc, char **argv) {
     struct stat sb;
     if (::fstat(lf[e].fd, &sb) != 0) throw std::runtime_error("cannot stat reads file: " + opt.reads[e]);
     lf[e].size = static_cast<uint64_t>(sb.st_size);
+    if (bgzf_input) {
+      // walk the block headers (each says how long its block is; its last four bytes how long its text): the text's
+      // extent and every block's place in it are known before a single block is inflated
+      LineFile &F = lf[e];
+      F.csize = F.size;
+      void *cm = F.csize ? ::mmap(nullptr, F.csize, PROT_READ, MAP_SHARED, F.fd, 0) : nullptr;
+      if (F.csize && cm == MAP_FAILED) throw std::runtime_error("cannot map reads file: " + opt.reads[e]);
+      F.cmap = static_cast<const unsigned char *>(cm);
+      uint64_t at = 0, text = 0;
+      while (at < F.csize) {
+        uint32_t data_off = 0;
+        const uint32_t len = bgzf_block_length(F.cmap + at, F.csize - at, data_off);
+        if (!len) throw std::runtime_error("reads file is not BGZF all the way through (block at byte " + std::to_string(at) + "): " + opt.reads[e]);
+        const uint32_t isize = le32(F.cmap + at + len - 4);
+        if (isize) { F.block_at.push_back(at); F.block_text.push_back(text); }
+        text += isize;
+        at += len;
+      }
+      F.block_at.push_back(at);
+      F.block_text.push_back(text);
+      F.size = text;
+      // chunks = runs of blocks holding up to kChunk of text
+      for (size_t b = 0; b + 1 < F.block_at.size();) {
+        F.chunk_begin.push_back(F.block_text[b]);
+        F.chunk_first_block.push_back(static_cast<uint32_t>(b));
+        size_t b1 = b + 1;
+        while (b1 + 1 < F.block_at.size() && F.block_text[b1 + 1] - F.block_text[b] <= kChunk) ++b1;
+        b = b1;
+      }
+      F.chunk_first_block.push_back(static_cast<uint32_t>(F.block_at.size() - 1));
+      F.chunk_begin.push_back(F.size);
+      F.n_chunks = F.chunk_begin.size() - 1;
+      F.chunks.resize(F.n_chunks);
+      if (F.size) {
+        void *m = ::mmap(nullptr, F.size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) throw std::runtime_error("cannot reserve address space for the inflated reads of " + opt.reads[e]);
+        F.map = static_cast<const char *>(m);
+        // the text's last byte (does the file end with a newline?): its last block, inflated here
+        const size_t lb = F.block_at.size() - 2;
+        uint32_t data_off = 0;
+        const uint32_t len = bgzf_block_length(F.cmap + F.block_at[lb], F.csize - F.block_at[lb], data_off);
+        std::vector<char> tail(F.block_text[lb + 1] - F.block_text[lb]);
+        BgzfInflater inf;
+        inf.block(F.cmap + F.block_at[lb], len, data_off, tail.data(), static_cast<uint32_t>(tail.size()));
+        F.ends_with_newline = tail.back() == '\n';
+      }
+      continue;
+    }
     lf[e].n_chunks = (lf[e].size + kChunk - 1) / kChunk;
     lf[e].chunks.resize(lf[e].n_chunks);
+    for (uint64_t k = 0; k <= lf[e].n_chunks; ++k) lf[e].chunk_begin.push_back(std::min(lf[e].size, k * kChunk));
     if (lf[e].size) { char c = 0; if (::pread(lf[e].fd, &c, 1, static_cast<off_t>(lf[e].size - 1)) == 1) lf[e].ends_with_newline = c == '\n'; }
     if (lf[e].size && !std::getenv("ABM_CLI_NO_MMAP")) {
       void *m = ::mmap(nullptr, lf[e].size, PROT_READ, MAP_SHARED, lf[e].fd, 0);
       if (m != MAP_FAILED) lf[e].map = static_cast<const char *>(m);
     }
   }
-  struct Unmapper { std::vector<LineFile> *v; ~Unmapper() { for (LineFile &F : *v) if (F.map) ::munmap(const_cast<char *>(F.map), F.size); } } unmapper{&lf};
+  struct Unmapper { std::vector<LineFile> *v; ~Unmapper() { for (LineFile &F : *v) { if (F.map) ::munmap(const_cast<char *>(F.map), F.size); if (F.cmap) ::munmap(const_cast<unsigned char *>(F.cmap), F.csize); } } } unmapper{&lf};
   const bool mapped_input = !lf.empty() && std::all_of(lf.begin(), lf.end(), [](const LineFile &F) { return F.map != nullptr || F.size == 0; });
   if (mapped_input) install_sigbus_handler();
   auto read_range = [&](int fd, const std::string &path, char *dst, uint64_t lo, uint64_t hi) {
@@ -1433,12 +1568,31 @@ int cmd_map(int argc, char **argv) {
     for (size_t f = 0; f < lf.size(); ++f)
       if (lf[f].next_chunk < lf[f].n_chunks && (best == lf.size() || lf[f].next_chunk < lf[best].next_chunk)) best = f;
     if (best == lf.size()) return false;
+    // (BGZF: the text is inflated into memory and handed back as slices are written; no further ahead of that than what
+    // may be in flight anyway)
+    if (lf[best].cmap && lf[best].chunk_begin[lf[best].next_chunk] > lf[best].released_upto + inflate_ahead_bytes) {
+      // (the mappers must not wait for more reads than this lets through: they take what is parsed)
+      if (!count_gated) { count_gated = true; for (Region &R : regions) R.cv_map.notify_all(); }
+      return false;
+    }
+    count_gated = false;
     e = best; k = lf[e].next_chunk++;
     return true;
   };
   auto count_chunk = [&](size_t e, uint64_t k, std::vector<char> &buf) {  // the newlines of one chunk
     const auto t0 = now();
-    const uint64_t lo = k * kChunk, hi = std::min(lf[e].size, lo + kChunk);
+    const uint64_t lo = lf[e].chunk_begin[k], hi = lf[e].chunk_begin[k + 1];
+    if (lf[e].cmap) {  // BGZF: this chunk's blocks are inflated into their place in the text first
+      thread_local BgzfInflater inf;
+      LineFile &F = lf[e];
+      for (uint32_t b = F.chunk_first_block[k]; b < F.chunk_first_block[k + 1]; ++b) {
+        uint32_t data_off = 0;
+        const uint32_t len = bgzf_block_length(F.cmap + F.block_at[b], F.csize - F.block_at[b], data_off);
+        if (!len) throw std::runtime_error("corrupt BGZF block in " + opt.reads[e]);
+        // (blocks without text were left out of the list: the next listed block begins where this one's text ends)
+        inf.block(F.cmap + F.block_at[b], len, data_off, const_cast<char *>(F.map) + F.block_text[b], static_cast<uint32_t>(F.block_text[b + 1] - F.block_text[b]));
+      }
+    }
     const char *base = lf[e].map ? lf[e].map + lo : nullptr;
     if (!base) {
       buf.resize(kChunk);
@@ -1496,7 +1650,7 @@ int cmd_map(int argc, char **argv) {
     const uint64_t local = line - cur.cum;          // the local-th newline of this chunk, 1-based
     const uint64_t mark = local / kMark;            // marks[m - 1] = offset past newline m * kMark
     uint64_t at = mark ? ci.marks[mark - 1] : 0, seen = mark * kMark;
-    const uint64_t base = cur.chunk * kChunk, hi = std::min(F.size, base + kChunk);
+    const uint64_t base = F.chunk_begin[cur.chunk], hi = F.chunk_begin[cur.chunk + 1];
     std::vector<char> buf;
     while (seen < local) {  // walk the <= kMark lines after the mark
       const uint64_t want = std::min<uint64_t>(hi - (base + at), 1u << 16);
@@ -1673,9 +1827,12 @@ int cmd_map(int argc, char **argv) {
             size_t k = (left + cap - 1) / cap;
             if (k <= 1) k = (!stream_slices && left >= (1u << 22)) ? 2 : 1;
             k = std::max<size_t>(k, std::min<size_t>(static_cast<size_t>(R.mappers_live + per_gpu - 1) / per_gpu, (left + (1u << 20) - 1) >> 20));
+            // (pairs: what is left is shared among the region's mapper threads, so that their batches' tails overlap)
+            if (paired) k = std::max<size_t>(k, std::min<size_t>(static_cast<size_t>(R.mappers_live), (left + (1u << 18) - 1) >> 18));
             return std::max<size_t>(slice_reads, (left + k - 1) / std::max<size_t>(k, 1));
           };
-          R.cv_map.wait(lk, [&] { return failure || R.run_reads >= target() || (all_parsed() && (R.run_end > R.next_to_map || R.parsed.empty())); });
+          R.cv_map.wait(lk, [&] { return failure || R.run_reads >= target() || (count_gated && R.run_end > R.next_to_map && R.n_parsed == R.n_slices) ||
+                                         (all_parsed() && (R.run_end > R.next_to_map || R.parsed.empty())); });
           if (failure || R.run_end == R.next_to_map) {
             // (the unused batch goes back to the pool: destroying it here would free its page-locked buffers -- a
             // device-wide wait and 0.1-0.2 s of unpinning -- inside the run's clock; the trace showed the run's end
@@ -2088,6 +2245,14 @@ int cmd_map(int argc, char **argv) {
             for (int j = 0; j < 6; ++j) gpu_stats[b->gpu].s[k].v[j] += to_write->stats.s[k].v[j];
           R.reads_in_flight -= std::min<size_t>(R.reads_in_flight, slice_reads);
           ++R.slices_written;
+          for (size_t e = 0; e < lf.size(); ++e)
+            if (lf[e].cmap) {  // BGZF: the inflated text behind this slice goes back to the system (whole pages of it)
+              LineFile &F = lf[e];
+              const uint64_t from = (F.released_upto + 4095) & ~4095ull, to = to_write->byte_hi[e] & ~4095ull;
+              if (to > from) ::madvise(const_cast<char *>(F.map) + from, to - from, MADV_DONTNEED);
+              F.released_upto = std::max(F.released_upto, to_write->byte_hi[e]);
+              for (NodeQueues &q : nq) if (q.idle > 0) q.cv.notify_one();  // (chunks further on may be inflated now)
+            }
           // the batch goes when its last slice is written; its slices and its own buffers are recycled
           if (--b->slices_left == 0) {
             for (auto it = live_batches.begin(); it != live_batches.end(); ++it)

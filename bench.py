@@ -62,6 +62,22 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs the container's CFS quota gives this process (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None: on a pod of
+    a shared node, threads beyond it do not run more, they are throttled (abm_cli.cpp: CpuQuota)"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 and p > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -401,7 +417,10 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         h1 = [bytes(r) for r in b1[: ns * L].cpu().numpy().reshape(ns, L)]
         h2 = [bytes(r) for r in b2[: ns * L].cpu().numpy().reshape(ns, L)]
         oix = o.index_load(os.path.join(args.workdir, f"g{int(args.genome_mbp)}.idx"))
+        quota = cpu_quota()
         cores = os.cpu_count() or 1
+        if quota:
+            cores = int(min(cores, max(1, round(4 * quota))))
         t0 = time.perf_counter()
         orc = o.map_pe(oix, h1, h2, mode=0, threads=cores)
         t_cpu = time.perf_counter() - t0
@@ -419,7 +438,8 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
             full = str(e)[:300]
         phys = physical_cores()
         cpu = {"value": round(2 * ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "physical_cores": phys, "per_thread": round(2 * ns / t_cpu / cores, 1), "per_core": round(2 * ns / t_cpu / phys, 1),
+               "physical_cores": phys, "cpu_quota_cpus": quota, "per_thread": round(2 * ns / t_cpu / cores, 1),
+               "per_core": round(2 * ns / t_cpu / (min(phys, quota) if quota else phys), 1),
                "sample": f"first {ns} pairs, oracle restatement (-O3 -DNDEBUG), {cores} threads, {t_cpu:.1f}s",
                "pair_positions_identical_to_gpu": f"{same}/{ns}",
                "pairs_hits_fallbacks_cigars_vs_oracle": full}
@@ -569,6 +589,19 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
                         with open(fq1, "rb") as fi:
                             shutil.copyfileobj(fi, fo, 1 << 24)
         fqs = [fq] + fqs1[1:]
+        if kind == "pe" and args.e2e_copies > 1:
+            # a paired-end batch ends in a tail of a second or two that only other batches hide: the run is
+            # timed on the pair of FASTQ files --e2e-copies times over (sim makes 150 k pairs a second on one thread)
+            copies = args.e2e_copies
+            fqs = []
+            for k, src in enumerate(fqs1):
+                dstp = os.path.join(wd, f"reads_x_{k + 1}.fq")
+                with open(dstp, "wb") as fo:
+                    for _ in range(copies):
+                        with open(src, "rb") as fi:
+                            shutil.copyfileobj(fi, fo, 1 << 24)
+                fqs.append(dstp)
+            fq = fqs[0]
         sam, tj = os.path.join(wd, "out.sam"), os.path.join(wd, "timing.json")
         gflag = ["-gpus", str(gpus)] + map_flags
         parts = gpus if gpus > 1 else 1
@@ -588,7 +621,7 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
         ceiling = []
         if kind == "se":
             for sink in (os.path.join(wd, "ceil.sam"), "/dev/null"):
-                for th in sorted({32, med["host_threads"], min(os.cpu_count() or 1, 128)}):
+                for th in sorted({med["host_threads"], min(os.cpu_count() or 1, 128)}):
                     r = subprocess.run([cli, "map", "-virtual-gpus", str(gpus)] + pflag + ["-t", str(th), "-i", idx, "-o", sink, "-timing", tj, fq],
                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
                     if r.returncode == 0:
@@ -629,6 +662,47 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
             for f in (gzp, os.path.join(wd, "gz.sam")):
                 if os.path.exists(f):
                     os.remove(f)
+            # ... and the whole FASTQ as BGZF (what bgzip writes: independent blocks of up to 64 KB), which the host workers
+            # inflate side by side
+            import struct
+            from concurrent.futures import ThreadPoolExecutor
+            bzp = os.path.join(wd, "reads.fq.bgz")
+
+            def bgzf_block(d):
+                co = zlib.compressobj(1, zlib.DEFLATED, -15)
+                z = co.compress(d) + co.flush()
+                return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(z) + 25) + z +
+                        struct.pack("<II", zlib.crc32(d), len(d)))
+
+            t0 = time.time()
+            with open(fq1, "rb") as fi, open(bzp, "wb") as fo, ThreadPoolExecutor(max_workers=16) as pool:
+                while True:
+                    big = fi.read(64 << 20)
+                    if not big:
+                        break
+                    for blk in pool.map(bgzf_block, [big[k:k + 0xff00] for k in range(0, len(big), 0xff00)]):
+                        fo.write(blk)
+                fo.write(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+            t_bz = time.time() - t0
+            bz_runs = []
+            for rep in range(2):
+                r = subprocess.run([cli, "map", "-gpus", "1", "-i", idx, "-o", os.path.join(wd, "bz.sam"), "-timing", tj, bzp],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                if r.returncode != 0:
+                    gz["bgzf"] = {"error": r.stderr[-500:]}
+                    break
+                bz_runs.append(json.load(open(tj)))
+            if bz_runs:
+                t = min(bz_runs, key=lambda x: x["seconds"])
+                same = os.path.getsize(os.path.join(wd, "bz.sam")) == os.path.getsize(sam)
+                gz["bgzf"] = {"value": round(t["reads"] / t["seconds"], 1), "unit": "reads/s", "reads": t["reads"], "seconds": round(t["seconds"], 3),
+                              "seconds_of_each_run": [round(x["seconds"], 3) for x in bz_runs], "host_threads": t["host_threads"],
+                              "input": f"the whole FASTQ as BGZF (level 1, {os.path.getsize(bzp)} bytes, written in {t_bz:.0f}s)",
+                              "sam_size_equals_plain_run": same, "cpu_s": t.get("cpu_s"),
+                              "note": "BGZF blocks are inflated by the host workers side by side (16 CPUs of quota on the measured box: zlib inflate is most of them)"}
+            for f in (bzp, os.path.join(wd, "bz.sam")):
+                if os.path.exists(f):
+                    os.remove(f)
         # one GPU: the same pipeline on a longer input (the FASTQ four times over) -- a 10 M-read run is a few batches
         # long, so it mostly measures how well the first batch's start and the last batch's output are hidden
         sustained = None
@@ -663,8 +737,8 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
                "host_ceiling_reads_per_s": max([c["reads_per_s"] for c in ceiling if c["sink"] != "/dev/null"], default=None),
                "host_ceiling_reads_per_s_dev_null": max([c["reads_per_s"] for c in ceiling if c["sink"] == "/dev/null"], default=None),
                "host_ceiling_note": ("abismal-amd map -virtual-gpus N on the same input: count, cut, parse, deal, format and write at full rate, every "
-                                     "read given a made-up hit instead of the mapping call; SAM into the run's kind of sink and into /dev/null, at 32 / "
-                                     "default / 128 host threads; scripts/r04_host_ceiling.py sweeps 40 M-read runs (profiles/r04_host_ceiling.log)") if ceiling else None}
+                                     "read given a made-up hit instead of the mapping call; SAM into the run's kind of sink and into /dev/null, at the default "
+                                     "and at 128 host threads (both clamped to the container's CPU quota); scripts/r04_host_ceiling.py sweeps 40 M-read runs (profiles/r04_host_ceiling.log)") if ceiling else None}
         # parity on a prefix: product CLI vs oracle CLI, SAM body (everything but the @PG line) byte for byte
         nchk = min(n, args.e2e_check)
         if nchk > 0:
@@ -696,7 +770,7 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
             subprocess.run([cli, "map"] + map_flags + ["-i", idx, "-o", os.path.join(wd, "p_gpu.sam")] + pfqs, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             t0 = time.time()
-            subprocess.run([ob.CLI, "map"] + map_flags + ["-t", str(os.cpu_count() or 1), "-i", idx, "-o", os.path.join(wd, "p_oracle.sam")] + pfqs,
+            subprocess.run([ob.CLI, "map"] + map_flags + ["-t", str(int(min(os.cpu_count() or 1, max(1, round(4 * (cpu_quota() or 1e9)))))), "-i", idx, "-o", os.path.join(wd, "p_oracle.sam")] + pfqs,
                            check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             t_or = time.time() - t0
             m_g, k_g = body_md5(os.path.join(wd, "p_gpu.sam"))
@@ -807,7 +881,7 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("ABM_BENCH_E2E_READS", 10_000_000)))
     ap.add_argument("--e2e-copies", type=int, default=int(os.environ.get("ABM_BENCH_E2E_COPIES", 4)),
                     help="also time the CLI on the e2e FASTQ concatenated this many times (0/1 = skip)")
-    ap.add_argument("--e2e-check", type=int, default=int(os.environ.get("ABM_BENCH_E2E_CHECK", 1_000_000)),
+    ap.add_argument("--e2e-check", type=int, default=int(os.environ.get("ABM_BENCH_E2E_CHECK", 500_000)),
                     help="reads of the FASTQ prefix mapped by the oracle CLI too (SAM body md5 must agree)")
     ap.add_argument("--e2e-gz-reads", type=int, default=int(os.environ.get("ABM_BENCH_E2E_GZ_READS", 2_000_000)),
                     help="reads of the e2e FASTQ's prefix that also run as gzip-compressed input (0 = skip)")
@@ -1039,7 +1113,12 @@ def main():
         seqs = [bytes(r) for r in host_reads]
         seqs = [b"" if s.count(b"N") > L - 44 else s for s in seqs]
         oix = o.index_load(idx)
+        # threads: every hardware thread -- unless the container's CPU quota is smaller, in which case four threads per CPU
+        # of quota (measured best on the 16-CPU pod: 64 threads 49 k reads/s, 256 threads 38 k: the rest is throttling)
+        quota = cpu_quota()
         cores = os.cpu_count() or 1
+        if quota:
+            cores = int(min(cores, max(1, round(4 * quota))))
         t0 = time.perf_counter()
         o_res, o_cig, o_cn, o_work = o.map_se(oix, seqs, mode=int(se_mode), threads=cores, cig_stride=L + 2)
         t_cpu = time.perf_counter() - t0
@@ -1069,7 +1148,7 @@ def main():
         phys = physical_cores()
         sweep = [{"threads": cores, "reads_per_s": round(ns / t_cpu, 1), "per_thread": round(ns / t_cpu / cores, 1), "sample_reads": ns}]
         ns_sw = max(1, ns // 5)
-        for th in sorted({max(1, phys // 2), phys} - {cores}):
+        for th in sorted(({int(max(1, round(quota))), os.cpu_count() or 1} if quota else {max(1, phys // 2), phys}) - {cores}):
             t0 = time.perf_counter()
             o.map_se(oix, seqs[:ns_sw], mode=int(se_mode), threads=th, cig_stride=L + 2)
             dt = time.perf_counter() - t0
@@ -1077,7 +1156,9 @@ def main():
         best = max(sweep, key=lambda s: s["reads_per_s"])
         o.index_free(oix)
         cpu = {"value": round(ns / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "physical_cores": phys, "per_thread": round(ns / t_cpu / cores, 1), "per_core": round(ns / t_cpu / phys, 1),
+               "physical_cores": phys, "cpu_quota_cpus": quota, "per_thread": round(ns / t_cpu / cores, 1),
+               # per core: of the cores the process can actually use (its quota, if it has one)
+               "per_core": round(ns / t_cpu / (min(phys, quota) if quota else phys), 1),
                "thread_sweep": sorted(sweep, key=lambda s: s["threads"]), "best_of_sweep": best,
                "sample": f"first {ns} reads of rank 0's batch, oracle restatement (-O3 -DNDEBUG), {cores} threads, {t_cpu:.1f}s",
                "positions_identical_to_gpu": f"{int(same_pos.sum())}/{ns}",
@@ -1157,7 +1238,7 @@ def main():
         common = [sys.executable, os.path.abspath(__file__), "--no-other-configs", "--genome-mbp", str(args.genome_mbp),
                   "--workdir", args.workdir] + (["--no-e2e"] if args.no_e2e else [])
         for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "16", "--warmup", "16", "--cpu-sample", "200000",
-                                                         "--e2e-reads", "2000000", "--e2e-check", "50000"]),
+                                                         "--e2e-reads", "2000000", "--e2e-check", "20000", "--e2e-copies", "4"]),
                            ("config5_random_pbat_150", ["--mode", "random", "--read-len", "150", "--reads", "4000000", "--steps", "3", "--warmup", "1",
                                                         "--cpu-sample", "200000", "--e2e-reads", "4000000", "--e2e-check", "200000", "--e2e-copies", "1",
                                                         "--e2e-gz-reads", "0"])):

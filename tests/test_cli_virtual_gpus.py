@@ -70,6 +70,45 @@ def test_pread_path_equals_mapped_input(reads, trex_index):
     assert body([f"{d}/m.sam.part000", f"{d}/m.sam.part001"]) == body([f"{d}/p.sam.part000", f"{d}/p.sam.part001"])
 
 
+def _write_bgzf(src, dst, block=0xff00):
+    import struct
+    import zlib
+    with open(src, "rb") as f, open(dst, "wb") as o:
+        while True:
+            d = f.read(block)
+            if not d:
+                break
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            z = co.compress(d) + co.flush()
+            o.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(z) + 25) + z + struct.pack("<II", zlib.crc32(d), len(d)))
+        o.write(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+
+
+def test_bgzf_input_is_inflated_block_parallel(reads, trex_index):
+    # bgzip-compressed FASTQ: the workers inflate its blocks side by side (single-member gzip: one inflating thread);
+    # same output as the plain file, also with blocks of odd sizes, chunks of a few blocks, and the inflated text held
+    # to a window of 300 kB ahead of the writer (the mappers then take what is there instead of waiting for a batch)
+    import gzip
+    fq, d = reads
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", d / "plain.sam", fq], env=SMALL)
+    ref = body([d / "plain.sam"])
+    _write_bgzf(fq, d / "b.fq.gz")
+    _write_bgzf(fq, d / "odd.fq.gz", block=7919)
+    with open(fq, "rb") as f, gzip.open(d / "single.fq.gz", "wb", compresslevel=1) as o:
+        o.write(f.read())
+    for name, env in (("b", SMALL), ("odd", dict(SMALL, ABM_CLI_CHUNK_BYTES="30000")), ("b", dict(SMALL, ABM_CLI_INFLATE_AHEAD="300000")),
+                      ("b", dict(SMALL, ABM_CLI_NO_BGZF="1")), ("single", SMALL)):
+        run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", d / "z.sam", d / f"{name}.fq.gz"], env=env)
+        assert body([d / "z.sam"]) == ref, (name, env)
+    # a damaged block is an error, not silence
+    raw = bytearray(open(d / "b.fq.gz", "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    open(d / "bad.fq.gz", "wb").write(raw)
+    r = subprocess.run([CLI, "map", "-virtual-gpus", "1", "-i", trex_index, "-o", str(d / "bad.sam"), str(d / "bad.fq.gz")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and ("BGZF" in r.stderr or "reads file" in r.stderr), r.stderr
+
+
 def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):
     # a library of uniformly short reads (45 bases: every read could be a ghost-bit source for the next
     # batch) made each batch carry every read seen so far.  The lead-in holds only records that are longer than

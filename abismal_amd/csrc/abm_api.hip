@@ -170,6 +170,7 @@ struct abm_ctx {
   uint64_t sliced_reads = 0;
   bool host_results = false;        // set by abm_map_se_batch around its launches: arena and summary words in pinned memory
   HostBuf<abm_hit> h_res;           // hits on their way out (a pinned target keeps the copy on the DMA engines)
+  HostBuf<abm_hit> h_pe_out;        // paired-end results (pairs, then both fallback hits) written by the kernels, pinned
   unsigned launch_seq = 0;
   // every device entry point reuses this context's workspaces: a call first makes its stream wait for
   // the previous call's work (whatever stream that ran on), so consecutive calls never overlap
@@ -405,7 +406,9 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.cig_stride = cig_stride;
   a.ctmp_cap = eff_len + 2;
   {  // arena for the CIGARs that outgrow their slot: few reads do, one op per read is ample
-    const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, n));
+    // (150-base reads with sim-like indel rates need 1.5 ops of arena per read beside their 4-op slots; an arena that
+    // overflows costs a second mapping of the batch)
+    const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, 2 * n));
     ctx->cig_arena_count.reserve(1);
     HIPCHK(hipMemsetAsync(ctx->cig_arena_count.p, 0, 4, st));
     a.cig_arena_count = ctx->cig_arena_count.p;
@@ -505,6 +508,9 @@ OffsetScan scan_offsets(const uint64_t *seq_off, uint64_t n, HostBuf<uint64_t> &
   return out;
 }
 
+// ops per CIGAR slot of the paired-end host entry point (longer CIGARs go to the arena): 150-base ends with sim-like
+// indel rates have more than 4 ops a quarter of the time, more than 8 one time in fifty
+constexpr uint32_t kPeHostSlotOps = 8;
 void assemble_cigars(uint64_t n, uint32_t stride, const uint32_t *cn, const uint32_t *slots, const uint32_t *arena,
                      uint64_t arena_n, uint32_t *out_blob, uint64_t cap, uint64_t *out_off) {
   out_off[0] = 0;
@@ -638,14 +644,28 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.se1 = reinterpret_cast<abm::Hit *>(d_se1); a.se2 = reinterpret_cast<abm::Hit *>(d_se2);
   a.cig1 = d_cig1; a.cig2 = d_cig2; a.cig_stride = cig_stride; a.cig_n1 = d_cig_n1; a.cig_n2 = d_cig_n2;
   a.ctmp_cap = eff_len + 2;
+  const bool has_long = max_len > abm::kLdsReadLen;
   {
-    const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, 2 * n));
-    ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+    // (two ends, and sim-like 150-base reads carry two or more indels a quarter of the time: 2 n ops overflowed, and an
+    // overflowing arena means the whole batch is mapped AGAIN with a larger one -- with 8 contexts per GPU half of an
+    // end-to-end run's batches were, profiles/r04_pe_e2e_variants_arena.log)
+    const size_t want = std::max<size_t>(ctx->arena_want, std::max<size_t>(1u << 16, 4 * n));
     ctx->cig_arena_count.reserve(1);
     HIPCHK(hipMemsetAsync(ctx->cig_arena_count.p, 0, 4, st));
-    a.cig_arena = ctx->cig_arena.p;
     a.cig_arena_count = ctx->cig_arena_count.p;
-    a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->cig_arena.cap, 0xFFFFFF00u));
+    if (ctx->host_results) {  // (abm_map_pe_batch: the arena lies in pinned host memory, like the rest of its results)
+      ctx->h_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+      ctx->h_tail.reserve(2);
+      ctx->finished.reserve(1);
+      ctx->h_tail.p[0] = ctx->h_tail.p[1] = 0;
+      a.cig_arena = ctx->h_arena.p;
+      a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->h_arena.cap, 0xFFFFFF00u));
+    }
+    else {
+      ctx->cig_arena.reserve(std::min<size_t>(want, 0xFFFFFF00u));
+      a.cig_arena = ctx->cig_arena.p;
+      a.cig_arena_cap = static_cast<abm::u32>(std::min<size_t>(ctx->cig_arena.cap, 0xFFFFFF00u));
+    }
   }
   a.status = d_status;
   a.work = ctx->work.p;
@@ -691,12 +711,24 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
     a.work = ctx->work.p + 16;  // tier 2 tallies separately (abm_ctx_take_work_tiers)
+    if (ctx->host_results && !has_long) {  // the batch's last launch: its last wave publishes arena count and status to the host
+      HIPCHK(hipMemsetAsync(ctx->finished.p, 0, 4, st));
+      a.finished = ctx->finished.p;
+      a.host_tail = ctx->h_tail.p;
+    }
     const hipEvent_t e1 = begin_timed(ctx, st);
     HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(waves), true, ctx->phase_stamps, wps, st));
     if (e1) HIPCHK(hipEventRecord(e1, st));
+    a.finished = nullptr;
+    a.host_tail = nullptr;
   }
-  if (max_len > abm::kLdsReadLen)
+  if (has_long) {
     pe_long_pairs(ctx, a, n, d_blob1, d_off1, d_blob2, d_off2, std::min<abm::u32>(max_len, abm::kMaxReadLen), params->valid_frac, st);
+    if (ctx->host_results) {  // (rare: with a long-end launch the two summary words are copied out after it)
+      HIPCHK(hipMemcpyAsync(&ctx->h_tail.p[0], a.cig_arena_count, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&ctx->h_tail.p[1], a.status, 4, hipMemcpyDeviceToHost, st));
+    }
+  }
   HIPCHK(hipEventRecord(ctx->last_done, st));
 }
 
@@ -965,7 +997,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->rep->arena = nullptr;
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_pe_out.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -1321,67 +1353,65 @@ int abm_map_pe_batch(abm_ctx *ctx, int mode, const abm_params *params, uint64_t 
       for (uint64_t i = 0; i < n; ++i)
         ctx->too_long += (seq_off1[i + 1] - seq_off1[i]) > abm::kMaxReadLen || (seq_off2[i + 1] - seq_off2[i]) > abm::kMaxReadLen;
     }
-    abm_pair *d_pair = nullptr;
-    abm_hit *d_se1 = nullptr, *d_se2 = nullptr;
+    // Nothing is copied back after the kernels: they write pairs, fallback hits, op counts and CIGAR slots (and the
+    // arena of longer CIGARs) straight into pinned host memory, and the last wave of the batch's last launch
+    // publishes the two summary words there as well.  Device-to-host copies queued after a kernel are carried out
+    // by copy kernels, which get no compute unit while other contexts' device-filling persistent kernels run -- with
+    // eight paired-end batches in flight every batch's results sat on the device until the device had a gap: 8 M
+    // pairs took 9.5 s end to end for 3.7 s of kernel work (profiles/r04_pe_e2e_variants_before.log).
+    const uint32_t stride = kPeHostSlotOps;
+    abm_pair *h_pair = nullptr;
+    abm_hit *h_se1 = nullptr, *h_se2 = nullptr;
     auto run = [&](uint64_t m, const char *b1, uint64_t nb1, const uint64_t *o1, const char *b2, uint64_t nb2,
-                   const uint64_t *o2, uint32_t stride) {
+                   const uint64_t *o2) {
       ctx->blob.reserve(std::max<uint64_t>(nb1, 1));
       ctx->blob2.reserve(std::max<uint64_t>(nb2, 1));
       ctx->off.reserve(m + 1);
       ctx->off2.reserve(m + 1);
-      ctx->pe_out.reserve(m * 5);  // 20 B pairs + 8 B + 8 B, in units of 8 B Hit
-      ctx->cig_n.reserve(m);
-      ctx->cig_n2h.reserve(m);
+      ctx->h_pe_out.reserve(m * 5);  // 20 B pairs + 8 B + 8 B, in units of 8 B
+      ctx->h_cn.reserve(m); ctx->h_cn2.reserve(m);
+      ctx->h_slots.reserve(m * stride); ctx->h_slots2.reserve(m * stride);
       ctx->status.reserve(1);
-      ctx->cig.reserve(m * stride);
-      ctx->cig2h.reserve(m * stride);
       if (nb1) HIPCHK(hipMemcpyAsync(ctx->blob.p, b1, nb1, hipMemcpyHostToDevice, st));
       if (nb2) HIPCHK(hipMemcpyAsync(ctx->blob2.p, b2, nb2, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(ctx->off.p, o1, (m + 1) * 8, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(ctx->off2.p, o2, (m + 1) * 8, hipMemcpyHostToDevice, st));
-      char *outb = reinterpret_cast<char *>(ctx->pe_out.p);
-      d_pair = reinterpret_cast<abm_pair *>(outb);
-      d_se1 = reinterpret_cast<abm_hit *>(outb + m * 20 + (8 - (m * 20) % 8) % 8);
-      d_se2 = d_se1 + m;
+      char *outb = reinterpret_cast<char *>(ctx->h_pe_out.p);
+      h_pair = reinterpret_cast<abm_pair *>(outb);
+      h_se1 = reinterpret_cast<abm_hit *>(outb + m * 20 + (8 - (m * 20) % 8) % 8);
+      h_se2 = h_se1 + m;
       HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4, st));
-      HIPCHK(hipMemsetAsync(ctx->cig_n.p, 0, m * 4, st));
-      HIPCHK(hipMemsetAsync(ctx->cig_n2h.p, 0, m * 4, st));
+      // (every pair's counts are written by exactly one launch; zeroed all the same, like the device arrays were)
+      std::memset(ctx->h_cn.p, 0, m * 4);
+      std::memset(ctx->h_cn2.p, 0, m * 4);
       // (no kernel turn here: a paired-end batch ends in a long tail of a few pairs with huge
       // candidate sets, which another context's batch fills)
-      pe_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, ctx->blob2.p, ctx->off2.p, max_len, d_pair, d_se1,
-                d_se2, ctx->cig.p, ctx->cig2h.p, stride, ctx->cig_n.p, ctx->cig_n2h.p, ctx->status.p, st);
-      uint32_t status = 0;
-      HIPCHK(hipMemcpyAsync(&status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+      ctx->host_results = true;
+      try {
+        pe_device(ctx, mode, params, m, ctx->blob.p, ctx->off.p, ctx->blob2.p, ctx->off2.p, max_len, h_pair, h_se1,
+                  h_se2, ctx->h_slots.p, ctx->h_slots2.p, stride, ctx->h_cn.p, ctx->h_cn2.p, ctx->status.p, st);
+      }
+      catch (...) { ctx->host_results = false; throw; }
+      ctx->host_results = false;
       HIPCHK(hipStreamSynchronize(st));
+      const uint32_t status = ctx->h_tail.p[1];
       if (status & ~static_cast<uint32_t>(ABM_STATUS_CIGAR_OVERFLOW | ABM_STATUS_READ_TOO_LONG))
         throw std::runtime_error("kernel reported status " + std::to_string(status));
       return status;
     };
-    const uint32_t stride = 4;
     for (;;) {
       const uint32_t status = run(n, seq_blob1 + seq_off1[0], seq_off1[n] - seq_off1[0], scan1.use, seq_blob2 + seq_off2[0],
-                                  seq_off2[n] - seq_off2[0], scan2.use, stride);
+                                  seq_off2[n] - seq_off2[0], scan2.use);
       if (!(status & ABM_STATUS_CIGAR_OVERFLOW)) break;
-      if (ctx->cig_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
-      ctx->arena_want = ctx->cig_arena.cap * 4;
+      if (ctx->h_arena.cap >= 0xFFFFFF00u) throw std::runtime_error("CIGAR arena exhausted");
+      ctx->arena_want = ctx->h_arena.cap * 4;
     }
-    ctx->h_cn.reserve(n); ctx->h_cn2.reserve(n);
-    ctx->h_slots.reserve(n * stride); ctx->h_slots2.reserve(n * stride);
-    uint32_t arena_n = 0;
-    HIPCHK(hipMemcpyAsync(out_pair, d_pair, n * sizeof(abm_pair), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out_se1, d_se1, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out_se2, d_se2, n * sizeof(abm_hit), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_cn.p, ctx->cig_n.p, n * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_cn2.p, ctx->cig_n2h.p, n * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_slots.p, ctx->cig.p, n * stride * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_slots2.p, ctx->cig2h.p, n * stride * 4ull, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&arena_n, ctx->cig_arena_count.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    ctx->h_arena.reserve(std::max<uint32_t>(arena_n, 1));
-    if (arena_n) {
-      HIPCHK(hipMemcpyAsync(ctx->h_arena.p, ctx->cig_arena.p, arena_n * 4ull, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-    }
+    const uint32_t arena_n = static_cast<uint32_t>(std::min<uint64_t>(ctx->h_tail.p[0], ctx->h_arena.cap));
+    parallel_ranges(n, [&](uint64_t lo, uint64_t hi) {
+      std::memcpy(out_pair + lo, h_pair + lo, (hi - lo) * sizeof(abm_pair));
+      std::memcpy(out_se1 + lo, h_se1 + lo, (hi - lo) * sizeof(abm_hit));
+      std::memcpy(out_se2 + lo, h_se2 + lo, (hi - lo) * sizeof(abm_hit));
+    });
     assemble_cigars(n, stride, ctx->h_cn.p, ctx->h_slots.p, ctx->h_arena.p, arena_n, out_cig_blob1, cig_capacity, out_cig_off1);
     assemble_cigars(n, stride, ctx->h_cn2.p, ctx->h_slots2.p, ctx->h_arena.p, arena_n, out_cig_blob2, cig_capacity, out_cig_off2);
   });
@@ -1402,12 +1432,12 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
       const uint32_t stride = 4;
       ctx->blob.reserve(n * L); ctx->off.reserve(n + 1);
       ctx->packed.reserve(n * 4 * W); ctx->lens.reserve(n); ctx->order.reserve(n); ctx->cls.reserve(n); ctx->class33.reserve(33);
-      ctx->cig.reserve(n * stride); ctx->cig_n.reserve(n); ctx->status.reserve(1);
-      ctx->cig_arena.reserve(std::max<size_t>(1u << 16, (paired ? 2 : 1) * n)); ctx->cig_arena_count.reserve(1);
-      ctx->h_cn.reserve(n); ctx->h_slots.reserve(n * stride);
+      ctx->status.reserve(1); ctx->cig_arena_count.reserve(1);
+      if (!paired) { ctx->cig.reserve(n * stride); ctx->cig_n.reserve(n); ctx->cig_arena.reserve(std::max<size_t>(1u << 16, 2 * n)); }
+      ctx->h_cn.reserve(n); ctx->h_slots.reserve(n * (paired ? kPeHostSlotOps : stride));
       // (what se_device asks for: growing any buffer later frees the old one, and hipFree / hipHostFree wait for the whole
       // device -- i.e. for the other context's mapping kernel -- with the runtime's lock held)
-      ctx->h_arena.reserve(std::max<size_t>({ctx->arena_want, size_t(1) << 16, static_cast<size_t>(n)}));
+      ctx->h_arena.reserve(std::max<size_t>({ctx->arena_want, size_t(1) << 16, static_cast<size_t>(paired ? 4 * n : 2 * n)}));
       if (!paired) {
         ctx->res.reserve(n); ctx->h_res.reserve(n);
         // (slices of at least 4096 reads; smaller ones make these buffers grow, which only tests do)
@@ -1419,8 +1449,9 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
         ctx->blob2.reserve(n * L); ctx->off2.reserve(n + 1);
         ctx->packed2.reserve(n * 4 * W); ctx->lens2.reserve(n);
         ctx->need_big.reserve(n); ctx->subset.reserve(n); ctx->subset_count.reserve(1);
-        ctx->pe_out.reserve(n * 5); ctx->cig2h.reserve(n * stride); ctx->cig_n2h.reserve(n);
-        ctx->h_cn2.reserve(n); ctx->h_slots2.reserve(n * stride);
+        ctx->h_pe_out.reserve(n * 5);
+        ctx->h_slots.reserve(n * kPeHostSlotOps);
+        ctx->h_cn2.reserve(n); ctx->h_slots2.reserve(n * kPeHostSlotOps);
       }
     }
     // a handful of reads through the real entry point: loads the code object, sizes the launch-shape caches

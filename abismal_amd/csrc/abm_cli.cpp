@@ -990,9 +990,10 @@ int cmd_map(int argc, char **argv) {
   const bool virtual_gpus = opt.host_ceiling;
   // (paired-end: a batch ends in a tail of a few pairs with huge candidate sets that keep single waves busy for a second or
   // two after the rest is done -- DESIGN 4.3 -- so many smaller batches are kept in flight, each on a context of its own,
-  // and their tails overlap: bench.py's kernel loop runs 16; with 3 batches of 2 M pairs an end-to-end run of 2 M pairs
-  // took 3.8 s for 0.9 s of kernel work, profiles/r04_bench_pe_e2e_before.json)
-  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 8 : 2);
+  // and their tails overlap: 16, as in bench.py's kernel loop.  8 M pairs 2x150 end to end on one GPU, kernels' own rate
+  // 4.3 M reads/s: 3 contexts x 2 M pairs 2.55 M reads/s, 4 x 1 M 2.83, 8 x 1 M 3.3-3.4, 12 x 512 k 3.66, 16 x 1 M 3.72
+  // (profiles/r04_pe_e2e_variants.log); a context's tier-2 workspaces are ~8 GB of HBM)
+  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 16 : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");

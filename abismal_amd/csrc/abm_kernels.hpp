@@ -87,6 +87,11 @@ struct PeArgs {
   u8 *long_tb;
   u32 *long_ctmp;
   u64 long_tb_bytes;
+  // optional (host entry point): waves that have run to their end (zero at launch), the last of which writes
+  // {arena count, status} to host_tail (pinned host memory) -- as in SeArgs: results that lie in pinned memory need
+  // no device-to-host copy after the kernels
+  u32 *finished;
+  u32 *host_tail;
 };
 
 // bytes the traceback table needs beyond the LDS it overlays (genome-window slots 1.. and the

@@ -813,7 +813,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   // production kernel does not (they cost it registers: 100 -> 64 bytes per lane of scratch without them)
   constexpr bool TALLY = TIMED || Set::kAppend;
   // direct narrowing of big ranges: in the pair kernels only (see narrow_direct)
-  constexpr bool kDirect = Set::kAppend ? ABM_PE_DIRECT_NARROWING : ABM_SE_DIRECT_NARROWING;
+  constexpr bool kDirect = Set::kAppend ? ABM_PE_DIRECT_NARROWING : false;
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
   if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
     for (u32 k = lane; k < (1u << kPosCacheBits); k += 64) lds.pcache[k] = 0;

@@ -795,6 +795,15 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   }
   if (lane == 0 && (w.overflow || too_long))
     atomicOr(a.status, (w.overflow ? 1u : 0u) | (too_long ? 2u : 0u));
+  if (a.host_tail != nullptr && lane == 0) {  // the last wave to get here publishes the launch's two summary words
+    __threadfence();
+    const u32 before = atomicAdd(a.finished, 1u);
+    if (before + 1u == gridDim.x) {
+      __threadfence();
+      a.host_tail[0] = __hip_atomic_load(a.cig_arena_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.host_tail[1] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // compact the pairs flagged by tier 1 into a list for tier 2, heaviest weight class first (a

@@ -465,24 +465,48 @@ struct Record {
 
 template <class S> void put_bam_record(S &o, const Record &r);
 thread_local bool t_bam = false;  // formatter threads switch put_record to BAM encoding
+// digits of v at w, returns one past them
+inline char *write_uint(char *w, uint64_t v) {
+  char buf[24];
+  int k = 24;
+  do { buf[--k] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+  std::memcpy(w, buf + k, static_cast<size_t>(24 - k));
+  return w + (24 - k);
+}
 template <class S> void put_record(S &o, const Chroms &ch, const Record &r) {
   if (t_bam) { put_bam_record(o, r); return; }
-  o.append(r.name->p, r.name->n); o += '\t'; put_uint(o, r.flag); o += '\t';
-  o += ch.names[r.tid + 1]; o += '\t'; put_uint(o, static_cast<uint64_t>(r.pos) + 1); o.append("\t255\t", 5);
-  for (size_t i = 0; i < r.n_cig; ++i) { put_uint(o, r.cig[i] >> 4); o += "MIDNSHP=XB"[std::min<uint32_t>(r.cig[i] & 15u, 9)]; }
-  o += '\t';
-  if (r.mtid < 0) o.append("*\t0\t", 4);
+  // one reservation for the whole line (its longest possible form), then plain pointer writes: a line is a dozen short
+  // fields, and appending them one by one through the buffer's capacity checks was a third of the formatting time
+  const std::string &chrom = ch.names[r.tid + 1];
+  const std::string *mate = r.mtid < 0 || r.mtid == r.tid ? nullptr : &ch.names[r.mtid + 1];
+  const size_t at0 = o.size();
+  o.resize(at0 + r.name->n + chrom.size() + (mate ? mate->size() : 1) + r.n_cig * 12 + r.n_seq + 128);
+  char *w = &o[at0];
+  std::memcpy(w, r.name->p, r.name->n); w += r.name->n; *w++ = '\t';
+  w = write_uint(w, r.flag); *w++ = '\t';
+  std::memcpy(w, chrom.data(), chrom.size()); w += chrom.size(); *w++ = '\t';
+  w = write_uint(w, static_cast<uint64_t>(r.pos) + 1);
+  std::memcpy(w, "\t255\t", 5); w += 5;
+  for (size_t i = 0; i < r.n_cig; ++i) { w = write_uint(w, r.cig[i] >> 4); *w++ = "MIDNSHP=XB"[std::min<uint32_t>(r.cig[i] & 15u, 9)]; }
+  *w++ = '\t';
+  if (r.mtid < 0) { std::memcpy(w, "*\t0\t", 4); w += 4; }
   else {
-    if (r.mtid == r.tid) o += '='; else o += ch.names[r.mtid + 1];
-    o += '\t'; put_uint(o, static_cast<uint64_t>(r.mpos) + 1); o += '\t';
+    if (!mate) *w++ = '=';
+    else { std::memcpy(w, mate->data(), mate->size()); w += mate->size(); }
+    *w++ = '\t'; w = write_uint(w, static_cast<uint64_t>(r.mpos) + 1); *w++ = '\t';
   }
-  put_int(o, r.tlen); o += '\t';
-  const size_t at = o.size();
-  o.resize(at + r.n_seq);
-  char *dst = &o[at];
-  if (r.rc) for (size_t i = 0; i < r.n_seq; ++i) dst[i] = kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])];
-  else for (size_t i = 0; i < r.n_seq; ++i) dst[i] = kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
-  o.append("\t*\tNM:i:", 8); put_int(o, r.nm); o.append("\tCV:A:", 6); o += r.cv; o += '\n';
+  if (r.tlen < 0) { *w++ = '-'; w = write_uint(w, static_cast<uint64_t>(-static_cast<int64_t>(r.tlen))); }
+  else w = write_uint(w, static_cast<uint64_t>(r.tlen));
+  *w++ = '\t';
+  if (r.rc) for (size_t i = 0; i < r.n_seq; ++i) w[i] = kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])];
+  else for (size_t i = 0; i < r.n_seq; ++i) w[i] = kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
+  w += r.n_seq;
+  std::memcpy(w, "\t*\tNM:i:", 8); w += 8;
+  if (r.nm < 0) { *w++ = '-'; w = write_uint(w, static_cast<uint64_t>(-static_cast<int64_t>(r.nm))); }
+  else w = write_uint(w, static_cast<uint64_t>(r.nm));
+  std::memcpy(w, "\tCV:A:", 6); w += 6;
+  *w++ = r.cv; *w++ = '\n';
+  o.resize(static_cast<size_t>(w - &o[0]));
 }
 
 // ---- BAM (-B): the same records as binary BAM in BGZF blocks (SAM spec 4.2 / 4.1) ------------------

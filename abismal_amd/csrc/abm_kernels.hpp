@@ -92,6 +92,10 @@ struct PeArgs {
   // no device-to-host copy after the kernels
   u32 *finished;
   u32 *host_tail;
+  // tier 1 only: pairs whose weight class (the ordering kernels' log2 of the first seed buckets' occupancy) is at least
+  // big_class go to tier 2 at once, without being started in tier 1 (0 = none: every pair is tried in tier 1 first)
+  const u8 *cls;
+  u32 big_class;
 };
 
 // bytes the traceback table needs beyond the LDS it overlays (genome-window slots 1.. and the

@@ -665,6 +665,12 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     const u64 it = it_next;
     it_next = next_item();
     const u64 r = BIG ? static_cast<u64>(a.subset[it]) : (a.order ? static_cast<u64>(a.order[it]) : it);
+    if constexpr (!BIG) {
+      if (a.big_class != 0 && a.cls[r] >= a.big_class) {  // (predicted to outgrow tier 1's lists: not started here)
+        if (lane == 0) a.need_big[r] = 1;
+        continue;
+      }
+    }
     w.L[0] = a.lens1[r];
     w.L[1] = a.lens2[r];
     if (w.L[0] > kMaxReadLen || w.L[1] > kMaxReadLen) { too_long = true; w.L[0] = w.L[1] = 0; }

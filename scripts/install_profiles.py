@@ -91,6 +91,15 @@ if os.path.exists(r_csv):
                      "counters": acc, "hbm_read_bytes_per_launch": rb, "kernel_seconds_under_pmc": secs_r, "build": build,
                      "note": "as the single-end pass, over `python3 bench.py --mode random --read-len 150 --reads 4000000 --steps 1 --warmup 0`"}
     json.dump(extra["r150"], open(os.path.join(dst, f"{tag}_traffic_rpbat150.json"), "w"), indent=1)
+who_csv = os.path.join(src, "pmc_who_map_se.csv")
+if os.path.exists(who_csv):
+    shutil.copy(who_csv, os.path.join(dst, f"{tag}_pmc_who_map_se.csv"))
+    acc = {}
+    for row in csv.reader(open(who_csv)):
+        r = dict(zip(hdr, row))
+        if "map_se_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] not in acc:
+            acc[r["Counter_Name"]] = int(float(r["Counter_Value"]))
+    extra["who"] = acc
 rows = list(csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv"))))[:6]
 calls_note = ""
 cpath = os.path.join(src, "map_se_calls.csv")
@@ -151,5 +160,8 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
     if "r150" in extra:
         f.write(f"\n150 bp random PBAT (config 5, `{tag}_traffic_rpbat150.json`): {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 1e9:.2f} G read requests per launch of 4 M reads "
                 f"= {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 4e6:.0f} lines per read.\n")
+    if "who" in extra:
+        w = extra["who"]
+        f.write(f"\nWho asks the L2s (single-end kernel, one launch of 10 M reads, `{tag}_pmc_who_map_se.csv`): " + ", ".join(f"{k} {v / 1e9:.2f} G" for k, v in w.items()) + ".\n")
     f.write(f"\nBuild: {build}.\n")
 print(open(os.path.join(dst, f"{tag}_README.md")).read())

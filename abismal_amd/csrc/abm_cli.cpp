@@ -523,43 +523,177 @@ inline int reg2bin(int64_t beg, int64_t end) {
   if (beg >> 26 == end >> 26) return static_cast<int>(((1 << 3) - 1) / 7 + (beg >> 26));
   return 0;
 }
+// 4-bit BAM base codes of what SEQ shows (kSeq.fwd / kSeq.rc, then htslib's seq_nt16_table)
+struct Seq4Tables {
+  unsigned char fwd[256], rc[256];
+  Seq4Tables() {
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    for (int c = 0; c < 256; ++c) {
+      const char *qf = std::strchr(nt16, kSeq.fwd[c]), *qr = std::strchr(nt16, kSeq.rc[c]);
+      fwd[c] = static_cast<unsigned char>(qf && kSeq.fwd[c] ? qf - nt16 : 15);
+      rc[c] = static_cast<unsigned char>(qr && kSeq.rc[c] ? qr - nt16 : 15);
+    }
+  }
+};
+const Seq4Tables kSeq4;
 template <class S> void put_bam_record(S &o, const Record &r) {
-  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  // (one reservation for the record, then pointer writes, as for the SAM line)
   const size_t start = o.size();
-  put_le32(o, 0);  // block_size, patched below
-  put_le32(o, static_cast<uint32_t>(r.tid));
-  put_le32(o, r.pos);
+  const size_t l_seq = r.n_seq, packed = (l_seq + 1) / 2;
+  o.resize(start + 36 + r.name->n + 1 + 4 * r.n_cig + packed + l_seq + 16);
+  unsigned char *w = reinterpret_cast<unsigned char *>(&o[start]);
+  auto le32w = [&](uint32_t v) { w[0] = static_cast<unsigned char>(v); w[1] = static_cast<unsigned char>(v >> 8); w[2] = static_cast<unsigned char>(v >> 16); w[3] = static_cast<unsigned char>(v >> 24); w += 4; };
+  auto le16w = [&](uint32_t v) { w[0] = static_cast<unsigned char>(v); w[1] = static_cast<unsigned char>(v >> 8); w += 2; };
+  unsigned char *const size_at = w;
+  le32w(0);  // block_size, patched below
+  le32w(static_cast<uint32_t>(r.tid));
+  le32w(r.pos);
   const uint32_t rl = ref_len(r.cig, r.n_cig);
-  o += static_cast<char>(r.name->n + 1);
-  o += static_cast<char>(255);
-  put_le16(o, static_cast<uint16_t>(reg2bin(r.pos, static_cast<int64_t>(r.pos) + (rl ? rl : 1))));
-  put_le16(o, static_cast<uint16_t>(r.n_cig));
-  put_le16(o, r.flag);
-  put_le32(o, static_cast<uint32_t>(r.n_seq));
-  put_le32(o, static_cast<uint32_t>(r.mtid));
-  put_le32(o, r.mtid < 0 ? 0xFFFFFFFFu : r.mpos);
-  put_le32(o, static_cast<uint32_t>(r.tlen));
-  o.append(r.name->p, r.name->n); o += '\0';
-  for (size_t i = 0; i < r.n_cig; ++i) put_le32(o, r.cig[i]);
-  auto code = [&](size_t i) -> int {
-    const char c = r.rc ? kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])] : kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
-    const char *q = std::strchr(nt16, c);
-    return q ? static_cast<int>(q - nt16) : 15;
-  };
-  for (size_t i = 0; i < r.n_seq; i += 2)
-    o += static_cast<char>((code(i) << 4) | (i + 1 < r.n_seq ? code(i + 1) : 0));
-  o.append(r.n_seq, static_cast<char>(0xFF));
-  o.append("NM", 2);  // bam_aux_update_int: smallest type that holds the value
-  if (r.nm >= 0 && r.nm <= 255) { o += 'C'; o += static_cast<char>(r.nm); }
-  else if (r.nm >= 0) { o += 'S'; put_le16(o, static_cast<uint16_t>(r.nm)); }
-  else if (r.nm >= -128) { o += 'c'; o += static_cast<char>(r.nm); }
-  else { o += 's'; put_le16(o, static_cast<uint16_t>(static_cast<int16_t>(r.nm))); }
-  o.append("CVA", 3); o += r.cv;
-  const uint32_t bs = static_cast<uint32_t>(o.size() - start - 4);
-  o[start] = static_cast<char>(bs); o[start + 1] = static_cast<char>(bs >> 8); o[start + 2] = static_cast<char>(bs >> 16); o[start + 3] = static_cast<char>(bs >> 24);
+  *w++ = static_cast<unsigned char>(r.name->n + 1);
+  *w++ = 255;
+  le16w(static_cast<uint32_t>(reg2bin(r.pos, static_cast<int64_t>(r.pos) + (rl ? rl : 1))));
+  le16w(static_cast<uint32_t>(r.n_cig));
+  le16w(r.flag);
+  le32w(static_cast<uint32_t>(l_seq));
+  le32w(static_cast<uint32_t>(r.mtid));
+  le32w(r.mtid < 0 ? 0xFFFFFFFFu : r.mpos);
+  le32w(static_cast<uint32_t>(r.tlen));
+  std::memcpy(w, r.name->p, r.name->n); w += r.name->n; *w++ = 0;
+  for (size_t i = 0; i < r.n_cig; ++i) le32w(r.cig[i]);
+  const unsigned char *s = reinterpret_cast<const unsigned char *>(r.seq);
+  if (r.rc)
+    for (size_t i = 0; i < l_seq; i += 2)
+      *w++ = static_cast<unsigned char>((kSeq4.rc[s[l_seq - 1 - i]] << 4) | (i + 1 < l_seq ? kSeq4.rc[s[l_seq - 2 - i]] : 0));
+  else
+    for (size_t i = 0; i < l_seq; i += 2)
+      *w++ = static_cast<unsigned char>((kSeq4.fwd[s[i]] << 4) | (i + 1 < l_seq ? kSeq4.fwd[s[i + 1]] : 0));
+  std::memset(w, 0xFF, l_seq); w += l_seq;
+  *w++ = 'N'; *w++ = 'M';  // bam_aux_update_int: smallest type that holds the value
+  if (r.nm >= 0 && r.nm <= 255) { *w++ = 'C'; *w++ = static_cast<unsigned char>(r.nm); }
+  else if (r.nm >= 0) { *w++ = 'S'; le16w(static_cast<uint32_t>(r.nm)); }
+  else if (r.nm >= -128) { *w++ = 'c'; *w++ = static_cast<unsigned char>(r.nm); }
+  else { *w++ = 's'; le16w(static_cast<uint32_t>(static_cast<uint16_t>(static_cast<int16_t>(r.nm)))); }
+  *w++ = 'C'; *w++ = 'V'; *w++ = 'A'; *w++ = static_cast<unsigned char>(r.cv);
+  const size_t end = static_cast<size_t>(reinterpret_cast<char *>(w) - &o[0]);
+  const uint32_t bs = static_cast<uint32_t>(end - start - 4);
+  size_at[0] = static_cast<unsigned char>(bs); size_at[1] = static_cast<unsigned char>(bs >> 8); size_at[2] = static_cast<unsigned char>(bs >> 16); size_at[3] = static_cast<unsigned char>(bs >> 24);
+  o.resize(end);
 }
 // raw bytes -> BGZF blocks (each an independent gzip member with the BC extra field)
-int g_bgzf_level = 1;  // deflate level of BAM output (-z): decoded content is the same at every level
+int g_bgzf_level = 1;  // deflate level of BAM output (-z): 1 = the fast encoder below, 0 = stored, 2..9 = zlib; decoded content is the same at every level
+// ---- a fast deflate for BGZF blocks (-z 1, the default) ---------------------------------------------------------------
+// zlib at level 1 costs 1.15 us of CPU per 100-base record (BAM through 16 CPUs: 13.6 M reads/s, profiles/r04_host_ceiling.log)
+// -- more than everything else the host does per read, six times over.  A BAM record stream is an easy input: runs (the
+// 0xFF of absent qualities), fields repeated from the record before, 4-bit sequence that does not compress.  This encoder
+// takes one greedy match per position from a single-probe hash of the last occurrence of each 4-byte string and writes
+// ONE block with the fixed Huffman code (RFC 1951 3.2.6: no trees to build or ship); whatever inflates it gets the same
+// bytes back.  Returns the compressed size, or 0 if `cap` does not suffice (the caller then stores the block).
+struct FastDeflate {
+  // fixed code, bit-reversed for the LSB-first stream: literal / length symbol -> (code, bits); length -> (symbol, extra)
+  uint16_t lit_code[288];
+  uint8_t lit_bits[288];
+  uint16_t len_sym[259];
+  uint8_t len_extra_bits[259];
+  uint16_t len_extra_val[259];
+  uint8_t dist_sym_small[513];  // distances 1..512 -> symbol; beyond: by the distance's top bits
+  static uint32_t rev(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; ++i) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
+  FastDeflate() {
+    for (int s = 0; s < 288; ++s) {
+      uint32_t code; int bits;
+      if (s < 144) { code = 0x30 + s; bits = 8; }
+      else if (s < 256) { code = 0x190 + (s - 144); bits = 9; }
+      else if (s < 280) { code = s - 256; bits = 7; }
+      else { code = 0xC0 + (s - 280); bits = 8; }
+      lit_code[s] = static_cast<uint16_t>(rev(code, bits));
+      lit_bits[s] = static_cast<uint8_t>(bits);
+    }
+    static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    for (int len = 3; len <= 258; ++len) {
+      int k = 28;
+      while (base[k] > len) --k;
+      if (len == 258) k = 28;
+      len_sym[len] = static_cast<uint16_t>(257 + k);
+      len_extra_bits[len] = extra[k];
+      len_extra_val[len] = static_cast<uint16_t>(len - base[k]);
+    }
+    for (int d = 1; d <= 512; ++d) dist_sym_small[d] = static_cast<uint8_t>(dist_symbol_slow(static_cast<uint32_t>(d)));
+  }
+  static int dist_symbol_slow(uint32_t d) {
+    static const uint16_t base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    int k = 29;
+    while (base[k] > d) --k;
+    return k;
+  }
+  size_t operator()(const unsigned char *src, size_t n, unsigned char *dst, size_t cap, uint16_t *table /*[1 << 13], zeroed by this call*/) const {
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dextra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    if (n > 0xFFFF || cap < 16) return 0;
+    std::memset(table, 0, sizeof(uint16_t) << 13);
+    uint64_t acc = 0;
+    int nbits = 0;
+    unsigned char *out = dst, *const out_end = dst + cap - 16;
+    auto put = [&](uint32_t v, int b) {
+      acc |= static_cast<uint64_t>(v) << nbits;
+      nbits += b;
+      if (nbits >= 32) { std::memcpy(out, &acc, 4); out += 4; acc >>= 32; nbits -= 32; }
+    };
+    put(1, 1);  // BFINAL
+    put(1, 2);  // BTYPE = 01, fixed Huffman
+    size_t i = 0;
+    const size_t last_hashable = n >= 4 ? n - 4 : 0;
+    while (i < n) {
+      if (out > out_end) return 0;
+      size_t mlen = 0, mdist = 0;
+      if (n >= 4 && i <= last_hashable) {
+        uint32_t w;
+        std::memcpy(&w, src + i, 4);
+        const uint32_t h = (w * 2654435761u) >> 19;
+        const size_t cand = table[h];  // position + 1 of the last string with this hash; 0 = none
+        table[h] = static_cast<uint16_t>(i + 1);
+        if (cand != 0) {
+          const size_t p = cand - 1;
+          uint32_t v;
+          std::memcpy(&v, src + p, 4);
+          if (v == w && i - p <= 32768) {
+            const size_t lim = std::min<size_t>(258, n - i);
+            size_t l = 4;
+            while (l + 8 <= lim) {
+              uint64_t a, b;
+              std::memcpy(&a, src + p + l, 8);
+              std::memcpy(&b, src + i + l, 8);
+              if (a != b) { l += static_cast<size_t>(__builtin_ctzll(a ^ b) >> 3); break; }
+              l += 8;
+            }
+            if (l + 8 > lim) while (l < lim && src[p + l] == src[i + l]) ++l;
+            mlen = std::min(l, lim);
+            mdist = i - p;
+          }
+        }
+      }
+      if (mlen >= 4) {
+        const uint32_t ls = len_sym[mlen];
+        put(lit_code[ls], lit_bits[ls]);
+        if (len_extra_bits[mlen]) put(len_extra_val[mlen], len_extra_bits[mlen]);
+        const int ds = mdist <= 512 ? dist_sym_small[mdist] : dist_symbol_slow(static_cast<uint32_t>(mdist));
+        put(rev(static_cast<uint32_t>(ds), 5), 5);
+        if (dextra[ds]) put(static_cast<uint32_t>(mdist - dbase[ds]), dextra[ds]);
+        // (the strings inside the match are not entered into the table: the next record repeats this one's fields at
+        // the positions where matches begin)
+        i += mlen;
+      }
+      else {
+        put(lit_code[src[i]], lit_bits[src[i]]);
+        ++i;
+      }
+    }
+    put(lit_code[256], lit_bits[256]);  // end of block
+    while (nbits > 0) { if (out >= dst + cap) return 0; *out++ = static_cast<unsigned char>(acc); acc >>= 8; nbits -= 8; }
+    return static_cast<size_t>(out - dst);
+  }
+};
+const FastDeflate kFastDeflate;
+
 // One deflate state and one block buffer per thread, reset per block: deflateInit2 allocates a quarter of a megabyte,
 // and a hundred formatter threads doing that once per 64 KB block spent six times their compression time waiting on
 // the allocator (profiles/r04_host_ceiling.log: -B busy 384 s for 60 s of CPU).
@@ -582,16 +716,22 @@ template <class A, class B> void bgzf_compress(const A &raw, B &out) {
   constexpr size_t kBlock = 0xff00;
   thread_local BgzfDeflater d;
   if (d.buf.empty()) d.buf.resize(compressBound(kBlock) + 64);
+  thread_local std::vector<uint16_t> hash_table(size_t(1) << 13);
   for (size_t at = 0; at < raw.size(); at += kBlock) {
     const size_t len = std::min(kBlock, raw.size() - at);
-    d.prepare(g_bgzf_level);
-    z_stream &zs = d.zs;
-    zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(raw.data() + at));
-    zs.avail_in = static_cast<uInt>(len);
-    zs.next_out = d.buf.data();
-    zs.avail_out = static_cast<uInt>(d.buf.size());
-    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate failed");
-    const size_t clen = zs.total_out;
+    size_t clen = 0;
+    if (g_bgzf_level == 1)  // the fast encoder (a block it cannot fit -- incompressible input -- goes through zlib, stored)
+      clen = kFastDeflate(reinterpret_cast<const unsigned char *>(raw.data() + at), len, d.buf.data(), std::min<size_t>(d.buf.size(), 0xFFFF - 26), hash_table.data());
+    if (clen == 0) {
+      d.prepare(g_bgzf_level == 1 ? 0 : g_bgzf_level);
+      z_stream &zs = d.zs;
+      zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(raw.data() + at));
+      zs.avail_in = static_cast<uInt>(len);
+      zs.next_out = d.buf.data();
+      zs.avail_out = static_cast<uInt>(d.buf.size());
+      if (deflate(&zs, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate failed");
+      clen = zs.total_out;
+    }
     const uint32_t crc = static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(raw.data() + at), static_cast<uInt>(len)));
     static const unsigned char head[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
     out.append(reinterpret_cast<const char *>(head), 12);
@@ -2430,6 +2570,23 @@ int main(int argc, char **argv) {
     if (cmd == "map") return cmd_map(argc - 1, argv + 1);
     if (cmd == "idx") return cmd_idx(argc - 1, argv + 1);
     if (cmd == "sim") return abm::sim_main(argc - 1, argv + 1);
+    if (cmd == "bgzf") {  // abismal-amd bgzf [-z n] <in> <out>: any file as BGZF blocks, the way -B output is compressed (a test hook)
+      std::vector<std::string> pos;
+      for (int i = 2; i < argc; ++i) {
+        if (std::string(argv[i]) == "-z" && i + 1 < argc) g_bgzf_level = std::max(0, std::min(9, std::atoi(argv[++i])));
+        else pos.push_back(argv[i]);
+      }
+      if (pos.size() != 2) { std::cerr << "usage: abismal-amd bgzf [-z n] <in> <out>\n"; return EXIT_FAILURE; }
+      std::ifstream in(pos[0], std::ios::binary);
+      if (!in) throw std::runtime_error("cannot open " + pos[0]);
+      std::string raw((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>()), z;
+      bgzf_compress(raw, z);
+      static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      z.append(reinterpret_cast<const char *>(eof_block), 28);
+      std::ofstream out(pos[1], std::ios::binary);
+      out.write(z.data(), static_cast<std::streamsize>(z.size()));
+      return out ? EXIT_SUCCESS : EXIT_FAILURE;
+    }
     std::cerr << "ERROR: invalid command " << cmd << '\n';
     return EXIT_SUCCESS;
   }

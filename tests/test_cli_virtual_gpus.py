@@ -109,6 +109,49 @@ def test_bgzf_input_is_inflated_block_parallel(reads, trex_index):
     assert r.returncode != 0 and ("BGZF" in r.stderr or "reads file" in r.stderr), r.stderr
 
 
+def test_bgzf_blocks_of_the_fast_deflate_inflate_to_their_input(tmp_path):
+    # -B output is compressed by the CLI's own deflate at -z 1 (one fixed-Huffman block per BGZF block, greedy matches from a
+    # single-probe hash), stored at -z 0, by zlib above: `abismal-amd bgzf` runs the same code on any file.  Runs, text,
+    # BAM-like records, incompressible bytes (a block the fast encoder cannot fit is stored), tiny and empty inputs.
+    import gzip
+    import random
+    rnd = random.Random(5)
+    cases = {"empty": b"", "one": b"x", "three": b"abc", "zeros": bytes(200000), "ff": b"\xff" * 70000,
+             "text": b"".join(b"@read%d\nACGTTGCA%s\n+\nIIIIIIII\n" % (k, b"ACGT"[k % 4:k % 4 + 1] * (k % 50)) for k in range(20000)),
+             "random": bytes(rnd.getrandbits(8) for _ in range(150000)), "high": bytes(144 + rnd.getrandbits(6) for _ in range(140000)),
+             "period7": (b"abcdefg" * 30000)[:199999], "far": (bytes(rnd.getrandbits(8) for _ in range(40000)) * 4)}
+    for name, data in cases.items():
+        src, dst = tmp_path / f"{name}.bin", tmp_path / f"{name}.bgzf"
+        open(src, "wb").write(data)
+        for z in (1, 0, 6):
+            r = subprocess.run([CLI, "bgzf", "-z", str(z), str(src), str(dst)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert r.returncode == 0, r.stderr
+            assert gzip.open(dst).read() == data, (name, z)
+            raw = open(dst, "rb").read()
+            at = 0
+            while at < len(raw):  # every block a valid BGZF block of at most 64 KB
+                assert raw[at:at + 4] == b"\x1f\x8b\x08\x04" and raw[at + 12:at + 14] == b"BC"
+                bsize = raw[at + 16] | (raw[at + 17] << 8)
+                at += bsize + 1
+            assert at == len(raw)
+        if name in ("zeros", "ff", "text", "period7"):
+            assert len(open(dst, "rb").read()) < len(data) // 2, name  # (-z 6 ran last)
+
+
+def test_bam_output_is_the_same_records_at_every_level(reads, trex_index):
+    import gzip
+    fq, d = reads
+    got = {}
+    for z in (1, 0, 6):
+        run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-B", "-z", z, "-i", trex_index, "-o", d / f"z{z}.bam", fq], env=SMALL)
+        x = gzip.open(d / f"z{z}.bam").read()
+        l_text = int.from_bytes(x[4:8], "little")
+        got[z] = x[8 + l_text:]  # (the header text holds the command line)
+        assert x[:4] == b"BAM\x01"
+    assert got[1] == got[0] == got[6] and len(got[1]) > 60000 * 150
+    assert os.path.getsize(d / "z1.bam") < os.path.getsize(d / "z0.bam") // 3
+
+
 def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):
     # a library of uniformly short reads (45 bases: every read could be a ghost-bit source for the next
     # batch) made each batch carry every read seen so far.  The lead-in holds only records that are longer than

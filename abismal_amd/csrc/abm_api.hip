@@ -531,6 +531,26 @@ void assemble_cigars(uint64_t n, uint32_t stride, const uint32_t *cn, const uint
   parallel_ranges(n, fill);
 }
 
+// tier 2's per-wave workspaces in global memory: scratch table, the two lists (positions, diffs, scores), heap / sort
+// buffer, best_single log
+void pe_tier2_reserve(abm_ctx *ctx, size_t waves) {
+  const size_t cap = abm::kPeCapLarge;
+  ctx->payload2.reserve(waves * cap);
+  ctx->list2.reserve(waves * 4 * cap);
+  ctx->heap2.reserve(waves * cap);
+  ctx->log2.reserve(waves * (32 + 12 * cap));
+}
+// waves a tier-2 launch for reads of up to max_len bases can keep resident (what pe_device computes per call)
+int pe_tier2_waves(abm_ctx *ctx, abm::u32 max_len, double valid_frac) {
+  const abm::u32 eff_len = std::min<abm::u32>(std::max<abm::u32>(max_len, 1), abm::kLdsReadLen);
+  const abm::u32 W = (eff_len + 15) / 16, WB = (eff_len + 63) / 64 + 1;
+  const double size_frac = ctx->ix->h.multibit_genome ? 1.0 : valid_frac;
+  const abm::u32 GW = abm::se_window_words(eff_len, size_frac);
+  const bool coop = ctx->dix.planes[0] != nullptr && eff_len <= 8 * abm::kPlaneBlock - 64;
+  const size_t lds = abm::pe_lds_bytes(W, WB, GW, eff_len + 2, eff_len, size_frac, abm::kPeCapLarge, true);
+  return abm::pe_resident_waves(lds, true, abm::pe_waves_per_simd(lds, false, coop));
+}
+
 // The launch for a batch's pairs with an end of kLdsReadLen + 1 .. kMaxReadLen bases (map_pe_kernel<.., LONG>), after
 // tiers 1 and 2 (which treat such a pair as empty): the pairs are listed on the device, the list's length is fetched
 // (the one place the paired-end device entry point waits for the device -- only when the caller announced such ends
@@ -700,12 +720,13 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, true);
     int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
     if (const char *e = experiment_env("ABM_PE_WPS2")) { if (!ctx->phase_stamps && a.G != 0 && (e[0] == '3' || e[0] == '4')) wps = e[0] - '0'; }
-    const int waves = abm::pe_resident_waves(lds, true, wps);
+    int waves = abm::pe_resident_waves(lds, true, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
-    ctx->payload2.reserve(static_cast<size_t>(waves) * a.cap);
-    ctx->list2.reserve(static_cast<size_t>(waves) * 4 * a.cap);
-    ctx->heap2.reserve(static_cast<size_t>(waves) * a.cap);
-    ctx->log2.reserve(static_cast<size_t>(waves) * (32 + 12 * static_cast<size_t>(a.cap)));
+    // (no more waves than the batch has pairs: every wave owns 2.3 MB of lists, heap and log in global memory -- 7.6 GB for
+    // a full grid -- which a batch of a few thousand pairs, or the 32 contexts of two replicas on one device, must not ask for;
+    // abm_ctx_reserve reserves for the batch size it is told)
+    waves = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(waves), std::max<uint64_t>(n, 64)));
+    pe_tier2_reserve(ctx, static_cast<size_t>(waves));
     a.log_ws = ctx->log2.p;
     a.heap_ws = ctx->heap2.p;
     a.payload_ws = ctx->payload2.p;
@@ -1453,6 +1474,10 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
         ctx->packed2.reserve(n * 4 * W); ctx->lens2.reserve(n);
         ctx->need_big.reserve(n); ctx->subset.reserve(n); ctx->subset_count.reserve(1);
         ctx->h_pe_out.reserve(n * 5);
+        {  // tier 2's workspaces for batches of n pairs (a full grid of waves from a few thousand pairs on)
+          const int waves = pe_tier2_waves(ctx, L, 0.1);
+          if (waves > 0) pe_tier2_reserve(ctx, static_cast<size_t>(std::min<uint64_t>(static_cast<uint64_t>(waves), std::max<uint64_t>(n, 64))));
+        }
         ctx->h_slots.reserve(n * kPeHostSlotOps);
         ctx->h_cn2.reserve(n); ctx->h_slots2.reserve(n * kPeHostSlotOps);
       }

@@ -1157,7 +1157,11 @@ int cmd_map(int argc, char **argv) {
   // and their tails overlap: 16, as in bench.py's kernel loop.  8 M pairs 2x150 end to end on one GPU, kernels' own rate
   // 4.3 M reads/s: 3 contexts x 2 M pairs 2.55 M reads/s, 4 x 1 M 2.83, 8 x 1 M 3.3-3.4, 12 x 512 k 3.66, 16 x 1 M 3.72
   // (profiles/r04_pe_e2e_variants.log); a context's tier-2 workspaces are ~8 GB of HBM)
-  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? 16 : 2);
+  // (GPUs of the run that are replicas on ONE device share that device's 16)
+  int most_shared = 1;
+  for (size_t g = 0; g < dev_of.size(); ++g)
+    most_shared = std::max<int>(most_shared, static_cast<int>(std::count(dev_of.begin(), dev_of.end(), dev_of[g])));
+  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");

@@ -891,8 +891,9 @@ Options parse_map(int argc, char **argv) {
   return o;
 }
 
+unsigned default_build_threads();  // hardware threads, or what the container's CPU quota pays for (defined with CpuQuota)
 int cmd_idx(int argc, char **argv) {
-  unsigned threads = std::max(1u, std::thread::hardware_concurrency());
+  unsigned threads = default_build_threads();
   std::vector<std::string> pos;
   std::string targets;  // -A: index only these regions (src/abismalidx.cpp:51-52, :91-92)
   uint32_t window = 20;
@@ -1119,6 +1120,12 @@ struct CpuQuota {
   }
 };
 
+unsigned default_build_threads() {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const CpuQuota q;
+  return q.cpus > 0 ? std::min(hw, std::max(1u, static_cast<unsigned>(q.cpus + 0.5))) : hw;
+}
+
 int cmd_map(int argc, char **argv) {
   const Options opt = parse_map(argc, argv);
   if (opt.out.empty()) { std::cerr << "Missing required argument\n-o, -outfile\n"; return EXIT_SUCCESS; }
@@ -1132,7 +1139,7 @@ int cmd_map(int argc, char **argv) {
   std::string index_path = opt.index;
   if (index_path.empty()) {  // -g: index the genome on the fly (src/abismal.cpp:2439-2446)
     index_path = opt.out + ".tmp.idx";
-    if (abm_index_build(opt.genome.c_str(), index_path.c_str(), std::max(1u, std::thread::hardware_concurrency())) != 0) die_abm("indexing genome");
+    if (abm_index_build(opt.genome.c_str(), index_path.c_str(), default_build_threads()) != 0) die_abm("indexing genome");
   }
   abm_index *ix = nullptr;
   const auto t_index = std::chrono::steady_clock::now();
@@ -2574,6 +2581,21 @@ int main(int argc, char **argv) {
     if (cmd == "map") return cmd_map(argc - 1, argv + 1);
     if (cmd == "idx") return cmd_idx(argc - 1, argv + 1);
     if (cmd == "sim") return abm::sim_main(argc - 1, argv + 1);
+    if (cmd == "host") {  // what the host pipeline sees of the machine: NUMA nodes, cores, the container's CPU quota, its default workers
+      const Topology topo;
+      const CpuQuota quota;
+      std::cout << "numa_nodes: " << topo.n_nodes() << "\n";
+      for (int n = 0; n < topo.n_nodes(); ++n)
+        std::cout << "  node" << n << ": " << topo.primary[n].size() << " cores, " << topo.all[n].size() << " hardware threads usable\n";
+      std::cout << "pinning: " << (topo.pinning ? "on" : "off") << "\ncpu_quota_cpus: " << quota.cpus << " (0 = none)\n";
+      for (int g : {1, 2, 4, 8}) {
+        unsigned n_host = static_cast<unsigned>(std::min<size_t>(std::max<size_t>(topo.n_cores(), 1), 8u + 8u * static_cast<unsigned>(g)));
+        if (quota.cpus > 0) n_host = std::min(n_host, std::max(1u, static_cast<unsigned>(quota.cpus + 0.5)));
+        std::cout << "default host workers with " << g << " GPU(s): " << n_host << "\n";
+      }
+      std::cout << "hip_devices: " << abm_device_count() << "\n";
+      return EXIT_SUCCESS;
+    }
     if (cmd == "bgzf") {  // abismal-amd bgzf [-z n] <in> <out>: any file as BGZF blocks, the way -B output is compressed (a test hook)
       std::vector<std::string> pos;
       for (int i = 2; i < argc; ++i) {

@@ -943,7 +943,8 @@ def main():
         synth_genome_fasta(fasta, args.genome_mbp, 1234, dev)
         log(f"synthetic genome written in {time.time() - t0:.1f}s")
         t0 = time.time()
-        A.index_build(fasta, idx + ".tmp", os.cpu_count() or 1)
+        # (threads: what the container's CPU quota pays for -- 256 runnable threads on a 16-CPU pod are throttled, not faster)
+        A.index_build(fasta, idx + ".tmp", int(min(os.cpu_count() or 1, max(1, round(cpu_quota() or 1e9)))))
         os.replace(idx + ".tmp", idx)  # atomic: a waiting rank never sees a partial file
         t_build = time.time() - t0
         log(f"index built in {t_build:.1f}s ({os.path.getsize(idx) / 1e9:.2f} GB)")

@@ -174,6 +174,19 @@ def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):
     assert t["batches"] >= 20 and 1 <= t["max_lead_in_records"] <= 67, t
 
 
+def test_host_report():
+    # `abismal-amd host`: the NUMA nodes, cores and CPU quota the pipeline places its threads by, and its default worker counts
+    r = subprocess.run([CLI, "host"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = dict(ln.split(": ", 1) for ln in r.stdout.splitlines() if ": " in ln and not ln.startswith(" "))
+    assert int(rows["numa_nodes"]) >= 1
+    workers = [int(rows[f"default host workers with {g} GPU(s)"]) for g in (1, 2, 4, 8)]
+    assert workers == sorted(workers) and 1 <= workers[0] <= (os.cpu_count() or 1)
+    quota = float(rows["cpu_quota_cpus"].split()[0])
+    if quota > 0:
+        assert workers[-1] <= max(1, round(quota))
+
+
 def test_more_parts_than_mappers_is_refused(reads, trex_index):
     fq, d = reads
     r = subprocess.run([CLI, "map", "-virtual-gpus", "1", "-out-parts", "3", "-i", trex_index, "-o", str(d / "x.sam"), fq],

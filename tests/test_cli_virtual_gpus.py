@@ -150,6 +150,12 @@ def test_bam_output_is_the_same_records_at_every_level(reads, trex_index):
         assert x[:4] == b"BAM\x01"
     assert got[1] == got[0] == got[6] and len(got[1]) > 60000 * 150
     assert os.path.getsize(d / "z1.bam") < os.path.getsize(d / "z0.bam") // 3
+    # part files of BAM output: `cat` of the parts is one valid BAM (header in the first, end-of-file block in the last)
+    run(["-virtual-gpus", 2, "-out-parts", 2, "-t", 4, "-batch", 4096, "-B", "-i", trex_index, "-o", d / "p.bam", fq], env=SMALL)
+    whole = open(f"{d}/p.bam.part000", "rb").read() + open(f"{d}/p.bam.part001", "rb").read()
+    assert whole[-28:-16] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0]) and open(f"{d}/p.bam.part000", "rb").read()[-28:] != whole[-28:]
+    x = gzip.decompress(whole)
+    assert x[8 + int.from_bytes(x[4:8], "little"):] == got[1]
 
 
 def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):

@@ -72,7 +72,7 @@ if os.path.exists(pe_csv):
     pe_bytes = tiers["tier1"]["bytes"] + tiers["tier2"]["bytes"]
     extra["pe"] = {"round": rnd, "kernel": "map_pe_kernel (tier 1 + tier 2, one step)",
                    "workload": {"kind": "pe", "genome_mbp": 3100, "reads": 1000000, "read_len": 150}, "tiers": tiers,
-                   "hbm_read_bytes_per_launch": pe_bytes, "lines_per_pair": pe_bytes / 128 / 1e6, "build": build,
+                   "hbm_read_bytes_per_launch": pe_bytes, "lines_per_pair": pe_bytes / 128 / 1e6,  # (1 M pairs per step) "build": build,
                    "note": "rocprofv3 --pmc TCC_EA0_RDREQ_* in a pass of its own over `python3 bench.py --pe --reads 1000000 --read-len 150 --steps 1 "
                            "--warmup 0 --streams 1` (scripts/r04_profile.sh); per step = one tier-1 launch + one tier-2 launch"}
     json.dump(extra["pe"], open(os.path.join(dst, f"{tag}_traffic_pe.json"), "w"), indent=1)
@@ -156,7 +156,7 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
     if "pe" in extra:
         t = extra["pe"]["tiers"]
         f.write(f"\nPaired-end (config 3, `{tag}_traffic_pe.json`): tier 1 {t['tier1']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G + tier 2 "
-                f"{t['tier2']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G read requests per step of 1 M pairs = {extra['pe']['lines_per_pair'] * 1e6 / 1e3:.1f} k lines per pair.\n")
+                f"{t['tier2']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G read requests per step of 1 M pairs = {extra['pe']['lines_per_pair'] / 1e3:.1f} k lines per pair.\n")
     if "r150" in extra:
         f.write(f"\n150 bp random PBAT (config 5, `{tag}_traffic_rpbat150.json`): {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 1e9:.2f} G read requests per launch of 4 M reads "
                 f"= {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 4e6:.0f} lines per read.\n")

@@ -18,6 +18,7 @@ ap.add_argument("--wd", default="/dev/shm/abm_ceiling")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_host_ceiling.json"))
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--only", default="")
+ap.add_argument("--final", action="store_true", help="the short list: the rows DESIGN quotes")
 a = ap.parse_args()
 os.makedirs(a.wd, exist_ok=True)
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
@@ -43,8 +44,14 @@ n_reads = max(1, a.reads_m // 10) * 10_000_000
 rows = []
 
 
+FINAL = ("8 parts on tmpfs, -t 8", "8 parts on tmpfs, -t 16", "8 parts on tmpfs, -t 64", "8 parts on tmpfs, -t 256", "one tmpfs file, -t 16", "one tmpfs file, -t 64",
+         "/dev/null, -t 16", "/dev/null, -t 64", "/dev/null, -t 256", "BAM", "1 vGPU", "default -t, not pinned")
+
+
 def one(label, args, env=None, sink="tmpfs"):
     if a.only and a.only not in label:
+        return
+    if a.final and not any(k in label for k in FINAL):
         return
     rates, busy, cpu = [], None, None
     out = "/dev/null" if sink == "null" else os.path.join(a.wd, "out.sam")
@@ -96,6 +103,8 @@ one("8 vGPUs, 8 parts, -t 64, clamp OFF, not pinned", ["-virtual-gpus", "8", "-o
 one("8 vGPUs, 8 parts, default -t, not pinned", ["-virtual-gpus", "8", "-out-parts", "8"], env={"ABM_CLI_PIN": "0"})
 one("8 vGPUs, 8 parts, default -t, input through pread (no mapping)", ["-virtual-gpus", "8", "-out-parts", "8"], env={"ABM_CLI_NO_MMAP": "1"})
 one("8 vGPUs, 8 parts BAM (-B) on tmpfs, default -t", ["-virtual-gpus", "8", "-out-parts", "8", "-B"])
+one("8 vGPUs, 8 parts BAM (-B -z 2: zlib) on tmpfs, default -t", ["-virtual-gpus", "8", "-out-parts", "8", "-B", "-z", "2"])
+one("8 vGPUs, 8 parts BAM (-B -z 0: stored) on tmpfs, default -t", ["-virtual-gpus", "8", "-out-parts", "8", "-B", "-z", "0"])
 one("8 vGPUs, one BAM (-B) on tmpfs, default -t", ["-virtual-gpus", "8", "-B"])
 for f in os.listdir(a.wd):
     if f.startswith("out.sam"):

@@ -697,6 +697,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     a.cls = ctx->cls.p;
     a.big_class = 0;
     if (const char *e = experiment_env("ABM_PE_BIG_CLASS")) a.big_class = static_cast<abm::u32>(std::max(0, std::atoi(e)));
+    if (const char *e = experiment_env("ABM_PE_DIAG_SKIP")) a.diag_skip = static_cast<abm::u32>(std::max(0, std::atoi(e)));
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, false);
     int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
     if (const char *e = experiment_env("ABM_PE_WPS")) { if (!ctx->phase_stamps && a.G != 0 && (e[0] == '3' || e[0] == '4')) wps = e[0] - '0'; }

@@ -96,6 +96,10 @@ struct PeArgs {
   // big_class go to tier 2 at once, without being started in tier 1 (0 = none: every pair is tried in tier 1 first)
   const u8 *cls;
   u32 big_class;
+  // diagnosis only (ABM_EXPERIMENTS=1 ABM_PE_DIAG_SKIP=bits; results are then garbage): 1 = stop an orientation call after its
+  // two ends are seeded (no sort, scoring, mating, best_single), 2 = no sensitive passes, 4 = no single-end fallback --
+  // for counter passes that attribute memory-side requests to phases
+  u32 diag_skip;
 };
 
 // bytes the traceback table needs beyond the LDS it overlays (genome-window slots 1.. and the

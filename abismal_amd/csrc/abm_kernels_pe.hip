@@ -105,7 +105,7 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
     if (len_of(end) >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
       seed_pass<true, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
-      if (!P.overflow && P.wants_sensitive()) {
+      if (!P.overflow && P.wants_sensitive() && !(a.diag_skip & 2u)) {
         P.set_sensitive();
         seed_pass<false, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       }
@@ -526,6 +526,7 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
     seed_end<TIMED>(1, endB, true, !ar);
     if (need_big && !BIG)
       return true;
+    if (a.diag_skip & 1u) return true;
     long long t0 = 0, t1 = 0;
     if (worth[0] && worth[1]) {
       ABM_STAMP(t0);
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     Hit h1, h2;
     h1.diffs = static_cast<i16>(0.4 * w.L[0]); h1.flags = 0; h1.pos = 0;
     h2.diffs = static_cast<i16>(0.4 * w.L[1]); h2.flags = 0; h2.pos = 0;
-    if (!best.should_report(a.allow_ambig != 0)) {  // single-end fallback at half the error budget
+    if (!best.should_report(a.allow_ambig != 0) && !(a.diag_skip & 4u)) {  // single-end fallback at half the error budget
       if (BIG) { wave_sync(); w.replay_singles(); }
       long long tf0 = 0, tf1 = 0;
       ABM_STAMP(tf0);

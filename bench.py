@@ -481,8 +481,10 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     if pe_traffic:
         lines_by_source["counters_total"] = round(pe_traffic / 128 / n, 1)
         lines_by_source["not_accounted"] = round(lines_by_source["counters_total"] - lines_by_source["accounted"], 1)
-        lines_by_source["not_accounted_is"] = ("tier 2's lists, heap, sort buffer and best_single log in global memory (per-wave, touched by one wave), the "
-                                               "hand-off arrays, second lines of windows / entry pairs that straddle one, minus whatever the L2s served")
+        lines_by_source["not_accounted_is"] = ("by phase (counter passes with phases switched off, profiles/r04_pe_pmc_phases.log) 99 % of tier 1's requests are "
+                                               "the seed passes', half of them the sensitive passes': lines the tallies count once and the L2s, turned over "
+                                               "every few microseconds by the window traffic, fetch again; tier 2 adds its per-wave lists, heap, sort buffer and "
+                                               "best_single log in global memory (DESIGN.md 4.3)")
     tier_lines = [{k: round(v / done_pairs, 1) for k, v in (("candidate_windows", tier_work[t].get("candidates", 0) - tier_work[t].get("window_cache_hits", 0)),
                                                             ("seed_offset_lookups", 2 * tier_work[t].get("seed_offsets", 0)),
                                                             ("narrowing_probes", 2 * tier_work[t].get("search_probes", 0)),

@@ -45,16 +45,21 @@ traffic = {"round": rnd, "kernel": "map_se_kernel",
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 # the other configurations' passes (scripts/r04_profile.sh): paired-end (both tiers of one step) and 150 bp random PBAT
 def sum_rows(path, want):
-    acc, secs, seen = {}, 0.0, set()
+    """counters of the LAST dispatch that matches: `bench.py --pe --steps 1 --warmup 0` launches each tier twice -- one step that
+    sizes the slot's workspaces, then the timed step -- and rounds 3's figures (and this round's until the last day) added the
+    two up: 22.8 k / 18.8 k lines per pair were 11.4 k / 9.4 k"""
+    per = {}
     for row in csv.reader(open(path)):
         r = dict(zip(hdr, row))
         if not want(r["Kernel_Name"]):
             continue
-        acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0) + int(float(r["Counter_Value"]))
-        if r["Dispatch_Id"] not in seen:
-            seen.add(r["Dispatch_Id"])
-            secs += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-    return acc, secs
+        d = per.setdefault(int(r["Dispatch_Id"]), {"acc": {}, "secs": 0.0})
+        d["acc"][r["Counter_Name"]] = int(float(r["Counter_Value"]))
+        d["secs"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    if not per:
+        return {}, 0.0
+    last = per[max(per)]
+    return last["acc"], last["secs"]
 extra = {}
 pe_csv = os.path.join(src, "pmc_rdreq_map_pe.csv")
 if os.path.exists(pe_csv):
@@ -74,7 +79,8 @@ if os.path.exists(pe_csv):
                    "workload": {"kind": "pe", "genome_mbp": 3100, "reads": 1000000, "read_len": 150}, "tiers": tiers,
                    "hbm_read_bytes_per_launch": pe_bytes, "lines_per_pair": pe_bytes / 128 / 1e6,  # (1 M pairs per step) "build": build,
                    "note": "rocprofv3 --pmc TCC_EA0_RDREQ_* in a pass of its own over `python3 bench.py --pe --reads 1000000 --read-len 150 --steps 1 "
-                           "--warmup 0 --streams 1` (scripts/r04_profile.sh); per step = one tier-1 launch + one tier-2 launch"}
+                           "--warmup 0 --streams 1` (scripts/r04_profile.sh); per step = one tier-1 launch + one tier-2 launch (the LAST dispatch of each: "
+                           "the run's first step only sizes the workspaces)"}
     json.dump(extra["pe"], open(os.path.join(dst, f"{tag}_traffic_pe.json"), "w"), indent=1)
 r_csv = os.path.join(src, "pmc_rdreq_map_se_r150.csv")
 if os.path.exists(r_csv):

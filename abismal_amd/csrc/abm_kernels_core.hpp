@@ -792,9 +792,13 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-template <bool SPECIFIC, bool TIMED, bool COOP, class Set>
+// (COPY: experiment only -- -DABM_EXP_CODE_BLOAT instantiates the passes once per call of a read, to see what a kernel that
+// does not fit the instruction cache costs; the marker is an assembly comment, no instruction)
+#define ABM_COPY_MARK() do { if (COPY != 0) asm volatile("; seed_pass copy %0" ::"n"(COPY)); } while (0)
+template <bool SPECIFIC, bool TIMED, bool COOP, class Set, int COPY = 0>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
                                           u32 flags, u32 L, Set &S, WorkTally &wt, u32 &seg_epoch) {
+  ABM_COPY_MARK();
   const int lane = lane_id();
   const u64 *qpk = lds.qpk + enc * lds.W;
   const u64 *qb = lds.qbits + enc * lds.WB;
@@ -820,6 +824,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     wave_sync();
   }
   for (u32 g0 = 0; g0 < n_off && !S.sure_ambig; g0 += 64) {
+    ABM_COPY_MARK();
     ABM_STAMP(ta);
     const u32 i = g0 + lane;
     const bool live = i < n_off;
@@ -972,6 +977,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     };
     fetch_entries(0);
     for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
+      ABM_COPY_MARK();
       ABM_STAMP(tc);
       if (TIMED) { ++wt.steps; if (total - c0 <= 64) ++wt.light_steps; }
       const bool two = c0 + 64 < total;  // (uniform: this step has a b half)

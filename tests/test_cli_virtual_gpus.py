@@ -180,6 +180,25 @@ def test_lead_in_is_bounded_for_a_library_of_short_reads(reads, trex_index):
     assert t["batches"] >= 20 and 1 <= t["max_lead_in_records"] <= 67, t
 
 
+def test_tiny_and_ragged_inputs(reads, trex_index):
+    # an empty file, one record, a last line without its newline, a record cut off after its sequence line -- with one
+    # output file and with more parts than there are slices (the later regions are empty), plain and BGZF
+    fq, d = reads
+    head = open(fq).read().split("\n")
+    cases = {"empty": "", "one": "\n".join(head[:4]) + "\n", "nonl": "\n".join(head[:8]), "partial": "\n".join(head[:6]) + "\n"}
+    for name, text in cases.items():
+        open(d / f"{name}.fq", "w").write(text)
+        _write_bgzf(d / f"{name}.fq", d / f"{name}.fq.gz")
+        want = {"empty": 0, "one": 1, "nonl": 2, "partial": 2}[name]
+        for src, parts in ((f"{name}.fq", 1), (f"{name}.fq", 2), (f"{name}.fq.gz", 1)):
+            run(["-virtual-gpus", 2, "-out-parts", parts, "-t", 3, "-i", trex_index, "-o", d / "e.sam", "-s", d / "e.st", d / src])
+            files = [d / "e.sam"] if parts == 1 else [f"{d}/e.sam.part000", f"{d}/e.sam.part001"]
+            assert f"total_reads: {want}\n" in open(d / "e.st").read(), (name, src, parts)
+            assert len([ln for ln in body(files) if not ln.startswith("@")]) <= want
+            for f in files:
+                os.remove(f)
+
+
 def test_host_report():
     # `abismal-amd host`: the NUMA nodes, cores and CPU quota the pipeline places its threads by, and its default worker counts
     r = subprocess.run([CLI, "host"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -49,7 +49,8 @@ def test_virtual_gpus_write_what_one_gpu_writes(reads, trex_index):
         assert open(d / "x.st").read() == open(d / "one.st").read()
         t = json.load(open(d / "t.json"))
         assert t["out_parts"] == parts and t["gpus"] == gpus and sum(t["reads_per_gpu"]) == 60000
-        assert min(t["batches_per_gpu"]) >= 1, t  # every "GPU" was dealt batches
+        if parts >= gpus:  # (a region of its own: every "GPU" maps; GPUs that share a region race for its batches, and a
+            assert min(t["batches_per_gpu"]) >= 1, t  # virtual GPU is done with one at once)
         for f in files:
             os.remove(f)
 

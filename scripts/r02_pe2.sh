@@ -1,4 +1,5 @@
 #!/bin/bash
+export ABM_EXPERIMENTS=1  # (the experiment variables below are honoured only with this set: abm_api.hip, experiment_env)
 set -u
 export ABM_BENCH_GENOME_MBP=3100
 python -m pytest tests/test_gpu_pe_parity.py tests/test_gpu_scale_parity.py tests/test_gpu_params.py tests/test_gpu_cli_goldens.py -q -x 2>&1 | tail -4

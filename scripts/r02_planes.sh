@@ -1,4 +1,5 @@
 #!/bin/bash
+export ABM_EXPERIMENTS=1  # (the experiment variables below are honoured only with this set: abm_api.hip, experiment_env)
 # the bit-plane genome for filter + narrowing: one copy vs two half-line-shifted copies; 10 M x 100 bp at hg38 scale
 set -u
 export ABM_BENCH_GENOME_MBP=3100

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ABM_EXPERIMENTS=1  # (the experiment variables below are honoured only with this set: abm_api.hip, experiment_env)
 # the bit-plane filter for real: GPU suite, default bench line (1 M-read parity sample), launch sizes, variants
 set -u
 export ABM_BENCH_GENOME_MBP=3100

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ABM_EXPERIMENTS=1  # (the experiment variables below are honoured only with this set: abm_api.hip, experiment_env)
 # L2 / fabric read requests of map_se_kernel by size, current build, for a few environment variants
 set -u
 export TMPDIR=/tmp ABM_BENCH_GENOME_MBP=3100

@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "abm_map_se_batch", "abm_map_se_batch_sliced", "abm_ctx_slice_results", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
     "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_index_set_direct_narrowing", "abm_ctx_seed_extension", "abm_ctx_rebuild_seed_extension", "abm_device_numa_node",
+    "abm_ctx_set_pe_split", "abm_ctx_pe_split_stats", "abm_ctx_pe_timed_launches",
 ]
 
 
@@ -343,6 +344,24 @@ class Context:
             d["phase_cycles"] = dict(zip(["probe_narrow", "gather_hamming", "replay", "align", "total"],
                                          [int(x) for x in out[6:11]]))
         return d
+
+    def set_pe_split(self, split=-1, seed_cap=0, hand_entries=0):
+        """abm_ctx_set_pe_split: how paired-end batches are launched (seed / mate kernels, or one kernel per pair)"""
+        self._lib.abm_ctx_set_pe_split.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64]
+        _check(self._lib.abm_ctx_set_pe_split(self.handle, int(split), int(seed_cap), int(hand_entries)))
+
+    def pe_split_stats(self):
+        """abm_ctx_pe_split_stats: pairs by route since the last call, and the last batch's hand-over entries"""
+        out = (C.c_uint64 * 4)()
+        self._lib.abm_ctx_pe_split_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _check(self._lib.abm_ctx_pe_split_stats(self.handle, out))
+        return {"mated_from_lds": int(out[0]), "mapped_whole": int(out[1]), "mated_from_device_memory": int(out[2]),
+                "hand_over_entries_last_batch": int(out[3])}
+
+    def pe_timed_launches(self):
+        self._lib.abm_ctx_pe_timed_launches.argtypes = [C.c_void_p]
+        self._lib.abm_ctx_pe_timed_launches.restype = C.c_uint32
+        return int(self._lib.abm_ctx_pe_timed_launches(self.handle))
 
     def set_read_cycles(self, d_ptr):
         _check(self._lib.abm_ctx_set_read_cycles(self.handle, d_ptr))

@@ -139,6 +139,16 @@ struct abm_ctx {
   DevBuf<abm::u64> packed, packed2;
   DevBuf<abm::u32> lens2, subset, subset_count, payload1, payload2, list2, heap2, log2;
   DevBuf<abm::u8> need_big;
+  // the paired-end phase split (seed kernel -> hand-over area -> mate kernels; PeArgs::hand_*): list headers per pair,
+  // the lists' entries, the bump counter, the seed kernel's per-wave staging area, the second route's pair list, and
+  // {pairs by route (3), unused}
+  DevBuf<abm::u32> hand_hdr, hand_pos, stage_pos, subset_b, subset_count_b, class33_b;
+  DevBuf<abm::i16> hand_d, stage_d;
+  DevBuf<unsigned long long> hand_count, split_stats;
+  size_t hand_want = 0;  // hand-over entries to reserve at least (abm_ctx_set_pe_split)
+  int pe_split = -1;     // -1: default (split), 0: tier 1 unsplit, 1: split
+  uint32_t pe_scap = 0;  // 0: default
+  uint32_t pe_timed_launches = 0;  // HIP-event brackets the last paired-end call recorded (abm_ctx_set_timing)
   DevBuf<abm::Hit> pe_out;  // staging: pairs (20 B each) then se1, se2
   DevBuf<abm::u32> cig2h, cig_n2h;
   DevBuf<char> blob2;
@@ -691,17 +701,16 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.work = ctx->work.p;
   a.need_big = ctx->need_big.p;
   a.pair_diag = ctx->phase_stamps ? ctx->read_cycles : nullptr;
-  // tier 1: every pair, small sets in LDS
-  {
+  bool split = ctx->pe_split != 0;  // (0: tier 1 as ONE kernel per pair, as in rounds 1-4 -- same-box comparisons)
+  if (const char *e = experiment_env("ABM_PE_SPLIT")) split = e[0] != '0';
+  const size_t events_before = ctx->events_used;
+  const size_t lds1 = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, abm::kPeTier1Cap, false);
+  if (!split) {
+    // tier 1 unsplit: every pair, seeding and mating in one kernel, small sets in LDS
     a.cap = abm::kPeTier1Cap;
-    a.cls = ctx->cls.p;
-    a.big_class = 0;
-    if (const char *e = experiment_env("ABM_PE_BIG_CLASS")) a.big_class = static_cast<abm::u32>(std::max(0, std::atoi(e)));
-    if (const char *e = experiment_env("ABM_PE_DIAG_SKIP")) a.diag_skip = static_cast<abm::u32>(std::max(0, std::atoi(e)));
-    const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, false);
-    int wps = abm::pe_waves_per_simd(lds, ctx->phase_stamps, a.G != 0);
+    int wps = abm::pe_waves_per_simd(lds1, ctx->phase_stamps, a.G != 0);
     if (const char *e = experiment_env("ABM_PE_WPS")) { if (!ctx->phase_stamps && a.G != 0 && (e[0] == '3' || e[0] == '4')) wps = e[0] - '0'; }
-    const int waves = abm::pe_resident_waves(lds, false, wps);
+    const int waves = abm::pe_resident_waves(lds1, false, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 1) does not fit on this device");
     ctx->payload1.reserve(static_cast<size_t>(waves) * a.cap);
     a.payload_ws = ctx->payload1.p;
@@ -710,12 +719,68 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
     const hipEvent_t e1 = begin_timed(ctx, st);
-    HIPCHK(abm::launch_map_pe(a, lds, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, ctx->phase_stamps, wps, st));
+    HIPCHK(abm::launch_map_pe(a, lds1, static_cast<abm::u32>(std::min<uint64_t>(n, waves)), false, ctx->phase_stamps, wps, st));
     if (e1) HIPCHK(hipEventRecord(e1, st));
   }
-  // tier 2: the pairs whose candidate sets outgrew tier 1, one wave per CU, 32768-entry sets
+  else {
+    // tier 1 split by phase.  SEED: both seed passes of every orientation call's two ends, shaped like the single-end
+    // kernel (no alignment state, 6 KB of LDS per wave at 2x150); the finished lists go to the hand-over area.
+    a.cap = abm::kPeTier1Cap;
+    const abm::u32 n_slots = mode == 2 ? 8u : 4u;
+    ctx->hand_hdr.reserve(n * n_slots * 2);
+    ctx->hand_count.reserve(1);
+    if (!ctx->split_stats.p) { ctx->split_stats.reserve(4); HIPCHK(hipMemsetAsync(ctx->split_stats.p, 0, 4 * sizeof(unsigned long long), st)); }
+    abm::u32 scap = ctx->pe_scap ? ctx->pe_scap : abm::kPeTier1Cap;  // entries a list may grow to in the seed kernel (beyond kPeTier1Cap: in its staging area)
+    if (const char *e = experiment_env("ABM_PE_SCAP")) scap = static_cast<abm::u32>(std::atoi(e));
+    scap = std::min<abm::u32>(16384, std::max<abm::u32>(abm::kPeTier1Cap, scap));
+    size_t per_pair = scap > abm::kPeTier1Cap ? 256 : 64;  // hand-over entries per pair (a list that finds no room sends its pair to the whole-pair kernel)
+    if (const char *e = experiment_env("ABM_PE_HAND_PER_PAIR")) per_pair = static_cast<size_t>(std::max(4, std::atoi(e)));
+    // (abm_ctx_set_pe_split's hand_entries, when given, is taken as it is: tests run the area out of room with it)
+    const size_t hand_cap = ctx->hand_want ? std::max<size_t>(ctx->hand_want, 64) : std::min<size_t>(std::max<size_t>(n * per_pair, size_t(1) << 16), 0xFFFFFF00u);
+    ctx->hand_pos.reserve(hand_cap);
+    ctx->hand_d.reserve(hand_cap);
+    a.hand_hdr = ctx->hand_hdr.p; a.hand_pos = ctx->hand_pos.p; a.hand_d = ctx->hand_d.p;
+    a.hand_count = ctx->hand_count.p;
+    a.hand_cap = static_cast<abm::u32>(std::min<size_t>(std::min(ctx->hand_pos.cap, ctx->hand_d.cap), 0xFFFFFF00u));
+    a.split_stats = ctx->split_stats.p;
+    HIPCHK(hipMemsetAsync(ctx->hand_count.p, 0, sizeof(unsigned long long), st));
+    const size_t lds_s = abm::pe_seed_lds_bytes(W, WB, eff_len, a.cap);
+    const int waves_s = abm::pe_seed_resident_waves(lds_s, a.G != 0);
+    if (waves_s <= 0) throw HipFail("map_pe_kernel (seed) does not fit on this device");
+    const abm::u32 grid_s = static_cast<abm::u32>(std::min<uint64_t>(n, waves_s));
+    a.scap = scap;
+    if (scap > a.cap) {
+      ctx->stage_pos.reserve(static_cast<size_t>(grid_s) * scap);
+      ctx->stage_d.reserve(static_cast<size_t>(grid_s) * scap);
+      a.stage_pos = ctx->stage_pos.p; a.stage_d = ctx->stage_d.p;
+    }
+    a.payload_ws = nullptr;
+    a.list_ws = nullptr;
+    {
+      unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+      HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+      a.next_read = counter;
+      const hipEvent_t e1 = begin_timed(ctx, st);
+      HIPCHK(abm::launch_pe_seed(a, lds_s, grid_s, ctx->phase_stamps, st));
+      if (e1) HIPCHK(hipEventRecord(e1, st));
+    }
+    // MATE, small lists (every list of the pair within kPeTier1Cap entries: LDS): sort, scoring, mating, tracebacks,
+    // best_single, fallback -- instruction-bound, it overlaps with the other contexts' seed kernels
+    {
+      const size_t lds_m = abm::pe_mate_lds_bytes(W, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, false);
+      const int waves_m = abm::pe_mate_resident_waves(lds_m, false);
+      if (waves_m <= 0) throw HipFail("map_pe_kernel (mate) does not fit on this device");
+      a.order = nullptr;  // (in input order: the lists were handed over in whatever order the seed kernel finished them)
+      unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+      HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+      a.next_read = counter;
+      const hipEvent_t e1 = begin_timed(ctx, st);
+      HIPCHK(abm::launch_pe_mate(a, lds_m, static_cast<abm::u32>(std::min<uint64_t>(n, waves_m)), false, ctx->phase_stamps, st));
+      if (e1) HIPCHK(hipEventRecord(e1, st));
+    }
+  }
+  // tier 2: lists and heaps of up to 32768 entries per wave in global memory
   {
-    HIPCHK(abm::launch_collect_big(ctx->need_big.p, ctx->cls.p, n, ctx->class33.p, ctx->subset.p, ctx->subset_count.p, st));
     a.cap = abm::kPeCapLarge;
     a.order = nullptr;
     const size_t lds = abm::pe_lds_bytes(W, WB, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, true);
@@ -723,19 +788,38 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     if (const char *e = experiment_env("ABM_PE_WPS2")) { if (!ctx->phase_stamps && a.G != 0 && (e[0] == '3' || e[0] == '4')) wps = e[0] - '0'; }
     int waves = abm::pe_resident_waves(lds, true, wps);
     if (waves <= 0) throw HipFail("map_pe_kernel (tier 2) does not fit on this device");
+    const size_t lds_mb = abm::pe_mate_lds_bytes(W, a.GW, a.ctmp_cap, eff_len, size_frac, a.cap, true);
+    int waves_mb = split ? abm::pe_mate_resident_waves(lds_mb, true) : 0;
+    if (split && waves_mb <= 0) throw HipFail("map_pe_kernel (mate, tier 2) does not fit on this device");
     // (no more waves than the batch has pairs: every wave owns 2.3 MB of lists, heap and log in global memory -- 7.6 GB for
     // a full grid -- which a batch of a few thousand pairs, or the 32 contexts of two replicas on one device, must not ask for;
     // abm_ctx_reserve reserves for the batch size it is told)
     waves = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(waves), std::max<uint64_t>(n, 64)));
+    waves_mb = std::min(waves_mb, waves);  // (the two launches share the workspaces)
     pe_tier2_reserve(ctx, static_cast<size_t>(waves));
     a.log_ws = ctx->log2.p;
     a.heap_ws = ctx->heap2.p;
     a.payload_ws = ctx->payload2.p;
     a.list_ws = ctx->list2.p;
+    a.work = ctx->work.p + 16;  // tier 2 tallies separately (abm_ctx_take_work_tiers)
+    if (split) {
+      // the pairs whose lists outgrew LDS inside the seed kernel's staging area: mated from global memory (nothing is seeded twice)
+      ctx->subset_b.reserve(n); ctx->subset_count_b.reserve(1); ctx->class33_b.reserve(33);
+      HIPCHK(abm::launch_collect_big(ctx->need_big.p, ctx->cls.p, n, abm::kRouteBig, ctx->class33_b.p, ctx->subset_b.p, ctx->subset_count_b.p, st));
+      a.subset = ctx->subset_b.p; a.subset_count = ctx->subset_count_b.p;
+      unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
+      HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+      a.next_read = counter;
+      const hipEvent_t e1 = begin_timed(ctx, st);
+      HIPCHK(abm::launch_pe_mate(a, lds_mb, static_cast<abm::u32>(waves_mb), true, ctx->phase_stamps, st));
+      if (e1) HIPCHK(hipEventRecord(e1, st));
+      a.subset = ctx->subset.p; a.subset_count = ctx->subset_count.p;
+    }
+    // the pairs whose candidate sets outgrew tier 1 (the seed kernel): the whole pair again, one wave each, 32768-entry sets
+    HIPCHK(abm::launch_collect_big(ctx->need_big.p, ctx->cls.p, n, abm::kRouteWhole, ctx->class33.p, ctx->subset.p, ctx->subset_count.p, st));
     unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
-    a.work = ctx->work.p + 16;  // tier 2 tallies separately (abm_ctx_take_work_tiers)
     if (ctx->host_results && !has_long) {  // the batch's last launch: its last wave publishes arena count and status to the host
       HIPCHK(hipMemsetAsync(ctx->finished.p, 0, 4, st));
       a.finished = ctx->finished.p;
@@ -747,6 +831,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
     a.finished = nullptr;
     a.host_tail = nullptr;
   }
+  ctx->pe_timed_launches = static_cast<uint32_t>(ctx->events_used - events_before);
   if (has_long) {
     pe_long_pairs(ctx, a, n, d_blob1, d_off1, d_blob2, d_off2, std::min<abm::u32>(max_len, abm::kMaxReadLen), params->valid_frac, st);
     if (ctx->host_results) {  // (rare: with a long-end launch the two summary words are copied out after it)
@@ -1022,7 +1107,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->rep->arena = nullptr;
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_pe_out.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->hand_hdr.release(); c->hand_pos.release(); c->hand_d.release(); c->hand_count.release(); c->split_stats.release(); c->stage_pos.release(); c->stage_d.release(); c->subset_b.release(); c->subset_count_b.release(); c->class33_b.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_pe_out.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -1344,6 +1429,41 @@ int abm_ctx_slice_results(abm_ctx *ctx, uint64_t lo, uint64_t hi, abm_hit *out_r
     }
   });
 }
+
+int abm_ctx_set_pe_split(abm_ctx *ctx, int split, uint32_t seed_cap, uint64_t hand_entries) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    if (split < -1 || split > 1) throw std::invalid_argument("split: -1, 0 or 1");
+    if (seed_cap > 16384) throw std::invalid_argument("seed_cap: at most 16384");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->pe_split = split;
+    ctx->pe_scap = seed_cap;
+    ctx->hand_want = static_cast<size_t>(std::min<uint64_t>(hand_entries, 0xFFFFFF00u));
+  });
+}
+
+int abm_ctx_pe_split_stats(abm_ctx *ctx, uint64_t out[4]) {
+  return guarded([&] {
+    if (!ctx || !out) throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (ctx->split_stats.p) {
+      unsigned long long tmp[4];
+      HIPCHK(hipMemcpy(tmp, ctx->split_stats.p, sizeof(tmp), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemset(ctx->split_stats.p, 0, sizeof(tmp)));
+      for (int k = 0; k < 3; ++k) out[k] = tmp[k];
+    }
+    if (ctx->hand_count.p) {
+      unsigned long long cnt = 0;
+      HIPCHK(hipMemcpy(&cnt, ctx->hand_count.p, sizeof(cnt), hipMemcpyDeviceToHost));
+      out[3] = cnt;
+    }
+  });
+}
+
+uint32_t abm_ctx_pe_timed_launches(const abm_ctx *ctx) { return ctx ? ctx->pe_timed_launches : 0; }
 
 int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                       const char *d_seq_blob1, const uint64_t *d_seq_off1, const char *d_seq_blob2,

@@ -234,9 +234,12 @@ struct Batch {
 // that can still be such a source for reads that come later.  Indices in descending order; at most 67 per end.
 constexpr uint32_t kGhostReach = 110;
 inline uint32_t ghost_len(uint64_t len) { return len < g_min_read_len ? 0u : static_cast<uint32_t>(std::min<uint64_t>(len, kGhostReach)); }
-std::vector<uint32_t> ghost_tail(const std::vector<uint64_t> *off, size_t n, int ends) {
+// (reach: how far each end is covered by the records after these n -- a scan that continues further back in the input
+// passes the same array on; a fresh scan starts from ghost_reach_start)
+inline void ghost_reach_start(uint32_t reach[2], int ends) { reach[0] = 0; reach[1] = ends == 2 ? 0u : kGhostReach; }
+inline bool ghost_closed(const uint32_t reach[2]) { return reach[0] >= kGhostReach && reach[1] >= kGhostReach; }
+std::vector<uint32_t> ghost_tail(const std::vector<uint64_t> *off, size_t n, int ends, uint32_t reach[2]) {
   std::vector<uint32_t> out;
-  uint32_t reach[2] = {0, ends == 2 ? 0u : kGhostReach};
   for (size_t k = n; k-- > 0 && (reach[0] < kGhostReach || reach[1] < kGhostReach);) {
     bool raises = false;
     for (int e = 0; e < ends; ++e) {
@@ -246,6 +249,11 @@ std::vector<uint32_t> ghost_tail(const std::vector<uint64_t> *off, size_t n, int
     if (raises) out.push_back(static_cast<uint32_t>(k));
   }
   return out;
+}
+std::vector<uint32_t> ghost_tail(const std::vector<uint64_t> *off, size_t n, int ends) {
+  uint32_t reach[2];
+  ghost_reach_start(reach, ends);
+  return ghost_tail(off, n, ends, reach);
 }
 
 // batches are recycled with their buffers as well (a full batch's arrays are a gigabyte)
@@ -1447,6 +1455,7 @@ int cmd_map(int argc, char **argv) {
   std::vector<std::unique_ptr<Batch>> live_batches;
   uint64_t n_batches = 0;
   size_t max_lead = 0;  // the longest lead-in a batch carried (records)
+  uint64_t region_lead_scanned = 0, region_lead_records = 0;  // -out-parts: records before a region scanned for its lead-in / taken into it (largest over the regions)
   int mappers_live = n_gpus * per_gpu;
   std::vector<SlicePool> slice_pool(n_nodes);
   std::vector<BatchPool> batch_pool(n_nodes);
@@ -1866,8 +1875,13 @@ int cmd_map(int argc, char **argv) {
     const uint64_t records = (lines + 3) / 4;
     return records * static_cast<uint64_t>(r) / static_cast<uint64_t>(n_regions) / slice_reads * slice_reads;
   };
-  // the part of the input just before a region (its last kLeadRecords records) parsed for the region's lead-in
-  constexpr uint64_t kLeadRecords = 4096;
+  // the input before a region is parsed for the region's lead-in kLeadRecords records at a time, backwards, until the
+  // records found cover every position a 44-46-base read can look at (ghost_closed), the input begins, or kLeadBudget
+  // records have been looked at: the records a one-file run would still be carrying at that point (round 4
+  // looked at the last 4096 only).  A library of one read length below 110 bases never closes the scan -- its lead-in
+  // is the last record, whatever lies before -- hence the budget: a quarter of a million records are 60 ms of parsing.
+  static const uint64_t kLeadRecords = [] { const char *e = std::getenv("ABM_CLI_LEAD_RECORDS"); return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : uint64_t(4096); }();
+  static const uint64_t kLeadBudget = [] { const char *e = std::getenv("ABM_CLI_LEAD_BUDGET"); return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : uint64_t(1) << 18; }();
   auto cutter_plain = [&](int r) {
     Region &R = regions[r];
     try {
@@ -1880,25 +1894,40 @@ int cmd_map(int argc, char **argv) {
       const uint64_t end_line = 4 * end_rec;
       if (first_rec > 0) {
         // lead-in: what a 44-46-base read at the region's start finds past its end comes from the reads before it
-        const uint64_t lead_rec = first_rec > kLeadRecords ? first_rec - kLeadRecords : 0;
-        std::vector<NameRef> names; RawBuf blob[2], raw; std::vector<uint64_t> off[2];
-        for (size_t e = 0; e < nf; ++e) {
-          uint64_t a = 0, b = 0;
-          if (!offset_after_line(e, cur[e], 4 * lead_rec, a) || !offset_after_line(e, cur[e], line, b)) { done[e] = true; lo[e] = lf[e].size; continue; }
-          if (lf[e].map) parse_raw(lf[e].map + a, b - a, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
-          else {
-            raw.resize(b - a);
-            read_range(lf[e].fd, opt.reads[e], raw.p, a, b);
-            parse_raw(raw, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+        std::vector<std::string> lead[2];  // (nearest record first while it is collected)
+        uint32_t reach[2];
+        ghost_reach_start(reach, ends);
+        bool input_short = false;
+        uint64_t scanned = 0;
+        for (uint64_t upto = first_rec; upto > 0 && !ghost_closed(reach) && !input_short && scanned < kLeadBudget;) {
+          const uint64_t lead_rec = upto > kLeadRecords ? upto - kLeadRecords : 0;
+          std::vector<NameRef> names; RawBuf blob[2], raw; std::vector<uint64_t> off[2];
+          for (size_t e = 0; e < nf; ++e) {
+            Cursor c;  // (a window further back than the last one: its own cursor, from the file's first chunk)
+            uint64_t a = 0, b = 0;
+            if (!offset_after_line(e, c, 4 * lead_rec, a) || !offset_after_line(e, c, 4 * upto, b)) {
+              if (upto == first_rec) { done[e] = true; lo[e] = lf[e].size; }
+              input_short = true;
+              continue;
+            }
+            if (lf[e].map) parse_raw(lf[e].map + a, b - a, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+            else {
+              raw.resize(b - a);
+              read_range(lf[e].fd, opt.reads[e], raw.p, a, b);
+              parse_raw(raw, 4 * lead_rec, opt.reads[e], names, blob[e], off[e]);
+            }
+            if (upto == first_rec) lo[e] = b;
           }
-          lo[e] = b;
+          const size_t m = off[0].empty() ? 0 : off[0].size() - 1;
+          if (!input_short && (nf == 1 || (off[1].size() == off[0].size())))
+            for (uint32_t k : ghost_tail(off, m, ends, reach)) for (int e = 0; e < ends; ++e) lead[e].emplace_back(blob[e].data() + off[e][k], off[e][k + 1] - off[e][k]);
+          scanned += upto - lead_rec;
+          upto = lead_rec;
         }
-        std::vector<std::string> lead[2];
-        const size_t m = off[0].empty() ? 0 : off[0].size() - 1;
-        if (nf == 1 || (off[1].size() == off[0].size()))
-          for (uint32_t k : ghost_tail(off, m, ends)) for (int e = 0; e < ends; ++e) lead[e].emplace_back(blob[e].data() + off[e][k], off[e][k + 1] - off[e][k]);
         for (int e = 0; e < ends; ++e) std::reverse(lead[e].begin(), lead[e].end());
         std::lock_guard<std::mutex> lk(mu);
+        region_lead_scanned = std::max(region_lead_scanned, scanned);
+        region_lead_records = std::max<uint64_t>(region_lead_records, lead[0].size());
         R.carry[0] = std::move(lead[0]);
         R.carry[1] = std::move(lead[1]);
       }
@@ -2535,7 +2564,7 @@ int cmd_map(int argc, char **argv) {
     tj << "{\"records\": " << total_records << ", \"reads\": " << (paired ? 2 : 1) * total_records << ", \"seconds\": " << secs
        << ", \"index_load_s\": " << index_load_s << ", \"host_prepare_s\": " << host_prepare_s << ", \"gpus\": " << n_gpus << ", \"mappers_per_gpu\": " << per_gpu
        << ", \"host_threads\": " << n_host << ", \"numa_nodes\": " << n_nodes << ", \"pinned\": " << (topo.pinning ? "true" : "false")
-       << ", \"out_parts\": " << n_regions << ", \"out_bytes\": " << out_bytes << ", \"batches\": " << n_batches << ", \"max_lead_in_records\": " << max_lead
+       << ", \"out_parts\": " << n_regions << ", \"out_bytes\": " << out_bytes << ", \"batches\": " << n_batches << ", \"max_lead_in_records\": " << max_lead << ", \"region_lead_in_scanned_records\": " << region_lead_scanned << ", \"region_lead_in_records\": " << region_lead_records
        << ", \"batch_reads\": " << batch_reads << ", \"host_ceiling\": " << (virtual_gpus ? "true" : "false")
        << ", \"batches_per_gpu\": [";
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_batches[g];

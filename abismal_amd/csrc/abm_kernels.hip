@@ -208,29 +208,12 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-#ifdef ABM_EXP_CODE_BLOAT
-        // experiment: a copy of both passes per call of the read (4 x the seed-pass code: the kernel no longer fits the
-        // 64 KB instruction cache, as the pair kernels do not) -- profiles/r04_exp_se_code_bloat.log
-        auto passes = [&](auto copy) {
-          constexpr int K = decltype(copy)::value;
-          seed_pass<true, TIMED, COOP, SeSet, K>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
-          if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
-            S.cutoff = S.top_d();
-            seed_pass<false, TIMED, COOP, SeSet, K>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
-          }
-        };
-        if (cidx == 0) passes(std::integral_constant<int, 1>{});
-        else if (cidx == 1) passes(std::integral_constant<int, 2>{});
-        else if (cidx == 2) passes(std::integral_constant<int, 3>{});
-        else passes(std::integral_constant<int, 4>{});
-#else
         seed_pass<true, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         // should_do_sensitive, :367-370
         if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
           S.cutoff = S.top_d();  // set_sensitive
           seed_pass<false, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         }
-#endif
       }
       ABM_STAMP(t_a);
       choose_se<LONG>(a.ix, lds, L, a.valid_frac, S, best, cig_out, sink, n_ops, rd_overflow, n_aln, n_single);  // (n_aln, n_single: dead unless TIMED)

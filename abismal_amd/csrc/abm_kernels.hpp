@@ -92,15 +92,27 @@ struct PeArgs {
   // no device-to-host copy after the kernels
   u32 *finished;
   u32 *host_tail;
-  // tier 1 only: pairs whose weight class (the ordering kernels' log2 of the first seed buckets' occupancy) is at least
-  // big_class go to tier 2 at once, without being started in tier 1 (0 = none: every pair is tried in tier 1 first)
-  const u8 *cls;
-  u32 big_class;
-  // diagnosis only (ABM_EXPERIMENTS=1 ABM_PE_DIAG_SKIP=bits; results are then garbage): 1 = stop an orientation call after its
-  // two ends are seeded (no sort, scoring, mating, best_single), 2 = no sensitive passes, 4 = no single-end fallback --
-  // for counter passes that attribute memory-side requests to phases
-  u32 diag_skip;
+  // The phase-split launches (round 5): a SEED kernel runs both seed passes of every orientation call's two ends and
+  // hands the finished candidate lists over in global memory; MATE kernels take them from there (sort, scoring,
+  // mating, tracebacks, best_single, the single-end fallback).  Per pair and list (orientation call o, end which:
+  // slot 2 o + which of 2 n_or) two words {where the list starts in hand_pos / hand_d, entries | worth << 16 |
+  // heap_order << 17}; lists are bump-allocated from hand_count (a list that finds no room sends its pair through
+  // the whole-pair kernel).  need_big[] is the pair's route: kRouteSmall (every list fits the mate kernel's LDS),
+  // kRouteWhole (a set outgrew the seed kernel: the whole-pair kernel with its 32768-entry sets), kRouteBig (lists
+  // in global memory: the mate kernel's tier-2 form).
+  u32 *hand_hdr;                 // [n][2 n_or][2]
+  u32 *hand_pos;                 // [hand_cap]
+  i16 *hand_d;                   // [hand_cap]
+  unsigned long long *hand_count;
+  u32 hand_cap;
+  // seed kernel: a list that outgrows its LDS slot (cap entries) moves to this wave's staging area and keeps growing
+  // there, up to scap entries (scap <= cap: no staging)
+  u32 *stage_pos;                // [grid][scap]
+  i16 *stage_d;                  // [grid][scap]
+  u32 scap;
+  unsigned long long *split_stats;  // optional [4]: pairs by route (small, whole, big), [3] unused
 };
+constexpr u8 kRouteSmall = 0, kRouteWhole = 1, kRouteBig = 2;
 
 // bytes the traceback table needs beyond the LDS it overlays (genome-window slots 1.. and the
 // window cache, both idle while a traceback runs); the kernels carve exactly this much extra
@@ -114,8 +126,16 @@ size_t pe_long_lds_bytes(u32 GW);
 size_t pe_long_q_words(u32 W, u32 WB);
 int pe_long_resident_waves(u32 GW);
 hipError_t launch_map_pe_long(const PeArgs &a, u32 grid, hipStream_t st);
-hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *class33, u32 *subset, u32 *count,
+// the pairs whose route (PeArgs::need_big) is `want`, heaviest weight class first
+hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u8 want, u32 *class33, u32 *subset, u32 *count,
                               hipStream_t st);
+// the phase-split launches (seed kernel -> hand-over area -> mate kernels; abm_kernels_pe.hip)
+size_t pe_seed_lds_bytes(u32 W, u32 WB, u32 max_len, u32 cap);
+size_t pe_mate_lds_bytes(u32 W, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big);
+int pe_seed_resident_waves(size_t lds, bool coop);
+int pe_mate_resident_waves(size_t lds, bool big);
+hipError_t launch_pe_seed(const PeArgs &a, size_t lds, u32 grid, bool timed, hipStream_t st);
+hipError_t launch_pe_mate(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st);
 #ifndef ABM_PE_TIER1_CAP
 #define ABM_PE_TIER1_CAP 128
 #endif

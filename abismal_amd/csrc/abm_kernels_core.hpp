@@ -792,13 +792,9 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-// (COPY: experiment only -- -DABM_EXP_CODE_BLOAT instantiates the passes once per call of a read, to see what a kernel that
-// does not fit the instruction cache costs; the marker is an assembly comment, no instruction)
-#define ABM_COPY_MARK() do { if (COPY != 0) asm volatile("; seed_pass copy %0" ::"n"(COPY)); } while (0)
-template <bool SPECIFIC, bool TIMED, bool COOP, class Set, int COPY = 0>
+template <bool SPECIFIC, bool TIMED, bool COOP, class Set>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
                                           u32 flags, u32 L, Set &S, WorkTally &wt, u32 &seg_epoch) {
-  ABM_COPY_MARK();
   const int lane = lane_id();
   const u64 *qpk = lds.qpk + enc * lds.W;
   const u64 *qb = lds.qbits + enc * lds.WB;
@@ -813,9 +809,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   const bool use_ext = SPECIFIC && ix.ext2 != nullptr && ix.ext_maxc == maxc &&
                        L - n_off + 1 >= max(kKeyWeight + ix.e2, kKeyWeight3 + ix.e3);
 
-  // work tallies: the paired-end kernels and the single-end kernel's diagnostic build keep them; the single-end
-  // production kernel does not (they cost it registers: 100 -> 64 bytes per lane of scratch without them)
-  constexpr bool TALLY = TIMED || Set::kAppend;
+  // work tallies: the diagnostic builds keep them, the production kernels do not (they cost the single-end kernel
+  // registers: 100 -> 64 bytes per lane of scratch without them; the pair kernels kept them until round 5, when five
+  // lane-resident counters were what the seed kernel spilled in its offset loop)
+  constexpr bool TALLY = TIMED;
   // direct narrowing of big ranges: in the pair kernels only (see narrow_direct)
   constexpr bool kDirect = Set::kAppend ? ABM_PE_DIRECT_NARROWING : false;
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
@@ -824,8 +821,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     wave_sync();
   }
   for (u32 g0 = 0; g0 < n_off && !S.sure_ambig; g0 += 64) {
-    ABM_COPY_MARK();
-    ABM_STAMP(ta);
+      ABM_STAMP(ta);
     const u32 i = g0 + lane;
     const bool live = i < n_off;
     u32 lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0;
@@ -977,8 +973,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     };
     fetch_entries(0);
     for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
-      ABM_COPY_MARK();
-      ABM_STAMP(tc);
+          ABM_STAMP(tc);
       if (TIMED) { ++wt.steps; if (total - c0 <= 64) ++wt.light_steps; }
       const bool two = c0 + 64 < total;  // (uniform: this step has a b half)
       const bool va = nva, vb = nvb;

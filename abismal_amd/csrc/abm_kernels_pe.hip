@@ -4,9 +4,15 @@
 // (map_fragments :1849-1885), each seeding both ends into growable candidate
 // sets (pe_candidates :775-863), mating them (best_pair :1722-1831), feeding the
 // single-end sets (best_single :1715-1720), then valid_pair and the single-end
-// fallback.  Two tiers run the same code: tier 1 keeps sets of up to 256
-// entries in LDS at normal occupancy; pairs whose sets outgrow that are redone
-// by tier 2 with one wave per CU and a 32768-entry set in LDS.
+// fallback.  The per-pair body is split by phase where its register pressure
+// is (round 5): a SEED kernel (both seed passes of every orientation call's two
+// ends; shaped like the single-end kernel: no alignment state, small LDS) hands
+// the finished candidate lists over in global memory, and MATE kernels take
+// them from there (sort, scoring, mating, tracebacks, best_single, fallback) --
+// lists of up to kPeTier1Cap entries in LDS, longer ones in global memory.
+// Pairs whose sets outgrow the seed kernel (its staging area, or the heap of a
+// sensitive pass) go through the WHOLE-pair kernel: the same code unsplit, one
+// wave per pair with 32768-entry sets in global memory (tier 2).
 #include <climits>
 #include "abm_kernels_core.hpp"
 #include "abm_pe_set.hpp"
@@ -57,7 +63,10 @@ struct PairBest {
 // 32766 bases are 164 KB: more than a CU's LDS), so do every traceback table ((L + 61) x 61 bytes) and the CIGAR scratch;
 // bands are up to 61 lanes wide (two window slots), the filter runs on the nibble array, scores wrap at 16 bits like the
 // reference's score_t, and the lists are tier 2's (global memory).
-template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
+// PHASE: kWhole = seeding and mating in one kernel (tier 2's whole-pair launch, the long-end launch; BIG = false is the
+// unsplit tier 1 of rounds 1-4, kept for same-box comparisons), kSeed / kMate = the two halves of the split
+enum : int { kWhole = 0, kSeed = 1, kMate = 2 };
+template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeWave {
   const PeArgs &a;
   WaveLds lds;      // qpk/qbits point at end 0; end 1 follows at +4W / +4WB
   PeLds pl;
@@ -78,6 +87,8 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
   long long t_sort, t_score, t_mate, t_single;
   u32 *log_base;  // tier 2: this wave's best_single log
   int max_set;
+  u32 *stage_pos;  // seed kernel: this wave's staging area for a list that outgrows its LDS slot
+  i16 *stage_d;
 
   // (ends are run-time values -- the orientation calls are ONE piece of code looped over -- so the two-element register
   // arrays are read and written through selects, never indexed)
@@ -101,11 +112,15 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
     lflags[which] = flags;
     P.lpos = pl.lpos[which];
     P.ld = pl.ld[which];
+    if constexpr (PHASE == kSeed) {  // (a list may outgrow its LDS slot: PeSet::append)
+      P.cap_avail = a.cap;
+      P.spill_pos = stage_pos; P.spill_d = stage_d; P.spill_cap = a.scap; P.spilled = false;
+    }
     P.begin_read(len_of(end));
     if (len_of(end) >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
       seed_pass<true, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
-      if (!P.overflow && P.wants_sensitive() && !(a.diag_skip & 2u)) {
+      if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
         seed_pass<false, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       }
@@ -154,6 +169,48 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
     P.heapify();
     freeze_heap_order(which, lsz[which]);
     heap_order[which] = true;
+  }
+
+  // ---- the hand-over between the seed kernel and the mate kernels (PeArgs::hand_*) ----
+  __device__ __forceinline__ u32 *hand_slot(u64 r, int slot) const {
+    const u32 n_slots = a.mode == 2 ? 8u : 4u;
+    return a.hand_hdr + (r * n_slots + static_cast<u32>(slot)) * 2;
+  }
+  // seed kernel: the list seed_end(which) has just finished -- in P.lpos / P.ld: its LDS slot (frozen in heap order if
+  // it was heaped) or the staging area -- goes to the hand-over area; no room there = the pair is the whole-pair kernel's
+  __device__ __forceinline__ void emit_list(int which, u64 r, int slot) {
+    if (need_big) return;
+    const int lane = lane_id();
+    const int n = lsz[which];
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(a.hand_count, static_cast<unsigned long long>(n));
+    const u64 off = (static_cast<u64>(static_cast<u32>(uni(static_cast<int>(at >> 32)))) << 32) | static_cast<u32>(uni(static_cast<int>(at)));
+    if (off + static_cast<u64>(n) > static_cast<u64>(a.hand_cap)) { need_big = true; return; }
+    const u32 *lp = P.lpos;
+    const i16 *ldv = P.ld;
+    for (int i = lane; i < n; i += 64) { a.hand_pos[off + i] = lp[i]; a.hand_d[off + i] = ldv[i]; }
+    if (lane == 0) {
+      u32 *h = hand_slot(r, slot);
+      h[0] = static_cast<u32>(off);
+      h[1] = static_cast<u32>(n) | (worth[which] ? 1u << 16 : 0u) | (heap_order[which] ? 1u << 17 : 0u);
+    }
+    wave_sync();  // (the next seed_end writes the LDS slot / staging area this copy reads)
+  }
+  // mate kernels: the same list back into lists `which` of this wave (LDS, or tier 2's global memory)
+  __device__ __forceinline__ void load_list(int which, u64 r, int slot, u32 flags) {
+    const int lane = lane_id();
+    const u32 *h = hand_slot(r, slot);
+    const u32 off = static_cast<u32>(uni(static_cast<int>(h[0]))), meta = static_cast<u32>(uni(static_cast<int>(h[1])));
+    const int n = static_cast<int>(meta & 0xFFFFu);
+    lflags[which] = flags;
+    lsz[which] = n;
+    worth[which] = (meta >> 16) & 1u;
+    heap_order[which] = (meta >> 17) & 1u;
+    max_set = max(max_set, n);
+    u32 *lp = pl.lpos[which];
+    i16 *ldv = pl.ld[which];
+    for (int i = lane; i < n; i += 64) { lp[i] = a.hand_pos[off + i]; ldv[i] = a.hand_d[off + i]; }
+    wave_sync();
   }
 
   // prepare_for_mating (:844-852): sort by position, drop duplicates; diffs are
@@ -522,11 +579,24 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
       return false;
     }
     // endA forward with (rc=0, a_rich=ar); endB reverse-complemented with (rc=1, a_rich=!ar)
-    seed_end<TIMED>(0, endA, false, ar);
-    seed_end<TIMED>(1, endB, true, !ar);
-    if (need_big && !BIG)
+    if constexpr (PHASE == kSeed) {  // (one list at a time: each is handed over as soon as it is finished)
+      seed_end<TIMED>(0, endA, false, ar);
+      emit_list(0, r, 2 * O);
+      if (need_big) return true;
+      seed_end<TIMED>(0, endB, true, !ar);
+      emit_list(0, r, 2 * O + 1);
       return true;
-    if (a.diag_skip & 1u) return true;
+    }
+    else if constexpr (PHASE == kMate) {
+      load_list(0, r, 2 * O, ar ? kFlagARich : 0u);
+      load_list(1, r, 2 * O + 1, kFlagRC | (ar ? 0u : kFlagARich));
+    }
+    else {
+      seed_end<TIMED>(0, endA, false, ar);
+      seed_end<TIMED>(1, endB, true, !ar);
+      if (need_big && !BIG)
+        return true;
+    }
     long long t0 = 0, t1 = 0;
     if (worth[0] && worth[1]) {
       ABM_STAMP(t0);
@@ -576,14 +646,17 @@ template <bool BIG, bool COOP, bool LONG = false> struct PeWave {
   }
 };
 
-template <bool BIG, bool TIMED, bool COOP, int WPS, bool LONG = false>
+template <bool BIG, bool TIMED, bool COOP, int WPS, bool LONG = false, int PHASE = kWhole>
 __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
-  static_assert(!LONG || (BIG && !COOP && !TIMED), "the long-end launch: tier 2's lists, nibble filter, no stamps");
+  static_assert(!LONG || (BIG && !COOP && !TIMED && PHASE == kWhole), "the long-end launch: tier 2's lists, nibble filter, no stamps");
+  static_assert(PHASE != kSeed || !BIG, "the seed kernel keeps its lists in LDS (and its staging area)");
+  static_assert(PHASE != kMate || !COOP, "the mate kernels fetch no candidate windows");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  PeWave<BIG, COOP, LONG> w{a};
+  PeWave<BIG, COOP, LONG, PHASE> w{a};
   WaveLds &lds = w.lds;
   lds.W = a.W; lds.WB = a.WB; lds.GW = a.GW;
+  u32 *after_heap;
   if constexpr (LONG) {
     // read data in this wave's piece of global memory; LDS holds the two window slots, the cache and the job lists
     u64 *q = a.long_q + static_cast<u64>(blockIdx.x) * (8ull * a.W + 8ull * a.WB);
@@ -598,12 +671,29 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     lds.ctmp = a.long_ctmp + static_cast<u64>(blockIdx.x) * ((a.ctmp_cap + 1) & ~1u);
     lds.jpos = reinterpret_cast<u32 *>(lds.pcache + (1u << kPosCacheBits));
   }
-  else {
+  else if constexpr (PHASE == kSeed) {
+    // (pe_seed_lds_bytes) read data, the window cache, the step's distances, then the set: no alignment state at all
     lds.qpk = reinterpret_cast<u64 *>(smem);
     lds.qbits = lds.qpk + 8 * a.W;
     lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
     lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
-    lds.gwin = lds.qmask + 8 * lds.MB * 4;
+    lds.pcache = lds.qmask + 8 * lds.MB * 4;
+    lds.gwin = nullptr; lds.max_jobs = 0; lds.tb = nullptr; lds.ctmp = nullptr; lds.jpos = nullptr; lds.jdf = nullptr;
+    w.pl.jidx = nullptr;
+    lds.lbest = reinterpret_cast<int *>(lds.pcache + (1u << kPosCacheBits));
+  }
+  else {
+    lds.qpk = reinterpret_cast<u64 *>(smem);
+    if constexpr (PHASE == kMate) {  // (pe_mate_lds_bytes: the packed encodings are all a mate kernel reads of a read)
+      lds.qbits = nullptr; lds.MB = 0; lds.qmask = nullptr;
+      lds.gwin = lds.qpk + 8 * a.W;
+    }
+    else {
+      lds.qbits = lds.qpk + 8 * a.W;
+      lds.MB = (a.max_len + kPlaneBlock - 1) / kPlaneBlock;
+      lds.qmask = lds.qbits + 8 * a.WB;  // [2 ends][4][MB][4]
+      lds.gwin = lds.qmask + 8 * lds.MB * 4;
+    }
     lds.max_jobs = kMaxJobs;
     lds.pcache = lds.gwin + kMaxJobs * a.GW;
     // the traceback table overlays window slots 1.. and the window cache (a traceback uses slot 0 only)
@@ -611,12 +701,14 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     lds.ctmp = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(lds.pcache + (1u << kPosCacheBits)) + a.tb_extra);
     lds.jpos = lds.ctmp + a.ctmp_cap;
   }
-  lds.jdf = lds.jpos + kSeCap;
-  w.pl.jidx = lds.jdf + kSeCap;
-  lds.lbest = reinterpret_cast<int *>(w.pl.jidx + kSeCap);
+  if constexpr (PHASE != kSeed) {
+    lds.jdf = lds.jpos + kSeCap;
+    w.pl.jidx = lds.jdf + kSeCap;
+    lds.lbest = reinterpret_cast<int *>(w.pl.jidx + kSeCap);
+  }
   // tier 1: the set's heap is in LDS.  tier 2: a 32768-entry heap per wave would cap the CU at one
   // wave, so it lives in global memory (L2-resident, touched by this wave only) and occupancy stays normal
-  u32 *after_heap = reinterpret_cast<u32 *>(lds.lbest + 64);
+  after_heap = reinterpret_cast<u32 *>(lds.lbest + 64);
   if (BIG) w.pl.heap = a.heap_ws + static_cast<u64>(blockIdx.x) * a.cap;
   else { w.pl.heap = after_heap; after_heap += a.cap; }
   w.pl.cap = a.cap;
@@ -625,6 +717,12 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     w.pl.lpos[0] = ws; w.pl.lpos[1] = ws + a.cap;
     i16 *h = reinterpret_cast<i16 *>(ws + 2 * a.cap);
     w.pl.ld[0] = h; w.pl.ld[1] = h + a.cap; w.pl.lsc[0] = h + 2 * a.cap; w.pl.lsc[1] = h + 3 * a.cap;
+  }
+  else if constexpr (PHASE == kSeed) {  // one list at a time (positions, diffs)
+    w.pl.lpos[0] = w.pl.lpos[1] = after_heap;
+    i16 *h = reinterpret_cast<i16 *>(after_heap + a.cap);
+    w.pl.ld[0] = w.pl.ld[1] = h; w.pl.lsc[0] = w.pl.lsc[1] = nullptr;
+    after_heap = reinterpret_cast<u32 *>(h + a.cap + (a.cap & 1u));
   }
   else {
     w.pl.lpos[0] = after_heap; w.pl.lpos[1] = after_heap + a.cap;
@@ -637,10 +735,19 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   lds.mark = reinterpret_cast<u16 *>(after_heap + 256);
   lds.hres = reinterpret_cast<u16 *>(lds.lbest);
   lds.G = a.G;
-  lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
+  if constexpr (PHASE != kMate) { lds.smark[lane] = 0; lds.smark[64 + lane] = 0; }
+  else lds.mark = reinterpret_cast<u16 *>(after_heap);  // (no seed passes: no segment marks)
   w.seg_epoch = 0;
 
   w.P.heap = w.pl.heap;
+  w.P.spill_pos = nullptr; w.P.spill_d = nullptr; w.P.spill_cap = 0; w.P.spilled = false;
+  w.stage_pos = nullptr; w.stage_d = nullptr;
+  if constexpr (PHASE == kSeed) {
+    if (a.scap > a.cap) {
+      w.stage_pos = a.stage_pos + static_cast<u64>(blockIdx.x) * a.scap;
+      w.stage_d = a.stage_d + static_cast<u64>(blockIdx.x) * a.scap;
+    }
+  }
   w.log_base = BIG ? a.log_ws + static_cast<u64>(blockIdx.x) * (32ull + 12ull * a.cap) : nullptr;
   // scratch table for permuting a list: global for tier 2; tier 1 borrows the window cache (idle outside seed passes)
   static_assert(kPeTier1Cap * 4 <= (8u << kPosCacheBits), "tier-1 scratch table must fit the window cache");
@@ -652,6 +759,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   w.t_sort = w.t_score = w.t_mate = w.t_single = 0;
   bool too_long = false;
   long long t_begin = 0, t_fb = 0;
+  u32 routed_small = 0, routed_whole = 0, routed_big = 0;  // seed kernel: pairs of this wave by route
   ABM_STAMP(t_begin);
 
   auto next_item = [&]() -> u64 {
@@ -666,11 +774,8 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     const u64 it = it_next;
     it_next = next_item();
     const u64 r = BIG ? static_cast<u64>(a.subset[it]) : (a.order ? static_cast<u64>(a.order[it]) : it);
-    if constexpr (!BIG) {
-      if (a.big_class != 0 && a.cls[r] >= a.big_class) {  // (predicted to outgrow tier 1's lists: not started here)
-        if (lane == 0) a.need_big[r] = 1;
-        continue;
-      }
+    if constexpr (PHASE == kMate && !BIG) {  // (the small-list mate kernel walks the whole batch: the other routes' pairs are not its)
+      if (static_cast<u8>(uni(static_cast<int>(a.need_big[r]))) != kRouteSmall) continue;
     }
     w.L[0] = a.lens1[r];
     w.L[1] = a.lens2[r];
@@ -684,19 +789,39 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
       for (u32 k = lane; k < 4 * a.W; k += 64) lds.qpk[e * 4 * a.W + k] = src[k];
     }
     wave_sync();
-    for (u32 e8 = 0; e8 < 8; ++e8)
-      for (u32 wb = 0; wb < a.WB; ++wb) {
-        const u32 j = wb * 64 + lane, Le = e8 < 4 ? w.L[0] : w.L[1];
-        const bool b = j < Le ? bit2(q_nibble(lds.qpk + e8 * a.W, j)) : true;
-        const u64 word = __ballot(b);
-        if (lane == 0) lds.qbits[e8 * a.WB + wb] = word;
+    if constexpr (PHASE != kMate) {
+      for (u32 e8 = 0; e8 < 8; ++e8)
+        for (u32 wb = 0; wb < a.WB; ++wb) {
+          const u32 j = wb * 64 + lane, Le = e8 < 4 ? w.L[0] : w.L[1];
+          const bool b = j < Le ? bit2(q_nibble(lds.qpk + e8 * a.W, j)) : true;
+          const u64 word = __ballot(b);
+          if (lane == 0) lds.qbits[e8 * a.WB + wb] = word;
+        }
+      if constexpr (COOP) { build_qmasks(w.lds_of(0), w.L[0]); build_qmasks(w.lds_of(1), w.L[1]); }
+      wave_sync();
+      #pragma unroll
+      for (int e = 0; e < 2; ++e)  // 44-46 bases: seeds reach past the end of the read (see ghost_bits)
+        if (w.L[e] >= a.ix.min_len && w.L[e] < max(a.ix.window, w.L[e] >> 1) + kKeyWeight - 1)
+          ghost_bits(e ? a.packed2 : a.packed1, e ? a.lens2 : a.lens1, r, w.L[e], a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits + e * 4 * a.WB);
+    }
+
+    if constexpr (PHASE == kSeed) {
+      // both seed passes of every orientation call's two ends; the lists go to the hand-over area, the pair to its route
+      w.need_big = false;
+      w.max_set = 0;
+      const int n_or = a.mode == 2 ? 4 : 2;
+#pragma clang loop unroll(disable)
+      for (int o = 0; o < n_or; ++o) {
+        if (w.need_big) break;
+        const bool ar_o = a.mode == 2 ? (o == 1 || o == 2) : ((a.mode == 1) != (o == 1));
+        PairBest unused;
+        (void)w.template orientation<TIMED>(o, o & 1, ar_o, r, unused);
       }
-    if constexpr (COOP) { build_qmasks(w.lds_of(0), w.L[0]); build_qmasks(w.lds_of(1), w.L[1]); }
-    wave_sync();
-    #pragma unroll
-    for (int e = 0; e < 2; ++e)  // 44-46 bases: seeds reach past the end of the read (see ghost_bits)
-      if (w.L[e] >= a.ix.min_len && w.L[e] < max(a.ix.window, w.L[e] >> 1) + kKeyWeight - 1)
-        ghost_bits(e ? a.packed2 : a.packed1, e ? a.lens2 : a.lens1, r, w.L[e], a.max_len, a.ix.min_len, a.W, a.WB, lds.qbits + e * 4 * a.WB);
+      const u8 route = w.need_big ? kRouteWhole : (w.max_set > static_cast<int>(kPeTier1Cap) ? kRouteBig : kRouteSmall);
+      if (lane == 0) a.need_big[r] = route;
+      routed_small += route == kRouteSmall; routed_whole += route == kRouteWhole; routed_big += route == kRouteBig;
+      continue;
+    }
 
     PairBest best;
     best.f1 = best.f2 = 0;
@@ -724,7 +849,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
       }
     }
     if (w.need_big && !BIG) {
-      if (lane == 0) a.need_big[r] = 1;
+      if (lane == 0) a.need_big[r] = kRouteWhole;
       continue;
     }
     if (!any) {  // :1981-1985
@@ -741,7 +866,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     Hit h1, h2;
     h1.diffs = static_cast<i16>(0.4 * w.L[0]); h1.flags = 0; h1.pos = 0;
     h2.diffs = static_cast<i16>(0.4 * w.L[1]); h2.flags = 0; h2.pos = 0;
-    if (!best.should_report(a.allow_ambig != 0) && !(a.diag_skip & 4u)) {  // single-end fallback at half the error budget
+    if (!best.should_report(a.allow_ambig != 0)) {  // single-end fallback at half the error budget
       if (BIG) { wave_sync(); w.replay_singles(); }
       long long tf0 = 0, tf1 = 0;
       ABM_STAMP(tf0);
@@ -769,7 +894,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
       a.se2[r] = h2;
       a.cig_n1[r] = w.n_ops[0];
       a.cig_n2[r] = w.n_ops[1];
-      if (!BIG) a.need_big[r] = 0;
+      if (!BIG && PHASE == kWhole) a.need_big[r] = kRouteSmall;
       if (TIMED && a.pair_diag)
         a.pair_diag[r] = (min(static_cast<u32>(w.max_set), 0xFFFFu) << 16) |
                          static_cast<u32>(min((phase_stamp() - t_pair) >> 20, 0xFFFFll));
@@ -800,6 +925,13 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
       }
     }
   }
+  if constexpr (PHASE == kSeed) {
+    if (a.split_stats && lane == 0) {
+      if (routed_small) atomicAdd(&a.split_stats[kRouteSmall], static_cast<unsigned long long>(routed_small));
+      if (routed_whole) atomicAdd(&a.split_stats[kRouteWhole], static_cast<unsigned long long>(routed_whole));
+      if (routed_big) atomicAdd(&a.split_stats[kRouteBig], static_cast<unsigned long long>(routed_big));
+    }
+  }
   if (lane == 0 && (w.overflow || too_long))
     atomicOr(a.status, (w.overflow ? 1u : 0u) | (too_long ? 2u : 0u));
   if (a.host_tail != nullptr && lane == 0) {  // the last wave to get here publishes the launch's two summary words
@@ -813,16 +945,16 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   }
 }
 
-// compact the pairs flagged by tier 1 into a list for tier 2, heaviest weight class first (a
-// counting sort on the class the tier-1 ordering already computed): the few pairs with huge
+// compact the pairs of one route (PeArgs::need_big) into a list for that route's launch, heaviest weight class first (a
+// counting sort on the class the ordering kernels already computed): the few pairs with huge
 // candidate sets run for a long time on their single wave and must not start last
 __global__ __launch_bounds__(256) void big_hist_kernel(const u8 *__restrict__ need_big, const u8 *__restrict__ cls,
-                                                       u64 n, u32 *__restrict__ class_count) {
+                                                       u64 n, u8 want, u32 *__restrict__ class_count) {
   __shared__ u32 hist[33];
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
   __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r < n && need_big[r]) atomicAdd(&hist[cls[r]], 1u);
+  if (r < n && need_big[r] == want) atomicAdd(&hist[cls[r]], 1u);
   __syncthreads();
   if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], hist[threadIdx.x]);
 }
@@ -834,13 +966,13 @@ __global__ void big_bases_kernel(u32 *class_count /*[33] in: counts, out: start 
   }
 }
 __global__ __launch_bounds__(256) void big_scatter_kernel(const u8 *__restrict__ need_big, const u8 *__restrict__ cls,
-                                                          u64 n, u32 *__restrict__ class_cursor,
+                                                          u64 n, u8 want, u32 *__restrict__ class_cursor,
                                                           u32 *__restrict__ subset) {
   __shared__ u32 hist[33], base[33];
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
   __syncthreads();
   const u64 r = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const bool take = r < n && need_big[r];
+  const bool take = r < n && need_big[r] == want;
   u32 c = 0, rank = 0;
   if (take) { c = cls[r]; rank = atomicAdd(&hist[c], 1u); }
   __syncthreads();
@@ -930,15 +1062,80 @@ hipError_t launch_map_pe_long(const PeArgs &a, u32 grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u32 *class33, u32 *subset, u32 *count,
+hipError_t launch_collect_big(const u8 *need_big, const u8 *cls, u64 n, u8 want, u32 *class33, u32 *subset, u32 *count,
                               hipStream_t st) {
   if (n == 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(class33, 0, 33 * sizeof(u32), st);
   if (e != hipSuccess) return e;
   const u32 blocks = static_cast<u32>((n + 255) / 256);
-  hipLaunchKernelGGL(big_hist_kernel, dim3(blocks), dim3(256), 0, st, need_big, cls, n, class33);
+  hipLaunchKernelGGL(big_hist_kernel, dim3(blocks), dim3(256), 0, st, need_big, cls, n, want, class33);
   hipLaunchKernelGGL(big_bases_kernel, dim3(1), dim3(64), 0, st, class33, count);
-  hipLaunchKernelGGL(big_scatter_kernel, dim3(blocks), dim3(256), 0, st, need_big, cls, n, class33, subset);
+  hipLaunchKernelGGL(big_scatter_kernel, dim3(blocks), dim3(256), 0, st, need_big, cls, n, want, class33, subset);
+  return hipGetLastError();
+}
+
+// ---- the phase-split launches ------------------------------------------------------------------------------------
+// Registers: the seed kernel is built for kPeSeedWps waves per SIMD, the mate kernels for kPeMateWps (what each needs
+// without scratch: profiles/r05_pe_split_resources.log)
+#ifndef ABM_PE_SEED_WPS
+#define ABM_PE_SEED_WPS 4
+#endif
+#ifndef ABM_PE_MATE_WPS
+#define ABM_PE_MATE_WPS 4
+#endif
+constexpr int kPeSeedWps = ABM_PE_SEED_WPS, kPeMateWps = ABM_PE_MATE_WPS;
+
+size_t pe_seed_lds_bytes(u32 W, u32 WB, u32 max_len, u32 cap) {
+  const u32 MB = (max_len + kPlaneBlock - 1) / kPlaneBlock;
+  const size_t b = static_cast<size_t>(8) * W * 8 + static_cast<size_t>(8) * WB * 8 + static_cast<size_t>(8) * MB * 4 * 8 +
+                   (static_cast<size_t>(8) << kPosCacheBits) + 64 * 4 + static_cast<size_t>(cap) * 4 /* heap */ +
+                   static_cast<size_t>(cap) * 4 + static_cast<size_t>(cap + (cap & 1u)) * 2 /* one list */ + 2 * 128 * 4 + 64 * 2;
+  return (b + 15) & ~static_cast<size_t>(15);
+}
+size_t pe_mate_lds_bytes(u32 W, u32 GW, u32 cig_stride, u32 max_len, double valid_frac, u32 cap, bool big) {
+  size_t b = static_cast<size_t>(8) * W * 8 + (static_cast<size_t>(8) << kPosCacheBits) + static_cast<size_t>(kMaxJobs) * GW * 8 +
+             static_cast<size_t>(cig_stride) * 4 + 3 * kSeCap * 4 + 64 * 4 + 64 * 2;
+  if (!big) b += static_cast<size_t>(cap) * (4 + 2 * 4 + 4 * 2);
+  b += tb_extra_bytes(GW, max_len, valid_frac);
+  return (b + 15) & ~static_cast<size_t>(15);
+}
+static int resident(const void *fn, size_t lds) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess) return 0;
+  return per_cu * prop.multiProcessorCount;
+}
+int pe_seed_resident_waves(size_t lds, bool coop) {
+  return coop ? resident(reinterpret_cast<const void *>(map_pe_kernel<false, false, true, kPeSeedWps, false, kSeed>), lds)
+              : resident(reinterpret_cast<const void *>(map_pe_kernel<false, false, false, kPeSeedWps, false, kSeed>), lds);
+}
+int pe_mate_resident_waves(size_t lds, bool big) {
+  return big ? resident(reinterpret_cast<const void *>(map_pe_kernel<true, false, false, kPeMateWps, false, kMate>), lds)
+             : resident(reinterpret_cast<const void *>(map_pe_kernel<false, false, false, kPeMateWps, false, kMate>), lds);
+}
+hipError_t launch_pe_seed(const PeArgs &a, size_t lds, u32 grid, bool timed, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  if (a.G != 0) {
+    if (timed) hipLaunchKernelGGL((map_pe_kernel<false, true, true, kPeSeedWps, false, kSeed>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_pe_kernel<false, false, true, kPeSeedWps, false, kSeed>), dim3(grid), dim3(64), lds, st, a);
+  }
+  else {
+    if (timed) hipLaunchKernelGGL((map_pe_kernel<false, true, false, kPeSeedWps, false, kSeed>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_pe_kernel<false, false, false, kPeSeedWps, false, kSeed>), dim3(grid), dim3(64), lds, st, a);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_pe_mate(const PeArgs &a, size_t lds, u32 grid, bool big, bool timed, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  if (big) {
+    if (timed) hipLaunchKernelGGL((map_pe_kernel<true, true, false, kPeMateWps, false, kMate>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_pe_kernel<true, false, false, kPeMateWps, false, kMate>), dim3(grid), dim3(64), lds, st, a);
+  }
+  else {
+    if (timed) hipLaunchKernelGGL((map_pe_kernel<false, true, false, kPeMateWps, false, kMate>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_pe_kernel<false, false, false, kPeMateWps, false, kMate>), dim3(grid), dim3(64), lds, st, a);
+  }
   return hipGetLastError();
 }
 

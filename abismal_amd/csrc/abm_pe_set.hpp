@@ -48,6 +48,13 @@ struct PeSet {
   u32 *lpos;   // [cap] positions: arrival order while appending, handle-indexed once heaped
   i16 *ld;     // [cap] diffs of the same entries (not maintained once heaped: the keys hold them)
   u32 cap_avail;
+  // the seed kernel of the phase-split launches: a list still growing by appends that outgrows its LDS slot moves to the
+  // wave's staging area in global memory (spill_cap entries; 0 = none) and carries on there -- appended entries are
+  // written once and not read again before the list is handed over, so where they lie costs nothing
+  u32 *spill_pos;
+  i16 *spill_d;
+  u32 spill_cap;
+  bool spilled;
   u32 top;     // heap[0]
   int sz, capacity, cutoff, good_cutoff;
   bool sure_ambig, overflow, heaped;
@@ -74,8 +81,17 @@ struct PeSet {
   // just reached 32768 entries and turned into a heap).
   __device__ __forceinline__ u64 append(u64 todo, int h, u32 pos) {
     const int lane = lane_id();
+    const int cnt = __popcll(todo);
+    if (spill_cap > cap_avail && sz + cnt > static_cast<int>(cap_avail)) {  // (only ever true in the seed kernel, once per list)
+      for (int i = lane; i < sz; i += 64) { spill_pos[i] = lpos[i]; spill_d[i] = ld[i]; }
+      lpos = spill_pos; ld = spill_d;
+      cap_avail = spill_cap;
+      spill_cap = 0;
+      spilled = true;
+      wave_sync();
+    }
     const int limit = static_cast<int>(min(cap_avail, kPeCapLarge));
-    const int cnt = __popcll(todo), take = min(cnt, limit - sz);
+    const int take = min(cnt, limit - sz);
     const int rank = __popcll(todo & ((1ull << lane) - 1));
     const bool mine = (todo >> lane) & 1ull;
     if (mine && rank < take) { lpos[sz + rank] = pos; ld[sz + rank] = static_cast<i16>(h); }

@@ -360,20 +360,26 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    # exact work tallies and per-launch durations (HIP events on the launch streams) of the timed steps
-    tier_work = [dict(), dict()]
-    tier_ms = [[], []]
+    # per-launch durations (HIP events on the launch streams) of the timed steps, by kernel: a paired-end call launches
+    # seed, mate (LDS lists), mate (lists in device memory) and whole-pair kernels -- or tier 1 and tier 2 when unsplit
+    per_call = max(1, slots[0].ctx.pe_timed_launches())
+    launch_names = ["seed", "mate_lds_lists", "mate_device_lists", "whole_pairs"] if per_call == 4 else ["tier1", "tier2"]
+    launch_ms = [[] for _ in range(per_call)]
+    split_routes = {}
     for z in slots:
-        times = z.ctx.take_kernel_times()
+        times = z.ctx.take_kernel_times(capacity=4096)
         z.ctx.set_timing(False)
-        tier_ms[0] += times[0::2]
-        tier_ms[1] += times[1::2]
-        for t, w in enumerate(z.ctx.take_work_tiers()):
-            for k, v in w.items():
-                tier_work[t][k] = tier_work[t].get(k, 0) + v
+        for k in range(per_call):
+            launch_ms[k] += times[k::per_call]
+        for k, v in z.ctx.pe_split_stats().items():
+            split_routes[k] = (split_routes.get(k, 0) + v) if k != "hand_over_entries_last_batch" else max(split_routes.get(k, 0), v)
+        z.ctx.take_work_tiers()
+    tier_ms = [sum(launch_ms[:per_call // 2], []), sum(launch_ms[per_call // 2:], [])]
+    # exact work tallies: the production kernels keep none (they cost the seed kernel registers), so ONE more step goes
+    # through the diagnostic kernels on rank 0 -- tallies, per-launch durations alone on the device, phase shares
+    tier_work = [dict(), dict()]
     diag = None
-    if args.phase_stamps and rank == 0:
-        # one more step through the diagnostic kernels: per-tier durations and phase shares
+    if rank == 0:
         ctx.take_work_tiers()
         ctx.set_timing(True)
         ctx.set_phase_stamps(True)
@@ -394,7 +400,8 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         times = ctx.take_kernel_times()
         ctx.set_timing(False)
         tiers = ctx.take_work_tiers()
-        diag = {"kernel_ms": [round(t, 2) for t in times], "by_set_size": hist, "tiers": []}
+        tier_work = [dict(t) for t in tiers]
+        diag = {"kernel_ms": dict(zip(launch_names, [round(t, 2) for t in times])), "by_set_size": hist, "tiers": []}
         for t in tiers:
             tot = max(1, t["cyc_total"])
             diag["tiers"].append({
@@ -456,10 +463,11 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         return 2 * L + S * 16 + P * 4.5 + C * 4 + (W + (C if Cw is None else Cw)) * 8 + Aln * (L + bw_band) / 2 + 36 + 16
 
     done_pairs = n * args.steps
+    tally_pairs = n  # (the tallies are one diagnostic step's)
     tw = {k: tier_work[0].get(k, 0) + tier_work[1].get(k, 0) for k in tier_work[0]}
     fetched = tw["candidates"] - tw["window_cache_hits"]
-    k_bytes = pair_bytes(tw["seed_offsets"] / done_pairs, tw["search_probes"] / done_pairs, tw["candidates"] / done_pairs,
-                         fetched * nw / done_pairs, tw["alignments"] / done_pairs, fetched / done_pairs)
+    k_bytes = pair_bytes(tw["seed_offsets"] / tally_pairs, tw["search_probes"] / tally_pairs, tw["candidates"] / tally_pairs,
+                         fetched * nw / tally_pairs, tw["alignments"] / tally_pairs, fetched / tally_pairs)
     s_bytes = None
     if cpu is not None:
         s_bytes = pair_bytes(strict["seed_iters"], strict["search_probes"], strict["candidates"], strict["words"],
@@ -473,9 +481,9 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
     # probe two (index entry + genome letter), the index-entry runs what they span, an alignment its window
     # ((L + band) / 2 bytes at a random offset) -- against the counters' total when a PMC pass is on file
     per_aln = ((L + bw_band) / 2 + 127) // 128 + 1
-    lines_by_source = {"candidate_windows": fetched / done_pairs, "seed_offset_lookups": 2 * tw["seed_offsets"] / done_pairs,
-                       "narrowing_probes": 2 * tw["search_probes"] / done_pairs, "index_entry_runs": tw["index_run_lines"] / done_pairs,
-                       "alignment_windows": per_aln * tw["alignments"] / done_pairs, "reads_in_results_out": 2 * ((4 * nw * 8 + 127) // 128) + 2}
+    lines_by_source = {"candidate_windows": fetched / tally_pairs, "seed_offset_lookups": 2 * tw["seed_offsets"] / tally_pairs,
+                       "narrowing_probes": 2 * tw["search_probes"] / tally_pairs, "index_entry_runs": tw["index_run_lines"] / tally_pairs,
+                       "alignment_windows": per_aln * tw["alignments"] / tally_pairs, "reads_in_results_out": 2 * ((4 * nw * 8 + 127) // 128) + 2}
     lines_by_source = {k: round(v, 1) for k, v in lines_by_source.items()}
     lines_by_source["accounted"] = round(sum(lines_by_source.values()), 1)
     if pe_traffic:
@@ -485,7 +493,7 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                                                "the seed passes', half of them the sensitive passes': lines the tallies count once and the L2s, turned over "
                                                "every few microseconds by the window traffic, fetch again; tier 2 adds its per-wave lists, heap, sort buffer and "
                                                "best_single log in global memory (DESIGN.md 4.3)")
-    tier_lines = [{k: round(v / done_pairs, 1) for k, v in (("candidate_windows", tier_work[t].get("candidates", 0) - tier_work[t].get("window_cache_hits", 0)),
+    tier_lines = [{k: round(v / tally_pairs, 1) for k, v in (("candidate_windows", tier_work[t].get("candidates", 0) - tier_work[t].get("window_cache_hits", 0)),
                                                             ("seed_offset_lookups", 2 * tier_work[t].get("seed_offsets", 0)),
                                                             ("narrowing_probes", 2 * tier_work[t].get("search_probes", 0)),
                                                             ("index_entry_runs", tier_work[t].get("index_run_lines", 0)),
@@ -496,13 +504,15 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                 "alg_bytes_per_pair_kernel_tally": round(k_bytes, 1),
                 "frac_kernel_tally": round(k_bytes * done_pairs / elapsed / 1e9 / 8000.0, 5),
                 "denominator": "wall time of the timed region (kernels of %d slots overlap)" % len(slots),
-                "tier1_ms_per_launch": round(sum(tier_ms[0]) / max(1, len(tier_ms[0])), 2),
-                "tier2_ms_per_launch": round(sum(tier_ms[1]) / max(1, len(tier_ms[1])), 2),
+                "tier1_ms_per_launch": round(sum(tier_ms[0]) / max(1, len(launch_ms[0])), 2),
+                "tier2_ms_per_launch": round(sum(tier_ms[1]) / max(1, len(launch_ms[-1])), 2),
+                "ms_per_launch": {nm: round(sum(v) / max(1, len(v)), 2) for nm, v in zip(launch_names, launch_ms)},
+                "pairs_by_route": split_routes,
                 "lines_per_pair_by_source": lines_by_source, "lines_per_pair_by_source_tier1": tier_lines[0],
                 "lines_per_pair_by_source_tier2": tier_lines[1],
                 "traffic": pe_traffic, "traffic_source": pe_traffic_source,
                 "traffic_over_algorithmic": round(pe_traffic / (use * n), 2) if pe_traffic else None,
-                "work_per_pair": {k: round(v / done_pairs, 2) for k, v in tw.items() if not k.startswith("cyc_")},
+                "work_per_pair": {k: round(v / tally_pairs, 2) for k, v in tw.items() if not k.startswith("cyc_")},
                 "tier2_share_of_candidates": round(tier_work[1].get("candidates", 0) / max(1, tw["candidates"]), 3),
                 "strict_counts_per_pair": {k: round(v, 2) for k, v in strict.items()} if cpu is not None else None}
     n_slots = len(slots)
@@ -533,7 +543,10 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp, {n} pairs x 2x{L} bp per GPU per step",
-                   "streams": n_slots},
+                   "streams": n_slots,
+                   "end_to_end": ({"reads_per_s": e2e.get("value"), "over_kernel": round(e2e["value"] / pe_value, 4) if e2e.get("value") else None,
+                                   "seconds_of_each_run": e2e.get("seconds_of_each_run"), "reads": e2e.get("reads"),
+                                   "sam_body_md5_equals_oracle_cli": (e2e.get("parity") or {}).get("identical")} if isinstance(e2e, dict) else None)},
         "roofline": roofline, "cpu_baseline": cpu,
         "e2e_reads_per_s": e2e.get("value") if isinstance(e2e, dict) else None,
         "e2e_over_kernel": round(e2e["value"] / pe_value, 4) if isinstance(e2e, dict) and e2e.get("value") else None,
@@ -620,7 +633,7 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
         med = [t for t in runs if t["seconds"] == secs[1]][0]
         # what the host side alone can carry around `gpus` GPUs: the same command with virtual GPUs (no device, no mapping
         # call), into the same kind of sink and into /dev/null, at several host-thread counts
-        def host_ceiling_rows(src, vgpus, vparts, thread_counts=None, reps=1):
+        def host_ceiling_rows(src, vgpus, vparts, thread_counts=None, reps=3):
             """-virtual-gpus runs of `src` (no device, no mapping call): SAM into tmpfs (one file, or part files) and into /dev/null,
             at the run's default worker count and at -t 128 (both clamped to the container's CPU quota)"""
             rows = []
@@ -637,8 +650,8 @@ def run_e2e(args, idx, fasta, L, gpus=1, kind="se"):
                             if f != "/dev/null" and os.path.exists(f):
                                 os.remove(f)
                     if got:
-                        t = min(got, key=lambda x: x["seconds"])
-                        rows.append({"virtual_gpus": vgpus, "sink": (f"{vparts} tmpfs part files" if vparts > 1 else "one tmpfs file") if sink != "/dev/null" else "/dev/null",
+                        t = sorted(got, key=lambda x: x["seconds"])[len(got) // 2]  # the median run (every run's time is listed)
+                        rows.append({"virtual_gpus": vgpus, "statistic": f"median of {len(got)} runs", "sink": (f"{vparts} tmpfs part files" if vparts > 1 else "one tmpfs file") if sink != "/dev/null" else "/dev/null",
                                      "host_threads": t["host_threads"], "asked_threads": th, "reads": t["reads"],
                                      "reads_per_s": round(t["reads"] / t["seconds"], 1), "seconds_of_each_run": [round(x["seconds"], 3) for x in got],
                                      "busy_s": {k: round(v, 3) for k, v in t["busy_s"].items()}, "cpu_s": t.get("cpu_s"),
@@ -1283,6 +1296,40 @@ def main():
                 other[key] = {"error": r.stderr[-1500:]}
             log(f"{key}: {other[key].get('value')} {other[key].get('unit', '')} in {time.time() - t0:.0f}s")
 
+    # what BASELINE's metric defines -- FASTQ on disk -> SAM on disk -- for this configuration and the other two, inside
+    # `config` (the driver's record keeps `config`, `roofline` and `cpu_baseline` whole and drops other top-level keys)
+    def e2e_summary(row, kernel_value):
+        if not isinstance(row, dict) or not row.get("value"):
+            return {"error": (row or {}).get("error", "not run")[:200]} if isinstance(row, dict) else None
+        out = {"reads_per_s": row["value"], "over_kernel": round(row["value"] / kernel_value, 4) if kernel_value else None,
+               "statistic": row.get("statistic"), "seconds_of_each_run": row.get("seconds_of_each_run"), "reads": row.get("reads"),
+               "sam_body_md5_equals_oracle_cli": (row.get("parity") or {}).get("identical")}
+        for k in ("host_ceiling_reads_per_s", "host_ceiling_reads_per_s_dev_null", "host_ceiling_reads_per_s_8_virtual_gpus_8_parts"):
+            if row.get(k) is not None:
+                out[k] = row[k]
+        gz = row.get("gzip_input")
+        if isinstance(gz, dict):
+            out["gzip_input_reads_per_s"] = gz.get("value")
+            out["bgzf_input_reads_per_s"] = (gz.get("bgzf") or {}).get("value")
+        if isinstance(row.get("sustained"), dict):
+            out["sustained_reads_per_s"] = row["sustained"].get("value")
+        return out
+
+    other_summary = None
+    if other:
+        other_summary = {}
+        for key, row in other.items():
+            if "error" in row and "value" not in row:
+                other_summary[key] = {"error": row["error"][-300:]}
+                continue
+            other_summary[key] = {"value": row.get("value"), "unit": row.get("unit"), "ms_per_step": row.get("ms_per_step"),
+                                  "workload": (row.get("config") or {}).get("workload"),
+                                  "roofline_frac": (row.get("roofline") or {}).get("frac"),
+                                  "roofline_basis": (row.get("roofline") or {}).get("basis"),
+                                  "traffic_over_algorithmic": (row.get("roofline") or {}).get("traffic_over_algorithmic"),
+                                  "ms_per_launch": (row.get("roofline") or {}).get("ms_per_launch"),
+                                  "end_to_end": e2e_summary(row.get("e2e"), row.get("value")),
+                                  "parity_sample": {k: v for k, v in (row.get("cpu_baseline") or {}).items() if "identical" in k or "vs_oracle" in k} or None}
     line = {
         "metric": f"mapped reads/sec (whole node), {L} bp SE on hg38-scale index" + ("" if args.mode == "trich" else f", {mode_name}"),
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -1293,7 +1340,9 @@ def main():
         "config": {"workload": f"synthetic hg38-shaped genome {args.genome_mbp:g} Mbp (hg38 unavailable offline), "
                                f"{n} sim-like reads x {L} bp SE per GPU per step, {mode_name}",
                    "reads_per_step_per_gpu": n, "read_len": L, "index_gb": index_gb,
-                   "parallelism": f"reads sharded over {world} GPU(s), index replicated"},
+                   "parallelism": f"reads sharded over {world} GPU(s), index replicated",
+                   "end_to_end": e2e_summary(e2e, value) if e2e is not None else None,
+                   "other_configs": other_summary},
         "roofline": roofline, "cpu_baseline": cpu,
         # SURVEY 8(d)'s metric proper -- FASTQ on disk -> SAM on disk through `abismal-amd map -gpus N` -- beside `value`
         # (the HBM-resident kernel-loop rate the measurement contract defines; at N > 1 `value` is N independent loops

@@ -194,6 +194,26 @@ int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t
                       uint32_t cig_stride, uint32_t *d_cig_n1, uint32_t *d_cig_n2,
                       uint32_t *d_status, void *stream);
 
+/* How a paired-end batch is launched (no reference counterpart: the reference's per-pair body is one function,
+ * src/abismal.cpp:1950-1999).  By default the body is split where its register pressure is: a SEED kernel runs both
+ * seed passes of every orientation call's two ends (process_seeds into pe_candidates, :1269-1375, :775-863) and hands the
+ * finished candidate lists over in device memory; MATE kernels take them from there (prepare_for_mating, best_pair,
+ * best_single, the single-end fallback: :844-852, :1715-1831).  Pairs whose sets outgrow the seed kernel are mapped whole
+ * by one wave each with 32768-entry sets, as every heavy pair was before round 5.  Results do not depend on any of this.
+ *   split      -1 = default (split), 0 = seeding and mating in ONE kernel per pair (rounds 1-4; same-box comparisons), 1 = split
+ *   seed_cap   entries a candidate list may reach inside the seed kernel (0 = default; up to 128 a list stays in LDS,
+ *              beyond that it moves to a per-wave staging area in device memory; at most 16384)
+ *   hand_entries  list entries the hand-over area holds (0 = default: a multiple of the batch size; a list that finds
+ *              no room sends its pair through the whole-pair kernel -- slower, never wrong) */
+int abm_ctx_set_pe_split(abm_ctx *ctx, int split, uint32_t seed_cap, uint64_t hand_entries);
+/* Measurement hook: pairs by route since the previous call, then reset -- out[0] mated from LDS lists, out[1] mapped
+ * whole (sets that outgrew the seed kernel), out[2] mated from lists in device memory -- and out[3] the hand-over entries
+ * the context's last batch asked for (waits for the device). */
+int abm_ctx_pe_split_stats(abm_ctx *ctx, uint64_t out[4]);
+/* HIP-event brackets (abm_ctx_set_timing) the context's last paired-end call recorded, in launch order: split -- seed,
+ * mate (LDS lists), mate (lists in device memory), whole pairs = 4; unsplit -- tier 1, tier 2 = 2. */
+uint32_t abm_ctx_pe_timed_launches(const abm_ctx *ctx);
+
 /* the arena of CIGARs longer than their slot left by the context's last device call (waits for it) */
 int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint64_t *n_ops);
 
@@ -245,7 +265,7 @@ int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles);
  * for them and returns the number of launches and their summed duration. */
 int abm_ctx_set_timing(abm_ctx *ctx, int enable);
 int abm_ctx_take_kernel_time(abm_ctx *ctx, uint64_t *launches, double *total_ms);
-/* Same, one duration per launch in launch order (paired-end: tier 1, tier 2, ...). */
+/* Same, one duration per launch in launch order (paired-end: abm_ctx_pe_timed_launches() per call). */
 int abm_ctx_take_kernel_times(abm_ctx *ctx, double *ms_out, uint64_t capacity, uint64_t *launches);
 
 /* Mapping statistics are six counters per struct (src/abismal.cpp:865-895) in

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64) void run(int n_chunks, u32 *heaps, u32 *poss, i
   S.lpos = poss + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
   S.ld = lds_ + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
   S.cap_avail = kPeCapLarge;
+  S.spill_pos = nullptr; S.spill_d = nullptr; S.spill_cap = 0; S.spilled = false;
   S.begin_read(100);
   S.cutoff = S.good_cutoff;  // set_specific
   const int shape = blockIdx.x % kShapes, lane = threadIdx.x;

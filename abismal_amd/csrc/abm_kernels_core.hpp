@@ -1050,11 +1050,12 @@ __device__ __forceinline__ int band_for(int diffs, int max_diffs) {
   const int v = 2 * min(diffs, max_diffs) + 1;
   return v < 0 ? static_cast<int>(kMaxBand) : min(static_cast<int>(kMaxBand), v);
 }
+// (bound_ctrl: the lane without a source reads 0 and no lane keeps its old value, so the destination needs no initialising move)
 __device__ __forceinline__ int from_prev_lane(int v) {  // lane j <- lane j-1 (lane 0 <- 0)
-  return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
 __device__ __forceinline__ int from_next_lane(int v) {  // lane j <- lane j+1 (lane 63 <- 0)
-  return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
 }
 
 // 16 nibbles starting at nibble index `start` of an LDS word array; nibbles
@@ -1491,44 +1492,80 @@ struct QuadJob {         // per lane: the two jobs of one set that share this la
   int gs_lo, gs_hi;      // nibble index of row 1's target base in the window, moved to the slot's band
 };
 
+// The loop (round 5).  At iteration n (anti-diagonal steps t_start + 2 n and + 2 n + 1) set P's cell has read index
+// q = n + q0p and set Q's q = n + q0q, with per-lane constants q0: ((a + 2 n) >> 1 = (a >> 1) + n).  A cell needs its
+// position only for three tests -- from_above exists if q < L - 1, from_left if q > 0, the cell itself if 0 <= q < L --
+// and for all lanes at once they can only fail in the first and last few iterations (the lanes' q differ by at most a
+// band's width).  So the iterations are cut in three: a head and a tail that make the tests, and a middle -- 1 <= q <=
+// L - 2 in every lane, five sixths of the iterations of a 150-base read -- that does not: 15 vector instructions per
+// packed cell against 28.  The match bits of a lane's next 16 cells sit one per cell in the halves of a 32-bit word
+// (bit r: low job, bit 16 + r: high job), so "this cell's +2 / -3" is an AND and a packed multiply-add.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wave_min_i32(int x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x = min(x, __shfl_xor(x, d));
+  return x;
+}
 __device__ __forceinline__ void wavefront_quad(const WaveLds &lds, const QuadJob &jp, const QuadJob &jq, int dp, int dq,
                                                int o, int width, int L, int w_min, int w_max, u32 &bestp, u32 &bestq) {
   const int t_start = max(0, w_min - 1), t_end = 2 * (L - 1 + w_max) + 1;
-  u32 curp = 0, curq = 0, pub = 0;
-  u64 Mp = 0, Mq = 0;
-  bestp = bestq = 0;
+  const int n_total = (t_end - t_start) / 2 + 1;
   const int W = static_cast<int>(lds.W), GW = static_cast<int>(lds.GW);
-  auto refill = [&](const QuadJob &j, int time) -> u64 {
-    const int i0 = (time - o) >> 1;
-    const int qs = i0 + o - width;
+  const int q0p = ((t_start - dp - o) >> 1) + o - width, q0q = ((t_start + 1 - dq - o) >> 1) + o - width;
+  // iterations [n_mid0, n_mid1): 1 <= q <= L - 2 for both cells of every lane that belongs to a slot (uniform)
+  const bool in_slot = width != 0;
+  const int q_lo = wave_min_i32(in_slot ? min(q0p, q0q) : 0x3fffffff), q_hi = wave_max_i32(in_slot ? max(q0p, q0q) : -0x3fffffff);
+  const int n_mid0 = min(max(1 - q_lo, 0), n_total), n_mid1 = min(max(L - 1 - q_hi, n_mid0), n_total);
+  u32 curp = 0, curq = 0, pub = 0, Mp = 0, Mq = 0;
+  bestp = bestq = 0;
+  auto refill = [&](const QuadJob &j, int q) -> u32 {  // match bits of the 16 cells from read index q on
+    const int i0 = q - o + width;
     u64 lo = 0, hi = 0;
-    if (j.mv & 0xFFFFu) lo = nibbles16(lds.qpk + j.qoff_lo, W, qs) & nibbles16(lds.gwin + j.g_lo * GW, GW, j.gs_lo + i0 - 1);
-    if (j.mv >> 16) hi = nibbles16(lds.qpk + j.qoff_hi, W, qs) & nibbles16(lds.gwin + j.g_hi * GW, GW, j.gs_hi + i0 - 1);
+    if (j.mv & 0xFFFFu) lo = nibbles16(lds.qpk + j.qoff_lo, W, q) & nibbles16(lds.gwin + j.g_lo * GW, GW, j.gs_lo + i0 - 1);
+    if (j.mv >> 16) hi = nibbles16(lds.qpk + j.qoff_hi, W, q) & nibbles16(lds.gwin + j.g_hi * GW, GW, j.gs_hi + i0 - 1);
     lo |= lo >> 1; lo |= lo >> 2;
     hi |= hi >> 1; hi |= hi >> 2;
-    return (lo & 0x1111111111111111ull) | ((hi & 0x1111111111111111ull) << 1);
+    return every_fourth_bit(lo) | (every_fourth_bit(hi) << 16);
   };
-  auto cell = [&](const QuadJob &j, int time, u32 &cur, u64 &M, u32 &best) {
-    const int i = (time - o) >> 1;
-    const int q = i + o - width;
+  // +2 on a match, -3 otherwise, in both halves: 5 * bit - 3
+  auto step_delta = [&](u32 &M) -> u32 {
+    const u16x2 bits = __builtin_bit_cast(u16x2, M & 0x00010001u);
+    M >>= 1;
+    const u16x2 five = {5, 5}, minus3 = {0xFFFD, 0xFFFD};
+    return __builtin_bit_cast(u32, static_cast<u16x2>(bits * five + minus3));
+  };
+  auto fast = [&](const QuadJob &j, u32 &cur, u32 &M, u32 &best) {
     const u32 lf = static_cast<u32>(from_prev_lane(static_cast<int>(pub))), up = static_cast<u32>(from_next_lane(static_cast<int>(pub)));
-    const u32 x = static_cast<u32>(M);
-    const u32 delta = 0xFFFDFFFDu ^ ((x & 1u) ? 0x0000FFFFu : 0u) ^ ((x & 2u) ? 0xFFFF0000u : 0u);  // halves: +2 on a match, -3 otherwise
-    u32 c = pk_max(pk_add(cur, delta), 0u);
+    u32 c = pk_max(pk_add(cur, step_delta(M)), 0u);
+    c = pk_max(c, pk_add(up, 0xFFFCFFFCu) & j.ma);  // from_above
+    c = pk_max(c, pk_add(lf, 0xFFFCFFFCu) & j.ml);  // from_left
+    cur = c & j.mv;
+    best = pk_max(best, cur);
+    pub = cur;
+  };
+  auto slow = [&](const QuadJob &j, int q, u32 &cur, u32 &M, u32 &best) {
+    const u32 lf = static_cast<u32>(from_prev_lane(static_cast<int>(pub))), up = static_cast<u32>(from_next_lane(static_cast<int>(pub)));
+    u32 c = pk_max(pk_add(cur, step_delta(M)), 0u);
     c = pk_max(c, pk_add(up, 0xFFFCFFFCu) & (q < L - 1 ? j.ma : 0u));  // from_above
     c = pk_max(c, pk_add(lf, 0xFFFCFFFCu) & (q > 0 ? j.ml : 0u));      // from_left
-    M >>= 4;
     cur = static_cast<u32>(q) < static_cast<u32>(L) ? (c & j.mv) : 0u;
     best = pk_max(best, cur);
     pub = cur;
   };
-  for (int t = t_start; t <= t_end; t += 2) {
-    if (((t - t_start) & 31) == 0) {
-      Mp = refill(jp, t - dp);
-      Mq = refill(jq, t + 1 - dq);
+  int n = 0;
+#pragma clang loop unroll(disable)
+  for (int seg = 0; seg < 3; ++seg) {
+    const int end = seg == 0 ? n_mid0 : (seg == 1 ? n_mid1 : n_total);
+    while (n < end) {
+      if ((n & 15) == 0) { Mp = refill(jp, n + q0p); Mq = refill(jq, n + q0q); }
+      const int stop = min(end, (n | 15) + 1);
+      if (seg == 1) {
+        for (; n < stop; ++n) { fast(jp, curp, Mp, bestp); fast(jq, curq, Mq, bestq); }
+      }
+      else {
+        for (; n < stop; ++n) { slow(jp, n + q0p, curp, Mp, bestp); slow(jq, n + q0q, curq, Mq, bestq); }
+      }
     }
-    cell(jp, t - dp, curp, Mp, bestp);
-    cell(jq, t + 1 - dq, curq, Mq, bestq);
   }
 }
 

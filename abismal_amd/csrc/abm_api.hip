@@ -194,6 +194,7 @@ struct abm_ctx {
   // optional HIP-event timing of the mapping kernel (abm_ctx_set_timing)
   bool timing = false;
   abm::u32 *read_cycles = nullptr;  // caller-owned device array for the diagnostic kernel
+  abm::u32 *pair_phases = nullptr;  // caller-owned device array [n][8] for the paired-end diagnostic kernels
   bool phase_stamps = false;  // launch the diagnostic kernel variant with in-kernel phase stamps
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -616,6 +617,7 @@ void pe_long_pairs(abm_ctx *ctx, const abm::PeArgs &main, uint64_t n, const char
     a.long_ctmp = ctx->long_ctmp.p;
     a.long_tb_bytes = abm::se_long_tb_bytes(max_len);
     a.pair_diag = nullptr;
+    a.pair_phases = nullptr;
     unsigned long long *counter = ctx->next_read.p + (ctx->launch_seq++ & 63u);
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     a.next_read = counter;
@@ -701,6 +703,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.work = ctx->work.p;
   a.need_big = ctx->need_big.p;
   a.pair_diag = ctx->phase_stamps ? ctx->read_cycles : nullptr;
+  a.pair_phases = ctx->phase_stamps ? ctx->pair_phases : nullptr;
   bool split = ctx->pe_split != 0;  // (0: tier 1 as ONE kernel per pair, as in rounds 1-4 -- same-box comparisons)
   if (const char *e = experiment_env("ABM_PE_SPLIT")) split = e[0] != '0';
   const size_t events_before = ctx->events_used;
@@ -902,6 +905,38 @@ int abm_device_numa_node(int device) {
   std::fclose(f);
   return node;
 }
+int abm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  return guarded([&] {
+    if (!free_bytes || !total_bytes) throw std::invalid_argument("null argument");
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
+  });
+}
+
+// (what pe_device and abm_ctx_reserve allocate on the device for such batches: tier 2's per-wave workspaces, the packed
+// encodings, blobs and offsets, orders and routes, the hand-over area, result slots for the device entry point)
+int abm_ctx_pe_footprint(abm_ctx *ctx, uint64_t n, uint32_t max_len, uint64_t *bytes) {
+  return guarded([&] {
+    if (!ctx || !bytes) throw std::invalid_argument("null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t L = std::min<uint32_t>(std::max<uint32_t>(max_len, 48), abm::kLdsReadLen);
+    const uint64_t W = words_for(L);
+    const int waves = pe_tier2_waves(ctx, L, 0.1);
+    const uint64_t w2 = std::min<uint64_t>(static_cast<uint64_t>(std::max(waves, 0)), std::max<uint64_t>(n, 64));
+    const uint64_t cap = abm::kPeCapLarge;
+    uint64_t b = w2 * (cap * 4 + 4 * cap * 4 + cap * 4 + (32 + 12 * cap) * 4);  // payload, lists, heap, log
+    b += 2 * n * 4 * W * 8;                   // packed encodings of both ends
+    b += 2 * (n * L + (n + 1) * 8);           // blobs and offsets
+    b += n * (4 + 4 + 4 + 1 + 1 + 4 + 4);     // lens x 2, order, class, route, two pair lists
+    b += n * 8 * 2 * 4 + n * 64 * 6;          // hand-over headers and entries
+    b += 4 * n;                               // CIGAR arena (device entry point)
+    *bytes = b + (uint64_t(64) << 20);
+  });
+}
+
 uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx) { return ctx ? ctx->too_long : 0; }
 int abm_ctx_filter_on_planes(const abm_ctx *ctx) { return ctx && ctx->dix.planes[0] != nullptr ? 1 : 0; }
@@ -1128,6 +1163,14 @@ int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles) {
     if (!ctx) throw std::invalid_argument("ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->read_cycles = d_read_cycles;
+  });
+}
+
+int abm_ctx_set_pair_phases(abm_ctx *ctx, uint32_t *d_pair_phases) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->pair_phases = d_pair_phases;
   });
 }
 

@@ -925,6 +925,7 @@ int cmd_idx(int argc, char **argv) {
 // ABM_CLI_PIN=0 leaves every thread where the scheduler puts it (round 3's behaviour).
 struct Topology {
   std::vector<std::vector<int>> primary, all;  // [node] -> CPUs
+  std::vector<int> node_id;                    // [node] -> the system's id of that node (nodes without an allowed CPU are left out)
   bool pinning = true;
   static std::vector<int> parse_list(const std::string &s) {
     std::vector<int> out;
@@ -964,16 +965,23 @@ struct Topology {
       if (p.empty()) p = a;
       primary.push_back(p);
       all.push_back(a);
+      node_id.push_back(n);
     }
     if (all.empty()) {  // no sysfs: one node holding whatever the mask allows
       std::vector<int> a;
       for (int c = 0; c < CPU_SETSIZE; ++c) if (!have_mask || CPU_ISSET(c, &mine)) { if (have_mask || c < static_cast<int>(std::thread::hardware_concurrency())) a.push_back(c); }
       primary.push_back(a);
       all.push_back(a);
+      node_id.push_back(0);
       pinning = false;
     }
   }
   int n_nodes() const { return static_cast<int>(all.size()); }
+  // the index here of the system's node `id` (sysfs numbering), or -1 if this process may not run there
+  int index_of(int id) const {
+    for (size_t k = 0; k < node_id.size(); ++k) if (node_id[k] == id) return static_cast<int>(k);
+    return -1;
+  }
   size_t n_cores() const { size_t k = 0; for (const auto &p : primary) k += p.size(); return k; }
   // the calling thread onto `node`: onto its cores' first siblings while the `group` threads that share the node fit there
   void pin(int node, size_t group) const {
@@ -1176,7 +1184,7 @@ int cmd_map(int argc, char **argv) {
   int most_shared = 1;
   for (size_t g = 0; g < dev_of.size(); ++g)
     most_shared = std::max<int>(most_shared, static_cast<int>(std::count(dev_of.begin(), dev_of.end(), dev_of[g])));
-  const int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
+  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
@@ -1208,6 +1216,32 @@ int cmd_map(int argc, char **argv) {
     }
     for (auto &t : th) t.join();
     if (!err.empty()) { std::cerr << "creating GPU context: " << err << "\n"; return EXIT_FAILURE; }
+    if (paired) {
+      // A paired-end context's workspaces are ~9 GB of device memory for batches of a million pairs (tier 2's per-wave lists
+      // above all): with the index and its tables resident, sixteen of them fit the 288 GB part, not every device and not
+      // every -mappers.  The default follows what is free; an explicit -mappers that cannot fit is an error here,
+      // with the figures, rather than a failing allocation inside the first batch.
+      const uint64_t pairs = opt.batch ? opt.batch : (1u << 20);
+      int fit = 1 << 20;
+      uint64_t need = 0, least_free = 0;
+      for (int g = 0; g < n_gpus; ++g) {
+        uint64_t free_b = 0, total_b = 0, per_ctx = 0;
+        if (!first[g] || abm_device_memory(dev_of[g], &free_b, &total_b) != 0 || abm_ctx_pe_footprint(first[g], pairs, 150, &per_ctx) != 0 || per_ctx == 0) continue;
+        const uint64_t share = static_cast<uint64_t>(std::count(dev_of.begin(), dev_of.end(), dev_of[g]));  // replicas of the run on this device
+        const uint64_t usable = free_b - std::min<uint64_t>(free_b, uint64_t(2) << 30);
+        const int f = static_cast<int>(std::min<uint64_t>(1 << 20, usable / per_ctx / share));
+        if (f < fit) { fit = f; need = per_ctx; least_free = free_b; }
+      }
+      if (fit < per_gpu) {
+        if (opt.mappers > 0 || fit < 1) {
+          std::cerr << "creating GPU contexts: " << per_gpu << " paired-end mapper contexts per GPU need " << (need >> 20) << " MB of device memory each ("
+                    << pairs << " pairs per batch), " << (least_free >> 20) << " MB are free beside the index: at most " << fit << " fit (-mappers, -batch)\n";
+          return EXIT_FAILURE;
+        }
+        if (opt.verbose) std::cerr << "[abismal-amd] " << fit << " mapper contexts per GPU instead of " << per_gpu << ": " << (need >> 20) << " MB each, " << (least_free >> 20) << " MB free\n";
+        per_gpu = fit;
+      }
+    }
     for (int g = 0; g < n_gpus; ++g)
       for (int k = 0; k < per_gpu; ++k) {
         abm_ctx *c = k == 0 ? first[g] : nullptr;
@@ -1219,7 +1253,8 @@ int cmd_map(int argc, char **argv) {
   // blocks, as the GPUs of a real node are wired)
   std::vector<int> gpu_node(n_gpus, 0);
   for (int g = 0; g < n_gpus; ++g) {
-    int node = virtual_gpus ? g * topo.n_nodes() / n_gpus : abm_device_numa_node(dev_of[g]);
+    // (abm_device_numa_node is the system's node id: under a cpuset that leaves a node out the nodes here are renumbered)
+    int node = virtual_gpus ? g * topo.n_nodes() / n_gpus : topo.index_of(abm_device_numa_node(dev_of[g]));
     if (node < 0 || node >= topo.n_nodes()) node = g % topo.n_nodes();
     gpu_node[g] = node;
   }
@@ -1440,6 +1475,7 @@ int cmd_map(int argc, char **argv) {
     std::deque<Slice *> format;                 // mapped, waiting for a worker
     std::condition_variable cv;                 // this node's idle workers
     int idle = 0;
+    int waking = 0;                             // wake-ups sent to idle workers that have not taken mu yet
   };
   std::vector<NodeQueues> nq(n_nodes);
   auto wake_everyone = [&] {
@@ -1448,9 +1484,11 @@ int cmd_map(int argc, char **argv) {
     for (Region &R : regions) { R.cv_flow.notify_all(); R.cv_map.notify_all(); R.cv_write.notify_all(); }
   };
   // a task for `node` has been queued (mu held): one idle worker there, or failing that anywhere, wakes up
+  // (a woken worker only leaves `idle` once it holds mu again: `waking` counts the wake-ups already sent, so that two tasks
+  // queued under one hold of mu wake two workers -- the second one of another node if this node has one idler)
   auto wake_worker = [&](int node) {
-    if (nq[node].idle > 0) { nq[node].cv.notify_one(); return; }
-    for (int n = 0; n < n_nodes; ++n) if (nq[n].idle > 0) { nq[n].cv.notify_one(); return; }
+    if (nq[node].idle > nq[node].waking) { ++nq[node].waking; nq[node].cv.notify_one(); return; }
+    for (int n = 0; n < n_nodes; ++n) if (nq[n].idle > nq[n].waking) { ++nq[n].waking; nq[n].cv.notify_one(); return; }
   };
   std::vector<std::unique_ptr<Batch>> live_batches;
   uint64_t n_batches = 0;
@@ -2411,6 +2449,7 @@ int cmd_map(int argc, char **argv) {
             ++nq[node].idle;
             nq[node].cv.wait(lk);
             --nq[node].idle;
+            if (nq[node].waking > 0) --nq[node].waking;
           }
         }
         if (to_count) count_chunk(ce, ck, count_buf);

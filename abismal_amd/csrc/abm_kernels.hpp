@@ -80,6 +80,9 @@ struct PeArgs {
   u32 *log_ws;                   // tier 2: [grid][32 + 12 cap] lists kept for a deferred best_single
   u32 cap;
   u32 *pair_diag;                // optional [n], diagnostic kernel only: largest set << 16 | shader cycles >> 20
+  u32 *pair_phases;              // optional [n][8], diagnostic kernel only: the pair's shader cycles >> 10 by phase -- probe + narrow,
+                                 // window gather + Hamming, replay, sort + unique, pairable-entry scoring, mating + tracebacks,
+                                 // best_single, single-end fallback (added to: the seed and mate kernels each fill in theirs)
   // the long-end launch only (pairs with an end of kLdsReadLen + 1 .. kMaxReadLen bases, listed in `subset`, packed by
   // list position): per wave, both ends' encodings and bit strings (pe_long_q_words u64), a traceback table
   // (long_tb_bytes) and CIGAR scratch (ctmp_cap rounded up to even), all in global memory

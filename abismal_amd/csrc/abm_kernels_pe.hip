@@ -833,6 +833,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
     w.max_set = 0;
     long long t_pair = 0;
     ABM_STAMP(t_pair);
+    const long long ph0[8] = {w.wt.t_probe, w.wt.t_stream, w.wt.t_replay, w.t_sort, w.t_score, w.t_mate, w.t_single, t_fb};
     w.n_ops[0] = w.n_ops[1] = 0;
     w.ref_len[0] = w.ref_len[1] = 0;
 
@@ -898,6 +899,10 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
       if (TIMED && a.pair_diag)
         a.pair_diag[r] = (min(static_cast<u32>(w.max_set), 0xFFFFu) << 16) |
                          static_cast<u32>(min((phase_stamp() - t_pair) >> 20, 0xFFFFll));
+      if (TIMED && a.pair_phases) {
+        const long long ph1[8] = {w.wt.t_probe, w.wt.t_stream, w.wt.t_replay, w.t_sort, w.t_score, w.t_mate, w.t_single, t_fb};
+        for (int k = 0; k < 8; ++k) a.pair_phases[r * 8 + k] += static_cast<u32>((ph1[k] - ph0[k]) >> 10);
+      }
     }
   }
   if (a.work) {

@@ -384,24 +384,35 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         ctx.set_timing(True)
         ctx.set_phase_stamps(True)
         pd = torch.zeros((n,), dtype=torch.int32, device=dev)
+        pph = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         ctx.set_read_cycles(pd.data_ptr())
+        ctx.set_pair_phases(pph.data_ptr())
         step(slots[0])
         torch.cuda.synchronize()
         ctx.set_phase_stamps(False)
         ctx.set_read_cycles(None)
+        ctx.set_pair_phases(None)
         pdh = pd.cpu().numpy().view(np.uint32)
         size, cyc = (pdh >> 16).astype(np.int64), (pdh & 0xFFFF).astype(np.int64) << 20
         hist = []
-        for lo_, hi_ in ((0, 257), (257, 1025), (1025, 4097), (4097, 16385), (16385, 65536)):
+        pphh = pph.cpu().numpy().view(np.uint32).astype(np.int64) << 10
+        phase_names = ["probe_narrow", "gather_hamming", "replay", "sort_unique", "score_pairable", "mate", "best_single", "se_fallback"]
+        for lo_, hi_ in ((0, 129), (129, 257), (257, 1025), (1025, 4097), (4097, 16385), (16385, 65536)):
             sel = (size >= lo_) & (size < hi_)
+            tot = max(1.0, float(pphh[sel].sum()))
             hist.append({"largest_set": f"{lo_}-{hi_ - 1}", "pairs": int(sel.sum()),
                          "gcycles": round(float(cyc[sel].sum()) / 1e9, 2),
-                         "max_mcycles": round(float(cyc[sel].max()) / 1e6, 1) if sel.any() else 0})
+                         "max_mcycles": round(float(cyc[sel].max()) / 1e6, 1) if sel.any() else 0,
+                         "phase_share_of_the_mating_kernel": {nm: round(float(pphh[sel][:, k].sum()) / tot, 3) for k, nm in enumerate(phase_names)}})
+        # the costliest pairs one by one: what a launch's tail is made of
+        top = np.argsort(-cyc)[:8]
+        slowest = [{"largest_set": int(size[i]), "mcycles": round(float(cyc[i]) / 1e6, 1),
+                    "phase_mcycles": {nm: round(float(pphh[i, k]) / 1e6, 1) for k, nm in enumerate(phase_names)}} for i in top]
         times = ctx.take_kernel_times()
         ctx.set_timing(False)
         tiers = ctx.take_work_tiers()
         tier_work = [dict(t) for t in tiers]
-        diag = {"kernel_ms": dict(zip(launch_names, [round(t, 2) for t in times])), "by_set_size": hist, "tiers": []}
+        diag = {"kernel_ms": dict(zip(launch_names, [round(t, 2) for t in times])), "by_set_size": hist, "slowest_pairs": slowest, "tiers": []}
         for t in tiers:
             tot = max(1, t["cyc_total"])
             diag["tiers"].append({

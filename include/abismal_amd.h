@@ -118,6 +118,11 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out);
  * src/abismal.cpp:1535-1539, :1919-1929). */
 int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired);
 void abm_ctx_destroy(abm_ctx *ctx);
+/* Device memory: free and total bytes of `device` right now (hipMemGetInfo), and what one more context's workspaces for
+ * paired-end batches of n pairs of up to max_len bases will take once reserved -- for a host that has to decide how many
+ * mapper contexts fit beside the index (no reference counterpart: the reference's per-thread scratch is host memory). */
+int abm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+int abm_ctx_pe_footprint(abm_ctx *ctx, uint64_t n, uint32_t max_len, uint64_t *bytes);
 
 /* Single-end batch, host buffers.  Replaces the loop body of
  * map_single_ended / map_single_ended_rand (src/abismal.cpp:1552-1576,
@@ -259,6 +264,10 @@ int abm_ctx_set_phase_stamps(abm_ctx *ctx, int enable);
 int abm_ctx_take_work_tiers(abm_ctx *ctx, uint64_t out[32]);
 /* Diagnostic kernel only: device array [n] receiving per-read shader cycles / 1024 (NULL = off). */
 int abm_ctx_set_read_cycles(abm_ctx *ctx, uint32_t *d_read_cycles);
+/* Paired-end diagnostic kernels only: device array [n][8] (zeroed by the caller) to which the kernels that mate a pair add
+ * its shader cycles / 1024 by phase -- probe + narrow, window gather + Hamming, replay, sort + unique, scoring of the
+ * pairable entries, mating + tracebacks, best_single, single-end fallback (NULL = off). */
+int abm_ctx_set_pair_phases(abm_ctx *ctx, uint32_t *d_pair_phases);
 
 /* Measurement hook: when enabled, every mapping-kernel launch is bracketed by
  * HIP events recorded on the stream it is launched on; take_kernel_time waits

@@ -119,6 +119,7 @@ struct DeviceReplica {
 struct abm_index {
   abm::HostIndex h;
   int want_e2 = -1, want_e3 = -1;  // letters of the seed-extension tables; -1 = chosen from the index's size
+  int cap_e2 = 7, cap_e3 = 4;      // ... but no more than these (abm_index_set_seed_extension_cap)
   mutable std::mutex mu;  // guards the map itself and the wishes below (a replica's contents: DeviceReplica::mu)
   mutable std::map<int, DeviceReplica> replicas;  // by device ordinal; nodes stay for the index's lifetime
   uint32_t want_maxc = 0;  // max_candidates the tables are built for; 0 = the index file's
@@ -222,8 +223,8 @@ void build_ext(DeviceReplica &rep, const abm_index &ix, abm::u32 maxc) {
   const uint64_t n_bases = h.chrom_starts.empty() ? 0 : h.chrom_starts.back();
   int e2 = ix.want_e2, e3 = ix.want_e3;
   if (const char *e = experiment_env("ABM_EXT_LETTERS")) { int a = 0, b = 0; if (std::sscanf(e, "%d,%d", &a, &b) == 2) { e2 = a; e3 = b; } }
-  if (e2 < 0) { e2 = 0; while (e2 < 7 && abm::ext_keys(0, e2) < n_bases) ++e2; }
-  if (e3 < 0) { e3 = 0; while (e3 < 4 && abm::ext_keys(1, e3) < n_bases) ++e3; }
+  if (e2 < 0) { e2 = 0; while (e2 < ix.cap_e2 && abm::ext_keys(0, e2) < n_bases) ++e2; }
+  if (e3 < 0) { e3 = 0; while (e3 < ix.cap_e3 && abm::ext_keys(1, e3) < n_bases) ++e3; }
   e2 = std::min(e2, 7); e3 = std::min(e3, 4);
   if (e2 <= 0 || e3 <= 0) return;
   auto need = [&](int a, int b) {
@@ -980,6 +981,16 @@ int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3) {
   });
 }
 
+int abm_index_set_seed_extension_cap(abm_index *ix, int letters2, int letters3) {
+  return guarded([&] {
+    if (!ix) throw std::invalid_argument("index is null");
+    if (letters2 < 0 || letters2 > 7 || letters3 < 0 || letters3 > 4) throw std::invalid_argument("seed-extension caps: 0..7 and 0..4 letters");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->cap_e2 = letters2;
+    ix->cap_e3 = letters3;
+  });
+}
+
 int abm_index_set_direct_narrowing(abm_index *ix, uint32_t min_entries) {
   return guarded([&] {
     if (!ix) throw std::invalid_argument("index is null");
@@ -1508,6 +1519,14 @@ int abm_ctx_pe_split_stats(abm_ctx *ctx, uint64_t out[4]) {
 
 uint32_t abm_ctx_pe_timed_launches(const abm_ctx *ctx) { return ctx ? ctx->pe_timed_launches : 0; }
 
+uint64_t abm_ctx_pinned_bytes(const abm_ctx *c) {
+  if (!c) return 0;
+  uint64_t b = 0;
+  b += (c->h_cn.cap + c->h_slots.cap + c->h_arena.cap + c->h_cn2.cap + c->h_slots2.cap + c->h_tail.cap + c->h_slice_first.cap + c->h_slice_done.cap) * 4;
+  b += (c->h_rel.cap + c->h_rel2.cap + c->h_res.cap + c->h_pe_out.cap) * 8;
+  return b;
+}
+
 int abm_map_pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n,
                       const char *d_seq_blob1, const uint64_t *d_seq_off1, const char *d_seq_blob2,
                       const uint64_t *d_seq_off2, uint32_t max_len, abm_pair *d_pair,
@@ -1637,6 +1656,17 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
         ctx->blob2.reserve(n * L); ctx->off2.reserve(n + 1);
         ctx->packed2.reserve(n * 4 * W); ctx->lens2.reserve(n);
         ctx->need_big.reserve(n); ctx->subset.reserve(n); ctx->subset_count.reserve(1);
+        // (the phase split's hand-over area and second pair list, sized as pe_device sizes them for a batch of n pairs in the
+        // random-PBAT mode's eight lists per pair: growing them mid-run frees the old ones, and hipFree waits for the whole
+        // device -- the split's first end-to-end run lost half its rate to exactly that, profiles/r05_pe_e2e_regrowth.log)
+        ctx->hand_hdr.reserve(n * 8 * 2); ctx->hand_count.reserve(1);
+        {
+          const abm::u32 scap = std::min<abm::u32>(16384, std::max<abm::u32>(abm::kPeTier1Cap, ctx->pe_scap ? ctx->pe_scap : abm::kPeTier1Cap));
+          const size_t hand_cap = ctx->hand_want ? std::max<size_t>(ctx->hand_want, 64) : std::min<size_t>(std::max<size_t>(n * (scap > abm::kPeTier1Cap ? 256 : 64), size_t(1) << 16), 0xFFFFFF00u);
+          ctx->hand_pos.reserve(hand_cap); ctx->hand_d.reserve(hand_cap);
+        }
+        ctx->subset_b.reserve(n); ctx->subset_count_b.reserve(1); ctx->class33_b.reserve(33);
+        ctx->lens.reserve(n); ctx->order.reserve(n); ctx->cls.reserve(n); ctx->class33.reserve(33); ctx->next_read.reserve(64); ctx->work.reserve(32);
         ctx->h_pe_out.reserve(n * 5);
         {  // tier 2's workspaces for batches of n pairs (a full grid of waves from a few thousand pairs on)
           const int waves = pe_tier2_waves(ctx, L, 0.1);

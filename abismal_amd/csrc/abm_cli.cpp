@@ -61,6 +61,7 @@ struct Stats3 { Stats s[3]; };  // SE: s[0]; PE: pairs, read1, read2
 
 // A batch's FASTQ text: grown with realloc (large blocks are remapped, not copied, and never
 // zero-filled) and recycled through a small pool so that its pages stay faulted in.
+std::atomic<uint64_t> g_pinned_bytes{0};  // page-locked memory the run has asked the library for (batches' read buffers)
 struct RawBuf {
   char *p = nullptr;
   size_t n = 0, cap = 0;
@@ -80,6 +81,7 @@ struct RawBuf {
     if (pinned) {
       void *v = nullptr;
       if (abm_host_alloc(want, &v) != 0) throw std::bad_alloc();
+      g_pinned_bytes += want - cap;
       q = static_cast<char *>(v);
       if (n) std::memcpy(q, p, n);
       abm_host_free(p);
@@ -1184,9 +1186,13 @@ int cmd_map(int argc, char **argv) {
   int most_shared = 1;
   for (size_t g = 0; g < dev_of.size(); ++g)
     most_shared = std::max<int>(most_shared, static_cast<int>(std::count(dev_of.begin(), dev_of.end(), dev_of[g])));
-  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
+  // (round 5: with the pair kernels split by phase 8 contexts carry what 16 did -- 3.80-3.91 M reads/s end to end on 8 M
+  // pairs against 3.15-3.93 with 16, profiles/r05_pe_e2e_after_reserve.log -- at half the device memory)
+  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 8 / most_shared) : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
+    // (pairs: 6 + 3 letters at most -- as fast as 7 + 4 for the pair kernels, 54 GB less of device memory at hg38 scale)
+    if (opt.ext2 < 0 && paired && abm_index_set_seed_extension_cap(ix, 6, 3) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
     const int visible = abm_device_count();
     if (visible <= 0) { std::cerr << "creating GPU context: no HIP device present (the mapping path has no CPU fallback)\n"; return EXIT_FAILURE; }
@@ -1339,6 +1345,7 @@ int cmd_map(int argc, char **argv) {
   // the paired-end path takes them); virtual GPUs hand their made-up hits over the same way
   const bool stream_slices = !paired && !std::getenv("ABM_CLI_NO_STREAM");
   // size of a GPU's first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
+  const size_t pe_taper = [] { const char *e = std::getenv("ABM_CLI_PE_TAPER"); return e ? static_cast<size_t>(std::max<long long>(0, std::atoll(e))) : size_t(4); }();  // paired-end batches near the end of the input: at most 1 / this of what is left (0 = off)
   const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", stream_slices ? 1u << 19 : (paired ? 1u << 17 : 1u << 21)));
   // BGZF-compressed input (bgzip): its blocks are independent, so the workers inflate them side by side into one
   // anonymous mapping that then IS the input as far as counting, cutting and parsing go (a single-member .gz, what plain
@@ -1614,6 +1621,8 @@ int cmd_map(int argc, char **argv) {
   struct rusage ru0;
   ::getrusage(RUSAGE_SELF, &ru0);
   const auto t_start = std::chrono::steady_clock::now();
+  double count_done_s = 0;                           // when the last chunk's newlines were counted (plain input)
+  std::vector<double> region_first_batch_s(n_regions, -1.0);  // when each region's first batch was handed to a mapper
 
   // seconds of work, summed over threads (the wait for the pipeline's lock is not in them: round 3's figures included it)
   double busy_split = 0, busy_parse = 0, busy_map = 0, busy_format = 0, busy_write = 0, lock_wait = 0;
@@ -1847,6 +1856,7 @@ int cmd_map(int argc, char **argv) {
       lf[e].chunks[k] = std::move(ci);
       ++lf[e].n_ready;
       busy_split += dt;
+      if (lf[e].n_ready == lf[e].n_chunks) count_done_s = std::max(count_done_s, since(t_start));
     }
     cv_chunk.notify_all();
   };
@@ -2067,6 +2077,11 @@ int cmd_map(int argc, char **argv) {
               cap = std::min<size_t>(batch_reads, std::max<size_t>(slice_reads, first_batch_reads >= (batch_reads >> grown) ? batch_reads : first_batch_reads << grown));
             if (!R.cut_done) return cap;
             const size_t left = static_cast<size_t>(R.n_slices - R.next_to_map) * slice_reads;
+            // (pairs: a batch's launch is as long as its costliest pair -- a second for a pair with two 32768-entry sets, of
+            // which a million pairs hold some five hundred -- and nothing hides the LAST batch's: so the batches taper off
+            // towards the end of the input, each at most a quarter of what is left, down to single slices, whose few such
+            // pairs are rarely the worst; profiles/r05_pe_e2e_taper.log)
+            if (paired && pe_taper) cap = std::min(cap, std::max<size_t>(slice_reads, (left / pe_taper + slice_reads - 1) / slice_reads * slice_reads));
             size_t k = (left + cap - 1) / cap;
             if (k <= 1) k = (!stream_slices && left >= (1u << 22)) ? 2 : 1;
             k = std::max<size_t>(k, std::min<size_t>(static_cast<size_t>(R.mappers_live + per_gpu - 1) / per_gpu, (left + (1u << 20) - 1) >> 20));
@@ -2095,6 +2110,7 @@ int cmd_map(int argc, char **argv) {
             ++R.next_to_map;
           }
           b->seq = n_batches++;
+          { const int rr = region_of(g, slot % per_gpu); if (region_first_batch_s[rr] < 0) region_first_batch_s[rr] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); }
           b->gpu = g;
           b->node = node;
           ++gpu_batches[g];
@@ -2609,7 +2625,15 @@ int cmd_map(int argc, char **argv) {
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_batches[g];
     tj << "], \"reads_per_gpu\": [";
     for (int g = 0; g < n_gpus; ++g) tj << (g ? ", " : "") << gpu_reads[g];
-    tj << "], \"cpu_quota_cpus\": " << quota.cpus << ", \"throttled_periods\": " << (throttled1 - throttled0) << ", \"throttled_s\": " << (throttled_s1 - throttled_s0)
+    tj << "], \"region_first_batch_s\": [";
+    for (int r = 0; r < n_regions; ++r) tj << (r ? ", " : "") << region_first_batch_s[r];
+    struct rusage ru_end;
+    getrusage(RUSAGE_SELF, &ru_end);
+    uint64_t lib_pinned = 0;
+    for (abm_ctx *c : ctxs) lib_pinned += abm_ctx_pinned_bytes(c);
+    tj << "], \"count_done_s\": " << count_done_s << ", \"peak_rss_mb\": " << (ru_end.ru_maxrss >> 10)
+       << ", \"pinned_mb\": {\"batches\": " << (g_pinned_bytes.load() >> 20) << ", \"library_contexts\": " << (lib_pinned >> 20) << "}";
+    tj << ", \"cpu_quota_cpus\": " << quota.cpus << ", \"throttled_periods\": " << (throttled1 - throttled0) << ", \"throttled_s\": " << (throttled_s1 - throttled_s0)
        << ", \"cpu_s\": {\"user\": " << cpu_user << ", \"sys\": " << cpu_sys << "}, \"busy_s\": {\"split\": " << busy_split
        << ", \"parse\": " << busy_parse << ", \"map\": " << busy_map << ", \"format\": " << busy_format << ", \"write\": "
        << busy_write << ", \"lock_wait\": " << lock_wait << "}}\n";

@@ -527,6 +527,8 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
                 "tier2_share_of_candidates": round(tier_work[1].get("candidates", 0) / max(1, tw["candidates"]), 3),
                 "strict_counts_per_pair": {k: round(v, 2) for k, v in strict.items()} if cpu is not None else None}
     n_slots = len(slots)
+    ext_pe = ctx.seed_extension()
+    seed_tables_pe = {"letters_2": ext_pe[0], "letters_3": ext_pe[1], "gb": round(ext_pe[2] / 1e9, 2)}
     e2e = None
     if not args.no_e2e:
         # SURVEY 8(d)'s window for config 3: product sim (2 x L, fragments 150-500) -> two FASTQ files -> abismal-amd map ->
@@ -561,7 +563,7 @@ def run_pe(args, A, ctx, index, genome_words, starts, dev, world, rank, barrier)
         "roofline": roofline, "cpu_baseline": cpu,
         "e2e_reads_per_s": e2e.get("value") if isinstance(e2e, dict) else None,
         "e2e_over_kernel": round(e2e["value"] / pe_value, 4) if isinstance(e2e, dict) and e2e.get("value") else None,
-        "e2e": e2e, "kernel_status": kstat, "phase_stamps": diag,
+        "e2e": e2e, "kernel_status": kstat, "phase_stamps": diag, "seed_extension_tables": seed_tables_pe,
         "mapping": {"pairs": n_pairs, "concordant": n_conc, "ends_mapped_single": n_single}}), flush=True)
 
 
@@ -1012,6 +1014,8 @@ def main():
     if args.seed_ext:
         ext_arg = tuple(int(x) for x in args.seed_ext.split(","))
     index = A.Index(idx, seed_extension=ext_arg)
+    if args.pe and ext_arg is None:
+        index.set_seed_extension_cap(6, 3)  # (as `abismal-amd map` does for pairs: as fast as 7 + 4 for the pair kernels, 54 GB less)
     ctx = A.Context(index, local_rank)
     on_planes = ctx.filter_on_planes()
     filter_genome = "bit planes (cooperative window loads)" if on_planes else "nibble array (one lane per window)"

@@ -89,6 +89,10 @@ uint32_t abm_index_window(const abm_index *ix);
  * abm_index_set_max_candidates before the context was created); a call with another value runs without them --
  * nothing is ever rebuilt inside a mapping call.  abm_ctx_rebuild_seed_extension rebuilds them explicitly. */
 int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3);
+/* The automatic choice (letters from the index's size) capped at these: at hg38 scale 7 + 4 letters are 90 GB and 6 + 3
+ * are 36 GB; the single-end kernel is 1.6 % faster with the former, the pair kernels 3 % faster with the latter
+ * (profiles/r05_exp_tables_repriced.log) -- so a host that maps pairs caps at 6 and 3.  Contexts created afterwards. */
+int abm_index_set_seed_extension_cap(abm_index *ix, int letters2, int letters3);
 /* the max_candidates (-c, src/abismal.cpp:2329) the calls on this index will pass, when it is not the value stored
  * in the index file: the tables of contexts created afterwards are built for it (0 = the file's value) */
 int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates);
@@ -218,6 +222,8 @@ int abm_ctx_pe_split_stats(abm_ctx *ctx, uint64_t out[4]);
 /* HIP-event brackets (abm_ctx_set_timing) the context's last paired-end call recorded, in launch order: split -- seed,
  * mate (LDS lists), mate (lists in device memory), whole pairs = 4; unsplit -- tier 1, tier 2 = 2. */
 uint32_t abm_ctx_pe_timed_launches(const abm_ctx *ctx);
+/* page-locked host memory the context holds for results on their way out (its pinned staging buffers), bytes */
+uint64_t abm_ctx_pinned_bytes(const abm_ctx *ctx);
 
 /* the arena of CIGARs longer than their slot left by the context's last device call (waits for it) */
 int abm_ctx_long_cigars(abm_ctx *ctx, uint32_t *out_ops, uint64_t capacity, uint64_t *n_ops);

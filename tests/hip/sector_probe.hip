@@ -81,5 +81,12 @@ int main() {
   // the same gathers from a table the Infinity Cache holds (192 MB)
   run<0>(d, 192ull << 20, "hipMalloc, plain loads, 192 MB table", dout);
   run<1>(d, 192ull << 20, "hipMalloc, nt loads, 192 MB table", dout);
+  // ... and from tables the L2s hold (4 MB per XCD, every XCD caching its own copy of whatever its CUs ask for): what a
+  // region-binned filter pass would gather its windows from (round 5)
+  for (uint64_t mb : {1ull, 2ull, 4ull, 8ull, 16ull, 64ull}) {
+    char label[96];
+    snprintf(label, sizeof(label), "hipMalloc, plain loads, %llu MB table", static_cast<unsigned long long>(mb));
+    run<0>(d, mb << 20, label, dout);
+  }
   return 0;
 }

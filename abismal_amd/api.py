@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "abm_map_se_batch", "abm_map_se_batch_sliced", "abm_ctx_slice_results", "abm_map_se_device", "abm_map_pe_batch", "abm_map_pe_device",
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
     "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_index_set_direct_narrowing", "abm_ctx_seed_extension", "abm_ctx_rebuild_seed_extension", "abm_device_numa_node",
-    "abm_ctx_set_pe_split", "abm_ctx_pe_split_stats", "abm_ctx_pe_timed_launches", "abm_ctx_set_pair_phases", "abm_device_memory", "abm_ctx_pe_footprint", "abm_index_set_seed_extension_cap", "abm_ctx_pinned_bytes",
+    "abm_ctx_set_pe_split", "abm_ctx_pe_split_stats", "abm_ctx_pe_timed_launches", "abm_ctx_set_pair_phases", "abm_device_memory", "abm_ctx_pe_footprint", "abm_index_set_seed_extension_cap", "abm_ctx_pinned_bytes", "abm_ctx_set_sam_tails", "abm_ctx_slice_sam_tails",
 ]
 
 

@@ -180,6 +180,12 @@ struct abm_ctx {
   uint32_t sliced_stride = 0;      // slot width of the results abm_ctx_slice_results reads
   uint64_t sliced_reads = 0;
   bool host_results = false;        // set by abm_map_se_batch around its launches: arena and summary words in pinned memory
+  // SAM text written by the single-end kernel (abm_ctx_set_sam_tails): the line after QNAME per read, in pinned memory
+  bool sam_on = false;
+  int sam_allow_ambig = 0;
+  uint32_t sam_stride = 0;          // of the launch whose results the buffers hold
+  HostBuf<char> h_sam;
+  HostBuf<abm::u32> h_sam_len;
   HostBuf<abm_hit> h_res;           // hits on their way out (a pinned target keeps the copy on the DMA engines)
   HostBuf<abm_hit> h_pe_out;        // paired-end results (pairs, then both fallback hits) written by the kernels, pinned
   unsigned launch_seq = 0;
@@ -269,6 +275,13 @@ void build_ext(DeviceReplica &rep, const abm_index &ix, abm::u32 maxc) {
 abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc);
 
 abm::u32 words_for(abm::u32 max_len) { return std::max(1u, (max_len + 15) / 16); }
+// bytes of a read's SAM-text slot (SeArgs::sam_stride): longest read + longest chromosome name + the fixed fields and a
+// slot's CIGAR as text, in whole 16 bytes
+abm::u32 sam_stride_for(const abm_ctx *ctx, abm::u32 eff_len, abm::u32 cig_stride) {
+  size_t longest_name = 0;
+  for (const std::string &nm : ctx->ix->h.chrom_names) longest_name = std::max(longest_name, nm.size());
+  return static_cast<abm::u32>((eff_len + longest_name + 64 + 12 * static_cast<size_t>(std::min<abm::u32>(cig_stride, 8)) + 15) & ~static_cast<size_t>(15));
+}
 abm::u32 bitwords_for(abm::u32 max_len) { return (max_len + 63) / 64 + 1; }
 
 void check_params(const abm_params *p) {
@@ -444,6 +457,21 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   a.cig_n = d_cig_n;
   a.status = d_status;
   a.work = ctx->work.p;
+  a.blob = d_blob;
+  a.off = reinterpret_cast<const abm::u64 *>(d_off);
+  ctx->sam_stride = 0;
+  if (ctx->sam_on && ctx->host_results && sliced) {
+    // the kernel writes every read's SAM text (after QNAME) next to its hit; a line that does not fit its slot is formatted
+    // by the host as before
+    const abm::u32 stride = sam_stride_for(ctx, eff_len, cig_stride);
+    ctx->h_sam.reserve(static_cast<size_t>(n) * stride);
+    ctx->h_sam_len.reserve(n);
+    a.sam_tail = ctx->h_sam.p;
+    a.sam_len = ctx->h_sam_len.p;
+    a.sam_stride = stride;
+    a.sam_allow_ambig = ctx->sam_allow_ambig;
+    ctx->sam_stride = stride;
+  }
   // a small ring of work counters so launches queued on different streams never share one
   ctx->next_read.reserve(64);
   auto fresh_counter = [&](hipStream_t on) {
@@ -1076,7 +1104,7 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
                                 h.index_a.size() * 4};
           const void *src[7] = {h.genome.data(),    h.counter.data(), h.counter_t.data(), h.counter_a.data(),
                                 h.index.data(),     h.index_t.data(), h.index_a.data()};
-          size_t offs[10], total = 0;
+          size_t offs[11], total = 0;
           for (int k = 0; k < 7; ++k) { offs[k] = total; total += up(sz[k] + 64); }
           // the filter's bit-plane copies of the genome (DevIndex::planes), derived on the device
           const uint64_t n_bases = h.chrom_starts.empty() ? 0 : h.chrom_starts.back();
@@ -1084,6 +1112,13 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
           for (int k = 7; k < 9; ++k) { offs[k] = total; total += up(n_blocks * 16 + 128); }
           const uint64_t nmap_words = n_blocks ? ((n_bases >> abm::kPlaneChunkBits) + 64) / 32 + 1 : 0;
           offs[9] = total; total += up(nmap_words * 4 + 64);
+          // the chromosome table (starts, name offsets, names) for the kernels that write SAM text themselves
+          const size_t n_chr = h.chrom_names.size();
+          std::vector<abm::u32> name_off(n_chr + 1, 0);
+          std::string names_cat;
+          for (size_t k = 0; k < n_chr; ++k) { name_off[k] = static_cast<abm::u32>(names_cat.size()); names_cat += h.chrom_names[k]; }
+          name_off[n_chr] = static_cast<abm::u32>(names_cat.size());
+          offs[10] = total; total += up((n_chr + 1) * 8 + names_cat.size() + 64);
           void *arena = nullptr;
           HIPCHK(hipMalloc(&arena, total));
           try {
@@ -1103,6 +1138,16 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
             rep.dix.min_len = abm::kKeyWeight + h.window - 1;
             rep.dix.planes[0] = rep.dix.planes[1] = nullptr;
             rep.dix.nmap = nullptr;
+            {
+              char *ct = base + offs[10];
+              HIPCHK(hipMemcpy(ct, h.chrom_starts.data(), (n_chr + 1) * 4, hipMemcpyHostToDevice));
+              HIPCHK(hipMemcpy(ct + (n_chr + 1) * 4, name_off.data(), (n_chr + 1) * 4, hipMemcpyHostToDevice));
+              if (!names_cat.empty()) HIPCHK(hipMemcpy(ct + (n_chr + 1) * 8, names_cat.data(), names_cat.size(), hipMemcpyHostToDevice));
+              rep.dix.chrom_starts = reinterpret_cast<const abm::u32 *>(ct);
+              rep.dix.chrom_name_off = reinterpret_cast<const abm::u32 *>(ct + (n_chr + 1) * 4);
+              rep.dix.chrom_names = ct + (n_chr + 1) * 8;
+              rep.dix.n_chroms = static_cast<abm::u32>(n_chr);
+            }
             if (n_blocks) {
               auto *p0 = reinterpret_cast<abm::u64 *>(base + offs[7]), *p1 = reinterpret_cast<abm::u64 *>(base + offs[8] + 64);
               abm::u32 *d_bad = reinterpret_cast<abm::u32 *>(base + offs[8]);  // (the first 64 bytes of copy 1's array are free)
@@ -1153,7 +1198,7 @@ void abm_ctx_destroy(abm_ctx *c) {
       c->rep->arena = nullptr;
     }
   }
-  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->hand_hdr.release(); c->hand_pos.release(); c->hand_d.release(); c->hand_count.release(); c->split_stats.release(); c->stage_pos.release(); c->stage_d.release(); c->subset_b.release(); c->subset_count_b.release(); c->class33_b.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_pe_out.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
+  c->packed.release(); c->packed2.release(); c->lens2.release(); c->subset.release(); c->subset_count.release(); c->payload1.release(); c->payload2.release(); c->list2.release(); c->heap2.release(); c->log2.release(); c->need_big.release(); c->hand_hdr.release(); c->hand_pos.release(); c->hand_d.release(); c->hand_count.release(); c->split_stats.release(); c->stage_pos.release(); c->stage_d.release(); c->subset_b.release(); c->subset_count_b.release(); c->class33_b.release(); c->pe_out.release(); c->cig2h.release(); c->cig_n2h.release(); c->blob2.release(); c->off2.release(); c->coff.release(); c->scan_tmp.release(); c->cblob.release(); c->lens.release(); c->long_list.release(); c->long_count.release(); c->long_ctmp.release(); c->packed_long.release(); c->packed_long2.release(); c->long_q.release(); c->long_tb.release(); c->order.release(); c->class33.release(); c->cls.release(); c->work.release(); c->next_read.release(); c->cig_arena.release(); c->cig_arena_count.release(); c->h_cn.release(); c->h_slots.release(); c->h_arena.release(); c->h_cn2.release(); c->h_slots2.release(); c->h_rel.release(); c->h_rel2.release(); c->h_res.release(); c->h_pe_out.release(); c->h_sam.release(); c->h_sam_len.release(); c->h_tail.release(); c->finished.release(); c->blob.release(); c->off.release();
   c->res.release(); c->cig.release(); c->cig_n.release(); c->status.release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -1484,6 +1529,27 @@ int abm_ctx_slice_results(abm_ctx *ctx, uint64_t lo, uint64_t hi, abm_hit *out_r
   });
 }
 
+int abm_ctx_set_sam_tails(abm_ctx *ctx, int enable, int allow_ambig) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->sam_on = enable != 0;
+    ctx->sam_allow_ambig = allow_ambig != 0;
+  });
+}
+
+int abm_ctx_slice_sam_tails(abm_ctx *ctx, uint64_t lo, uint64_t hi, const char **tails, uint32_t *stride, const uint32_t **lens) {
+  return guarded([&] {
+    if (!ctx || !tails || !stride || !lens) throw std::invalid_argument("null argument");
+    if (lo > hi || hi > ctx->sliced_reads) throw std::invalid_argument("slice range outside the batch");
+    // (no lock: called from inside the sliced entry point's callback, which holds it)
+    if (ctx->sam_stride == 0) { *tails = nullptr; *lens = nullptr; *stride = 0; return; }
+    *tails = ctx->h_sam.p + lo * ctx->sam_stride;
+    *lens = ctx->h_sam_len.p + lo;
+    *stride = ctx->sam_stride;
+  });
+}
+
 int abm_ctx_set_pe_split(abm_ctx *ctx, int split, uint32_t seed_cap, uint64_t hand_entries) {
   return guarded([&] {
     if (!ctx) throw std::invalid_argument("ctx is null");
@@ -1647,6 +1713,7 @@ int abm_ctx_reserve(abm_ctx *ctx, uint64_t n, uint32_t max_len, int paired) {
       ctx->h_arena.reserve(std::max<size_t>({ctx->arena_want, size_t(1) << 16, static_cast<size_t>(paired ? 4 * n : 2 * n)}));
       if (!paired) {
         ctx->res.reserve(n); ctx->h_res.reserve(n);
+        if (ctx->sam_on) { ctx->h_sam.reserve(static_cast<size_t>(n) * sam_stride_for(ctx, L, stride)); ctx->h_sam_len.reserve(n); }
         // (slices of at least 4096 reads; smaller ones make these buffers grow, which only tests do)
         const size_t ns = n / 4096 + 2;
         ctx->slice_id.reserve(n); ctx->slice_left.reserve(ns); ctx->slice_hist.reserve(abm::order_sliced_hist_words(static_cast<abm::u32>(ns)));

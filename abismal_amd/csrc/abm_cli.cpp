@@ -178,6 +178,11 @@ struct Slice {
   PodVec<abm_hit> own_se;
   PodVec<uint32_t> own_cig;
   PodVec<uint64_t> own_cig_off;
+  // ... and, when the kernel wrote the reads' SAM text itself (abm_ctx_set_sam_tails), every read's line after QNAME:
+  // lengths (0 = no record, 0xFFFFFFFF = format it here) and the text, one after the other
+  bool has_tails = false;
+  PodVec<uint32_t> tail_len;
+  RawBuf tail_text;
 };
 
 // written slices are recycled with their buffers (names, reads, output text keep their capacity): a
@@ -1186,9 +1191,10 @@ int cmd_map(int argc, char **argv) {
   int most_shared = 1;
   for (size_t g = 0; g < dev_of.size(); ++g)
     most_shared = std::max<int>(most_shared, static_cast<int>(std::count(dev_of.begin(), dev_of.end(), dev_of[g])));
-  // (round 5: with the pair kernels split by phase 8 contexts carry what 16 did -- 3.80-3.91 M reads/s end to end on 8 M
-  // pairs against 3.15-3.93 with 16, profiles/r05_pe_e2e_after_reserve.log -- at half the device memory)
-  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 8 / most_shared) : 2);
+  // (round 5, the pair kernels split by phase: on 8 M pairs 8 contexts carry what 16 do -- 3.80-3.91 M reads/s end to end
+  // against 3.15-3.93, profiles/r05_pe_e2e_after_reserve.log -- but on 50 M pairs 16 give 5.57 M reads/s and 8 give 4.80,
+  // profiles/r05_full_size.log: 16 it stays, as many as the device's free memory holds -- see below)
+  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
     // (pairs: 6 + 3 letters at most -- as fast as 7 + 4 for the pair kernels, 54 GB less of device memory at hg38 scale)
@@ -1206,6 +1212,7 @@ int cmd_map(int argc, char **argv) {
   }
   bool shared_device = false;
   for (int g = 0; g < n_gpus; ++g) for (int h = 0; h < g; ++h) shared_device |= dev_of[g] >= 0 && dev_of[g] == dev_of[h];
+  const bool device_sam = !paired && !opt.bam && !virtual_gpus && !std::getenv("ABM_CLI_NO_STREAM") && !std::getenv("ABM_CLI_HOST_FORMAT");
   std::vector<abm_ctx *> ctxs;  // [g * per_gpu + k]
   if (!virtual_gpus) {
     // the first context on a device uploads the index and derives its tables there: every device's at the same time
@@ -1289,6 +1296,11 @@ int cmd_map(int argc, char **argv) {
         reserve_reads = std::min<size_t>(reserve_reads, static_cast<size_t>(sb.st_size) * (gz ? 10 : 1) / (2 * std::max<uint32_t>(first_len, 1) + 4) + 256);
       }
     }
+    // single-end SAM text: the kernel writes every read's line after QNAME itself (abm_ctx_set_sam_tails), the formatters
+    // put names in front -- half of the host's CPU time per read was building that text base by base.  BAM records are
+    // built from the fields as before; ABM_CLI_HOST_FORMAT=1: SAM text too (same-box comparisons, tests)
+    if (device_sam)
+      for (abm_ctx *c : ctxs) if (abm_ctx_set_sam_tails(c, 1, opt.ambig ? 1 : 0) != 0) die_abm("SAM text on the device");
     std::vector<std::thread> warm;
     std::exception_ptr werr;
     std::mutex wmu;
@@ -1345,7 +1357,8 @@ int cmd_map(int argc, char **argv) {
   // the paired-end path takes them); virtual GPUs hand their made-up hits over the same way
   const bool stream_slices = !paired && !std::getenv("ABM_CLI_NO_STREAM");
   // size of a GPU's first batch (see the mapper's target()); ABM_CLI_FIRST_BATCH=n overrides, a huge n = no special first batch
-  const size_t pe_taper = [] { const char *e = std::getenv("ABM_CLI_PE_TAPER"); return e ? static_cast<size_t>(std::max<long long>(0, std::atoll(e))) : size_t(4); }();  // paired-end batches near the end of the input: at most 1 / this of what is left (0 = off)
+  // paired-end batches near the end of the input at most 1 / ABM_CLI_PE_TAPER of what is left (0 = off, the default: see target())
+  const size_t pe_taper = [] { const char *e = std::getenv("ABM_CLI_PE_TAPER"); return e ? static_cast<size_t>(std::max<long long>(0, std::atoll(e))) : size_t(0); }();
   const size_t first_batch_reads = static_cast<size_t>(env_or("ABM_CLI_FIRST_BATCH", stream_slices ? 1u << 19 : (paired ? 1u << 17 : 1u << 21)));
   // BGZF-compressed input (bgzip): its blocks are independent, so the workers inflate them side by side into one
   // anonymous mapping that then IS the input as far as counting, cutting and parsing go (a single-member .gz, what plain
@@ -2078,9 +2091,10 @@ int cmd_map(int argc, char **argv) {
             if (!R.cut_done) return cap;
             const size_t left = static_cast<size_t>(R.n_slices - R.next_to_map) * slice_reads;
             // (pairs: a batch's launch is as long as its costliest pair -- a second for a pair with two 32768-entry sets, of
-            // which a million pairs hold some five hundred -- and nothing hides the LAST batch's: so the batches taper off
-            // towards the end of the input, each at most a quarter of what is left, down to single slices, whose few such
-            // pairs are rarely the worst; profiles/r05_pe_e2e_taper.log)
+            // which a million pairs hold some five hundred -- and nothing hides the LAST batch's.  Tapering the batches off
+            // towards the end of the input (each at most 1 / ABM_CLI_PE_TAPER of what is left) was tried and COSTS: 8 M pairs
+            // 3.80-3.86 M reads/s without, 3.45-3.73 with a quarter, 3.2 with an eighth -- more batches, the same worst pair;
+            // profiles/r05_pe_e2e_taper.log.  Off by default.)
             if (paired && pe_taper) cap = std::min(cap, std::max<size_t>(slice_reads, (left / pe_taper + slice_reads - 1) / slice_reads * slice_reads));
             size_t k = (left + cap - 1) / cap;
             if (k <= 1) k = (!stream_slices && left >= (1u << 22)) ? 2 : 1;
@@ -2274,8 +2288,8 @@ int cmd_map(int argc, char **argv) {
               first[0] = lead;
               for (size_t k = 0; k < b->slices.size(); ++k) first[k + 1] = first[k] + b->slices[k]->n();
               struct Taker {
-                abm_ctx *ctx; Batch *b; const std::vector<uint64_t> *first; decltype(queue_slice) *queue; int rc; std::string err;
-              } taker{ctx, b, &first, &queue_slice, 0, std::string()};
+                abm_ctx *ctx; Batch *b; const std::vector<uint64_t> *first; decltype(queue_slice) *queue; int rc; std::string err; bool device_sam;
+              } taker{ctx, b, &first, &queue_slice, 0, std::string(), device_sam};
               auto on_done = [](void *user, uint32_t s) {
                 Taker &t = *static_cast<Taker *>(user);
                 Slice &sl = *t.b->slices[s];
@@ -2292,6 +2306,24 @@ int cmd_map(int argc, char **argv) {
                   t.err = abm_last_error();
                 }
                 sl.own = true;
+                sl.has_tails = false;
+                if (t.rc == 0 && t.device_sam) {
+                  const char *tails = nullptr; const uint32_t *lens = nullptr; uint32_t stride = 0;
+                  if (abm_ctx_slice_sam_tails(t.ctx, lo, hi, &tails, &stride, &lens) != 0) { t.rc = -1; t.err = abm_last_error(); }
+                  else if (tails) {
+                    sl.tail_len.resize(std::max<uint64_t>(m, 1));
+                    sl.tail_text.clear();
+                    sl.tail_text.reserve(m * stride);
+                    char *w = sl.tail_text.p;
+                    for (uint64_t k = 0; k < m; ++k) {
+                      const uint32_t len = lens[k];
+                      sl.tail_len[k] = len;
+                      if (len != 0 && len != 0xFFFFFFFFu) { std::memcpy(w, tails + k * stride, len); w += len; }
+                    }
+                    sl.tail_text.n = static_cast<size_t>(w - sl.tail_text.p);
+                    sl.has_tails = true;
+                  }
+                }
                 (*t.queue)(sl);
               };
               rc = abm_map_se_batch_sliced(ctx, se_mode, &par, n, blob_p[0], off_p[0], static_cast<uint32_t>(b->slices.size()),
@@ -2366,12 +2398,28 @@ int cmd_map(int argc, char **argv) {
       const abm_hit *hits = sl.own ? sl.own_se.data() : b->se[0].data() + base;
       const uint32_t *cig_blob = sl.own ? sl.own_cig.data() : b->cig[0].data();
       const uint64_t *cig_off = sl.own ? sl.own_cig_off.data() : b->cig_off[0].data() + base;
+      const char *tail_at = sl.has_tails ? sl.tail_text.p : nullptr;
       for (size_t k = 0; k < m; ++k) {
         abm_hit h = hits[k];
         const size_t len = sl.off[0][k + 1] - sl.off[0][k];
         const uint32_t *cg = cig_blob + cig_off[k];
         const size_t ncg = cig_off[k + 1] - cig_off[k];
-        if (len && emit_se(sam, opt.ambig, h, ch, sl.names[0][k], sl.blob[0].data() + sl.off[0][k], len, cg, ncg) == UNMAPPED) h.pos = 0;
+        const uint32_t tl = sl.has_tails ? sl.tail_len[k] : 0xFFFFFFFFu;
+        if (tl == 0xFFFFFFFFu) {  // (no text from the device for this read: format_se here)
+          if (len && emit_se(sam, opt.ambig, h, ch, sl.names[0][k], sl.blob[0].data() + sl.off[0][k], len, cg, ncg) == UNMAPPED) h.pos = 0;
+        }
+        else if (len && (opt.ambig || !(h.flags & 0x100))) {
+          // the kernel wrote the line after QNAME (or found no record: no hit, or one that runs across its chromosome's end)
+          if (tl == 0) h.pos = 0;
+          else {
+            const NameRef &nm = sl.names[0][k];
+            const size_t at0 = sam.size();
+            sam.resize(at0 + nm.n + tl);
+            std::memcpy(&sam[at0], nm.p, nm.n);
+            std::memcpy(&sam[at0 + nm.n], tail_at, tl);
+          }
+        }
+        if (tl != 0xFFFFFFFFu) tail_at += tl;
         st.s[0].tally(len == 0, h, opt.ambig, ref_len(cg, ncg));
       }
       return;

@@ -58,6 +58,12 @@ struct DevIndex {
   const uint2 *ext2, *ext3t, *ext3a;
   u32 e2, e3, ext_maxc;
   u32 direct_min;  // pair kernels: ranges of at least this many entries are narrowed directly (narrow_direct); 0 = never
+  // the index's chromosome table as `abismal-amd map` sees it (names and n + 1 starts, the two padding entries included):
+  // what the single-end kernel needs to write a read's SAM text itself (SeArgs::sam_tail)
+  const u32 *chrom_starts;    // [n_chroms + 1]
+  const u32 *chrom_name_off;  // [n_chroms + 1] into chrom_names
+  const char *chrom_names;
+  u32 n_chroms;
 };
 constexpr u32 kSortDepth = 256;  // letters a bucket is sorted by (src/AbismalIndex.hpp: seed::n_sorting_positions)
 // direct narrowing of big ranges (narrow_direct, abm_kernels_core.hpp): the pair kernels, ranges of at least kDirectMin entries

@@ -105,6 +105,94 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const u64 *__restrict_
 // ((L + 61) x 61 bytes, 2 MB) and CIGAR scratch lie in a per-wave piece of global memory, its bands are 61 lanes
 // wide (one alignment per set and round), its filter runs on the nibble array (COOP is false), its scores wrap at 16
 // bits like the reference's, and the reads are the ones listed in `order`, their encodings packed by list position.
+// ---- a read's SAM text written by the wave that mapped it (SeArgs::sam_tail) -------------------------------------
+// format_se (src/abismal.cpp:481-545) + the host's put_record, minus QNAME: the wave has everything else -- hit,
+// CIGAR (its first ops are still in LDS: CigarSink::fin), conversion type -- and the read's text is on the device.
+// Scalar fields are written byte by byte by lane 0 into an LDS line buffer (a few hundred scalar instructions: 1 % of a
+// read's work), SEQ by all lanes, and the line leaves as 4-byte words, written through like the other results.
+// Returns the line's length, 0 for "no record", 0xFFFFFFFF for "the host formats this one".
+struct SamWriter {
+  u8 *buf;
+  u32 w, cap;
+  __device__ __forceinline__ void put(u32 c) { if (w < cap && lane_id() == 0) buf[w] = static_cast<u8>(c); ++w; }
+  __device__ __forceinline__ void put_uint(u32 v) {
+    u32 digits = 1;
+    for (u32 t = v; t >= 10u; t /= 10u) ++digits;
+    u32 at = w + digits;
+    w = at;
+    do { --at; if (at < cap && lane_id() == 0) buf[at] = static_cast<u8>('0' + v % 10u); v /= 10u; } while (v);
+  }
+  __device__ __forceinline__ void put_str(const char *s, u32 n) { for (u32 i = 0; i < n; ++i) put(static_cast<u8>(s[i])); }
+};
+__device__ __forceinline__ u32 format_sam_tail(const SeArgs &a, u8 *line /*LDS, 4-byte aligned, a.sam_stride bytes*/, const u32 *fin, u64 r,
+                                               u32 L, const Hit &best, u32 n_ops) {
+  const int lane = lane_id();
+  const bool ambig = (best.flags & kFlagAmbig) != 0;
+  if (best.pos == 0 || L == 0 || (ambig && !a.sam_allow_ambig)) return 0;
+  if (n_ops == 0 || n_ops > a.cig_stride || n_ops > kSeCap) return 0xFFFFFFFFu;
+  wave_sync();  // (fin was written by whichever lanes stored the CIGAR)
+  u32 reflen = 0;
+  for (u32 k = 0; k < n_ops; ++k) {
+    const u32 v = static_cast<u32>(uni(static_cast<int>(fin[k]))), op = v & 15u;
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
+  }
+  // Chroms::locate: the last start <= pos; the record exists if the alignment ends inside that chromosome
+  const DevIndex &ix = a.ix;
+  u32 lo = 0, n = ix.n_chroms + 1;  // upper_bound over starts[0 .. n_chroms]
+  while (n > 0) {
+    const u32 half = n >> 1;
+    const u32 sv = static_cast<u32>(uni(static_cast<int>(ix.chrom_starts[lo + half])));
+    if (!(best.pos < sv)) { lo += half + 1; n -= half + 1; } else n = half;
+  }
+  if (lo == 0 || lo > ix.n_chroms) return 0;
+  const u32 chrom = lo - 1;
+  const u32 c0 = static_cast<u32>(uni(static_cast<int>(ix.chrom_starts[chrom]))), c1 = static_cast<u32>(uni(static_cast<int>(ix.chrom_starts[chrom + 1])));
+  if (static_cast<u64>(best.pos) + reflen > c1) return 0;
+  const u32 n0 = static_cast<u32>(uni(static_cast<int>(ix.chrom_name_off[chrom]))), n1 = static_cast<u32>(uni(static_cast<int>(ix.chrom_name_off[chrom + 1])));
+  const bool rc = (best.flags & kFlagRC) != 0;
+  SamWriter o{line, 0, a.sam_stride};
+  o.put('\t');
+  o.put_uint((rc ? 0x10u : 0u) | ((a.sam_allow_ambig && ambig) ? 0x100u : 0u));
+  o.put('\t');
+  for (u32 i = n0; i < n1; ++i) o.put(static_cast<u8>(uni(static_cast<int>(ix.chrom_names[i]))));
+  o.put('\t');
+  o.put_uint(best.pos - c0 + 1u);
+  o.put_str("\t255\t", 5);
+  for (u32 k = 0; k < n_ops; ++k) {
+    const u32 v = static_cast<u32>(uni(static_cast<int>(fin[k])));
+    o.put_uint(v >> 4);
+    o.put(static_cast<u8>("MIDNSHP=XB"[min(v & 15u, 9u)]));
+  }
+  o.put_str("\t*\t0\t0\t", 7);
+  // SEQ as htslib prints it after its 4-bit round trip: IUPAC letters upper-cased, everything else N; a reverse-strand
+  // hit shows the reverse complement as the mapper makes it (src/common.hpp:28-44: A<->T, C<->G, everything else N)
+  const char *seq = a.blob + a.off[r];
+  for (u32 i = lane; i < L; i += 64) {
+    u32 c = static_cast<u8>(seq[rc ? L - 1 - i : i]);
+    if (rc) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+    else {
+      const u32 u = (c >= 'a' && c <= 'z') ? c - 32u : c;
+      // "=ACMGRSVTWYHKDBN": the letters A B C D G H K M N R S T V W Y
+      const bool ok = u == '=' || (u >= 'A' && u <= 'Z' && ((0x016E34CFu >> (u - 'A')) & 1u));
+      c = ok ? u : 'N';
+    }
+    if (o.w + i < o.cap) line[o.w + i] = static_cast<u8>(c);
+  }
+  o.w += L;
+  o.put_str("\t*\tNM:i:", 8);
+  const int nm = best.diffs;
+  if (nm < 0) { o.put('-'); o.put_uint(static_cast<u32>(-nm)); } else o.put_uint(static_cast<u32>(nm));
+  o.put_str("\tCV:A:", 6);
+  o.put((best.flags & kFlagARich) ? 'A' : 'T');
+  o.put('\n');
+  if (o.w > o.cap) return 0xFFFFFFFFu;
+  wave_sync();
+  u32 *dst = reinterpret_cast<u32 *>(a.sam_tail + r * a.sam_stride);
+  const u32 *src = reinterpret_cast<const u32 *>(line);
+  for (u32 k = lane; k < (o.w + 3) / 4; k += 64) store_out(dst + k, src[k]);
+  return o.w;
+}
+
 template <bool TIMED, bool COOP, bool LONG>
 __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -146,7 +234,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   const u32 call_ar = a.mode == 2 ? 0x6u /*0,1,1,0*/ : (a.mode == 1 ? 0x3u : 0x0u);
 
   WorkTally wt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const CigarSink sink = {a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap};
+  const CigarSink sink = {a.cig_stride, a.ctmp_cap, a.cig_arena, a.cig_arena_count, a.cig_arena_cap, (!LONG && a.sam_tail) ? lds.jpos : nullptr};
   const u64 n_items = a.n_reads;
   long long t_begin = 0, t_a = 0, t_b = 0;
   ABM_STAMP(t_begin);
@@ -220,6 +308,14 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
       overflow |= rd_overflow;
       ABM_STAMP(t_b);
       if (TIMED) wt.t_align += t_b - t_a;
+    }
+    if constexpr (!LONG) {
+      if (a.sam_tail != nullptr) {
+        // (the line buffer: the traceback table's place -- window slots 1.., the window cache and the table's extra bytes --
+        // idle once the CIGAR is out; launch_map_se asks for at least sam_stride bytes there)
+        const u32 len = (L > a.max_len) ? 0xFFFFFFFFu : format_sam_tail(a, lds.tb, lds.jpos, r, (L >= a.ix.min_len) ? L : 0u, best, best.pos != 0 ? n_ops : 0u);
+        if (lane == 0) store_out(a.sam_len + r, len);
+      }
     }
     if (lane == 0) {
       store_out(a.res + r, best);

@@ -42,6 +42,18 @@ struct SeArgs {
   const u16 *slice_id;
   u32 *slice_left;
   u32 *slice_done;
+  // optional: the read's SAM line after QNAME written by the kernel itself -- "\tFLAG\tRNAME\tPOS\t255\tCIGAR\t*\t0\t0\tSEQ\t*\t
+  // NM:i:n\tCV:A:c\n" as format_se writes it (src/abismal.cpp:481-545): the wave has the hit, the CIGAR and the conversion,
+  // the reads' text is on the device anyway (blob / off: what the batch was packed from), and the chromosome table rides
+  // with the index.  sam_len[r]: bytes written into sam_tail[r * sam_stride ..), 0 = the read has no record (unmapped,
+  // ambiguous and not allowed, or across a chromosome's end), 0xFFFFFFFF = not written here (a CIGAR beyond its slot or
+  // the text beyond the stride: the host formats that one)
+  const char *blob;
+  const u64 *off;
+  char *sam_tail;
+  u32 *sam_len;
+  u32 sam_stride;
+  int sam_allow_ambig;
   u32 *read_cycles;   // optional [n], diagnostic kernel only: per-read shader cycles / 1024
   unsigned long long *work;  // optional [16]: seed_iters, search probes, candidates,
                              // read words compared, set updates, alignments

@@ -1208,6 +1208,7 @@ struct CigarSink {
   u32 *arena;          // [arena_cap] or null
   u32 *arena_count;    // ops handed out so far
   u32 arena_cap;
+  u32 *fin;            // optional: the CIGAR's first kSeCap ops in LDS as well (the single-end kernel's SAM text is made from them)
 };
 
 // build_cigar_len_and_pos + get_traceback (src/AbismalAlign.hpp:166-193, :388-440).
@@ -1219,7 +1220,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
   const int lane = lane_id();
   ins = del = 0;  // count_total_ops<I>/<D> with oplen() narrowed to uint8_t (abismal_cigar_utils.hpp:50-53)
   if (score == 0 || diffs == 0) {
-    if (lane == 0) store_out(cig_out, static_cast<u32>(L) << 4);
+    if (lane == 0) { store_out(cig_out, static_cast<u32>(L) << 4); if (sink.fin) sink.fin[0] = static_cast<u32>(L) << 4; }
     n_ops = 1;
     aln_len = static_cast<u32>(L);
     return;
@@ -1283,6 +1284,7 @@ __device__ __forceinline__ void wave_cigar(const u8 *tb, u32 *ctmp, int L, int d
     else if (kk < body) v = ctmp[body - 1 - kk];
     else v = (static_cast<u32>(clip_tail) << 4) | 4u;
     store_out(dst + k, v);
+    if (sink.fin && k < kSeCap) sink.fin[k] = v;
   }
   n_ops = full;  // > stride: the ops are in the arena at slot[0] (or, with ABM_STATUS_CIGAR_OVERFLOW set, nowhere complete)
   aln_len = static_cast<u32>(L - clip_tail - clip_head);
@@ -1669,7 +1671,7 @@ __device__ __forceinline__ void choose_se(const DevIndex &ix, const WaveLds &lds
   n_ops = 0;
   if (S.best_p != 0) {  // exact match: no alignment needed
     best.diffs = static_cast<i16>(S.best_d); best.flags = static_cast<u16>(S.best_f); best.pos = S.best_p;
-    if (lane == 0) store_out(cig_out, L << 4);
+    if (lane == 0) { store_out(cig_out, L << 4); if (sink.fin) sink.fin[0] = L << 4; }
     n_ops = 1;
     return;
   }

@@ -167,6 +167,20 @@ int abm_map_se_batch_sliced(abm_ctx *ctx, int mode, const abm_params *params, ui
 int abm_ctx_slice_results(abm_ctx *ctx, uint64_t lo, uint64_t hi, abm_hit *out_res,
                           uint32_t *out_cig_blob, uint64_t cig_capacity, uint64_t *out_cig_off);
 
+/* SAM text from the device (round 5; the reference's counterpart: format_se, src/abismal.cpp:481-545, run per read on the
+ * host after the mapping loop).  When enabled, the single-end kernel of abm_map_se_batch_sliced also writes, for every
+ * read, its SAM line after QNAME -- "\tFLAG\tRNAME\tPOS\t255\tCIGAR\t*\t0\t0\tSEQ\t*\tNM:i:n\tCV:A:c\n", byte for byte what
+ * format_se + htslib's SAM writer print: the wave that mapped the read holds hit, CIGAR and conversion type, the reads'
+ * text is on the device, and the chromosome table rides with the index -- so that the host's formatting of a record is
+ * two copies (name, tail).  allow_ambig: the run's -a (ambiguous hits are written, flag 0x100).
+ * Inside the slice callback, abm_ctx_slice_sam_tails hands out the context's pinned buffers for reads [lo, hi): tails at
+ * *tails + k * *stride, lens[k] bytes each -- 0: the read has no record (unmapped, ambiguous and not allowed, or a hit
+ * that runs across its chromosome's end), 0xFFFFFFFF: not written by the device (a CIGAR beyond its 4-op slot, a read of
+ * more than 1024 bases, a line beyond the slot): format that one from abm_ctx_slice_results as before.  *tails is NULL
+ * when the launch wrote none.  Valid until the callback returns. */
+int abm_ctx_set_sam_tails(abm_ctx *ctx, int enable, int allow_ambig);
+int abm_ctx_slice_sam_tails(abm_ctx *ctx, uint64_t lo, uint64_t hi, const char **tails, uint32_t *stride, const uint32_t **lens);
+
 /* Same computation with every buffer already resident in HBM (d_* are device
  * pointers), enqueued on `stream` (a hipStream_t; NULL = default stream) and
  * not synchronised.  CIGARs land in fixed slots of cig_stride ops per read,

@@ -15,11 +15,11 @@ ORACLE=oracle/_build/abismal_oracle
 [ -x $ORACLE ] || make -C oracle > /dev/null 2>&1
 WD=/dev/shm/abm_full; rm -rf $WD; mkdir -p $WD
 T0=$(date +%s)
-( /usr/bin/time -f "sim config 3: %e s" $CLI sim -seed 1 -n 50000000 -l 150 -min-fraglen 150 -max-fraglen 500 -m 0.01 -b 0.98 -o $WD/c3 $FA > /dev/null 2> $WD/sim3.log ) &
+( S=$(date +%s); $CLI sim -seed 1 -n 50000000 -l 150 -min-fraglen 150 -max-fraglen 500 -m 0.01 -b 0.98 -o $WD/c3 $FA > /dev/null 2> $WD/sim3.err; echo "sim config 3 (50 M pairs 2x150): $(( $(date +%s) - S )) s" > $WD/sim3.log ) &
 P3=$!
-( /usr/bin/time -f "sim config 5: %e s" $CLI sim -single -R -seed 2 -n 50000000 -l 150 -min-fraglen 150 -max-fraglen 500 -m 0.01 -b 0.98 -o $WD/c5 $FA > /dev/null 2> $WD/sim5.log ) &
+( S=$(date +%s); $CLI sim -single -R -seed 2 -n 50000000 -l 150 -min-fraglen 150 -max-fraglen 500 -m 0.01 -b 0.98 -o $WD/c5 $FA > /dev/null 2> $WD/sim5.err; echo "sim config 5 (50 M reads x 150, -R): $(( $(date +%s) - S )) s" > $WD/sim5.log ) &
 P5=$!
-( /usr/bin/time -f "sim config 4: %e s" $CLI sim -single -seed 3 -n 200000000 -l 100 -m 0.01 -b 0.98 -o $WD/c4 $FA > /dev/null 2> $WD/sim4.log ) &
+( S=$(date +%s); $CLI sim -single -seed 3 -n 200000000 -l 100 -m 0.01 -b 0.98 -o $WD/c4 $FA > /dev/null 2> $WD/sim4.err; echo "sim config 4 (200 M reads x 100): $(( $(date +%s) - S )) s" > $WD/sim4.log ) &
 P4=$!
 body_md5() { grep -v '^@PG' "$@" | md5sum | cut -c1-32; }
 row() {  # label, timing json
@@ -31,19 +31,7 @@ print("%-58s %7.2f M reads/s  %8.3f s  %d reads  batches/GPU %s  first batch of 
     t.get("count_done_s", -1), t.get("peak_rss_mb", -1), t.get("pinned_mb"), t["host_threads"]))
 PY
 }
-{
-# ---- the taper of the last paired-end batches, 8 M pairs (the three simulators above are running beside it: 3 of the pod's 16 CPUs)
-$CLI sim -seed 1 -n 2000000 -l 150 -min-fraglen 150 -max-fraglen 500 -m 0.01 -b 0.98 -o $WD/p $FA > /dev/null
-for k in 1 2; do for f in 1 2 3 4; do cat $WD/p_$k.fq; done > $WD/x_$k.fq; done
-for taper in 4 0 8; do
-  for rep in 1 2 3; do
-    ABM_CLI_PE_TAPER=$taper $CLI map -i $IDX -o $WD/out.sam -timing $WD/t.json $WD/x_1.fq $WD/x_2.fq 2> $WD/err.log || tail -3 $WD/err.log
-    row "8 M pairs, last batches at most 1/$taper of what is left (0: no taper), rep $rep" $WD/t.json
-  done
-done
-rm -f $WD/p_* $WD/x_* $WD/out.sam
-} 2>&1 | tee gpurun_out/r05_pe_e2e_taper.log
-{
+exec > >(tee $LOG) 2>&1
 echo "== box: $(nproc) hardware threads, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), memory.max $(cat /sys/fs/cgroup/memory.max 2>/dev/null), tmpfs $(df -h /dev/shm | tail -1 | awk '{print $2}')"
 # ---- config 5
 wait $P5; cat $WD/sim5.log | tail -1
@@ -60,7 +48,7 @@ rm -f $WD/c5*
 wait $P3; cat $WD/sim3.log | tail -1
 ls -la $WD/c3_1.fq $WD/c3_2.fq | awk '{print "   FASTQ bytes", $5}'
 $CLI map -i $IDX -o $WD/c3.sam -s $WD/c3.st -timing $WD/t.json $WD/c3_1.fq $WD/c3_2.fq 2> $WD/err.log || tail -3 $WD/err.log
-row "config 3: 50 M pairs 2x150, map (8 contexts, tapered batches)" $WD/t.json
+row "config 3: 50 M pairs 2x150, map (8 contexts)" $WD/t.json
 ls -la $WD/c3.sam | awk '{print "   SAM bytes", $5}'
 head -80000 $WD/c3_1.fq > $WD/c3p_1.fq; head -80000 $WD/c3_2.fq > $WD/c3p_2.fq
 $CLI map -i $IDX -o $WD/c3p.sam $WD/c3p_1.fq $WD/c3p_2.fq 2> /dev/null
@@ -85,5 +73,4 @@ rm -f $WD/c4one.sam $WD/c4.sam.part*
 $CLI map -virtual-gpus 8 -out-parts 8 -i $IDX -o $WD/c4v.sam -timing $WD/t.json $WD/c4_1.fq 2> $WD/err.log || tail -3 $WD/err.log
 row "config 4 input around 8 virtual GPUs, 8 parts (host pipeline alone)" $WD/t.json
 echo "== wall clock of the whole script: $(( $(date +%s) - T0 )) s"
-} 2>&1 | tee $LOG
 rm -rf $WD

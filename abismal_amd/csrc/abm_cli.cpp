@@ -1212,7 +1212,7 @@ int cmd_map(int argc, char **argv) {
   }
   bool shared_device = false;
   for (int g = 0; g < n_gpus; ++g) for (int h = 0; h < g; ++h) shared_device |= dev_of[g] >= 0 && dev_of[g] == dev_of[h];
-  const bool device_sam = !paired && !opt.bam && !virtual_gpus && !std::getenv("ABM_CLI_NO_STREAM") && !std::getenv("ABM_CLI_HOST_FORMAT");
+  bool device_sam = false;  // decided below, once the number of host workers is known
   std::vector<abm_ctx *> ctxs;  // [g * per_gpu + k]
   if (!virtual_gpus) {
     // the first context on a device uploads the index and derives its tables there: every device's at the same time
@@ -1299,6 +1299,17 @@ int cmd_map(int argc, char **argv) {
     // single-end SAM text: the kernel writes every read's line after QNAME itself (abm_ctx_set_sam_tails), the formatters
     // put names in front -- half of the host's CPU time per read was building that text base by base.  BAM records are
     // built from the fields as before; ABM_CLI_HOST_FORMAT=1: SAM text too (same-box comparisons, tests)
+    // Where it pays: with few host workers per GPU.  40 M reads on one GPU, end to end (profiles/r05_exp_device_sam_text.log):
+    // -t 2 12.2-12.4 M reads/s against 8.4 with host formatting, -t 4 13.0-13.5 against 12.9-13.0, -t 16 13.8-13.9 against
+    // 14.2-14.3 (the kernel writes 160 bytes more per read across PCIe); process CPU 8.5 s against 12.2 s.  So the device
+    // writes the text when a GPU has fewer than twelve workers to itself (ABM_CLI_DEVICE_SAM=0 / 1 decides otherwise).
+    {
+      const CpuQuota q0;
+      unsigned workers = opt.threads ? std::max(1u, opt.threads) : static_cast<unsigned>(std::min<size_t>(std::max<size_t>(topo.n_cores(), 1), 8u + 8u * static_cast<unsigned>(n_gpus)));
+      if (q0.cpus > 0 && !std::getenv("ABM_CLI_NO_QUOTA_CLAMP")) workers = std::min(workers, std::max(1u, static_cast<unsigned>(q0.cpus + 0.5)));
+      device_sam = !paired && !opt.bam && !std::getenv("ABM_CLI_NO_STREAM") && !std::getenv("ABM_CLI_HOST_FORMAT") && workers < 12u * static_cast<unsigned>(n_gpus);
+      if (const char *e = std::getenv("ABM_CLI_DEVICE_SAM")) device_sam = !paired && !opt.bam && !std::getenv("ABM_CLI_NO_STREAM") && e[0] != '0';
+    }
     if (device_sam)
       for (abm_ctx *c : ctxs) if (abm_ctx_set_sam_tails(c, 1, opt.ambig ? 1 : 0) != 0) die_abm("SAM text on the device");
     std::vector<std::thread> warm;
@@ -2666,7 +2677,7 @@ int cmd_map(int argc, char **argv) {
     std::ofstream tj(opt.timing);
     tj << "{\"records\": " << total_records << ", \"reads\": " << (paired ? 2 : 1) * total_records << ", \"seconds\": " << secs
        << ", \"index_load_s\": " << index_load_s << ", \"host_prepare_s\": " << host_prepare_s << ", \"gpus\": " << n_gpus << ", \"mappers_per_gpu\": " << per_gpu
-       << ", \"host_threads\": " << n_host << ", \"numa_nodes\": " << n_nodes << ", \"pinned\": " << (topo.pinning ? "true" : "false")
+       << ", \"sam_text_by\": \"" << (device_sam ? "device" : "host") << "\", \"host_threads\": " << n_host << ", \"numa_nodes\": " << n_nodes << ", \"pinned\": " << (topo.pinning ? "true" : "false")
        << ", \"out_parts\": " << n_regions << ", \"out_bytes\": " << out_bytes << ", \"batches\": " << n_batches << ", \"max_lead_in_records\": " << max_lead << ", \"region_lead_in_scanned_records\": " << region_lead_scanned << ", \"region_lead_in_records\": " << region_lead_records
        << ", \"batch_reads\": " << batch_reads << ", \"host_ceiling\": " << (virtual_gpus ? "true" : "false")
        << ", \"batches_per_gpu\": [";

@@ -143,16 +143,16 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
     i16 *ldv = pl.ld[which];
     if (n <= 64) {
       u32 e = 0, p = 0;
-      if (lane < n) { e = P.rd(lane); p = lp[e & 0x7FFFu]; }
+      if (lane < n) { e = P.heap[lane]; p = lp[e & 0x7FFFu]; }
       wave_sync();
       if (lane < n) { lp[lane] = p; ldv[lane] = static_cast<i16>(static_cast<int>(e) >> 16); }
     }
     else {  // through the per-wave scratch table
-      for (int i = lane; i < n; i += 64) pl.tmp[i] = lp[P.rd(i) & 0x7FFFu];
+      for (int i = lane; i < n; i += 64) pl.tmp[i] = lp[P.heap[i] & 0x7FFFu];
       wave_sync();
       for (int i = lane; i < n; i += 64) {
         lp[i] = pl.tmp[i];
-        ldv[i] = static_cast<i16>(static_cast<int>(P.rd(i)) >> 16);
+        ldv[i] = static_cast<i16>(static_cast<int>(P.heap[i]) >> 16);
       }
     }
     wave_sync();
@@ -740,14 +740,6 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   w.seg_epoch = 0;
 
   w.P.heap = w.pl.heap;
-  w.P.top_cache = nullptr; w.P.top_n = 0; w.P.top_levels = 0;
-  if constexpr (BIG && !LONG && PHASE == kWhole) {
-    // tier 2's heap is in global memory: its first levels live in LDS that the alignments leave idle during the seed
-    // passes -- the traceback table's extra bytes, the CIGAR scratch and the job lists (PeSet::top_cache)
-    unsigned char *idle = reinterpret_cast<unsigned char *>(lds.pcache + (1u << kPosCacheBits));
-    const u32 idle_bytes = a.tb_extra + a.ctmp_cap * 4u + 3u * kSeCap * 4u;
-    w.P.use_top_cache(idle, idle_bytes / 4u);
-  }
   w.P.spill_pos = nullptr; w.P.spill_d = nullptr; w.P.spill_cap = 0; w.P.spilled = false;
   w.stage_pos = nullptr; w.stage_d = nullptr;
   if constexpr (PHASE == kSeed) {

@@ -55,35 +55,6 @@ struct PeSet {
   i16 *spill_d;
   u32 spill_cap;
   bool spilled;
-  // The first top_n = 2^top_levels - 1 heap slots may live in LDS instead of `heap` (round 5): tier 2's heap is in
-  // global memory, and a pair whose set stands at 32768 entries makes a hundred thousand updates, each three dependent
-  // round trips down the hole's path and one up -- with ten levels in LDS (4 KB that the wave's alignment scratch leaves
-  // idle during the seed passes) the walk down needs ONE trip to memory.  top_n = 0: no such copy.
-  typedef __attribute__((address_space(3))) u32 lds_u32;
-  lds_u32 *top_cache;
-  u32 top_n;
-  int top_levels;
-  __device__ __forceinline__ u32 rd(int idx) const {  // heap[idx], per lane
-    u32 v;
-    if (static_cast<u32>(idx) < top_n) v = top_cache[idx]; else v = heap[idx];
-    return v;
-  }
-  __device__ __forceinline__ void wr(int idx, u32 v) const {
-    if (static_cast<u32>(idx) < top_n) top_cache[idx] = v; else heap[idx] = v;
-  }
-  __device__ __forceinline__ void use_top_cache(void *lds, u32 words) {  // the largest 2^k - 1 <= words, at most ten levels
-    int k = 0;
-    while (k < 10 && (2u << k) - 1u <= words) ++k;
-    top_levels = k; top_n = (1u << k) - 1u;
-    top_cache = (lds_u32 *)lds;
-  }
-  __device__ __forceinline__ void flush_top() const {  // (for whoever reads `heap` as an array afterwards)
-    for (u32 i = lane_id(); i < top_n && static_cast<int>(i) < sz; i += 64) heap[i] = top_cache[i];
-    wave_sync();
-  }
-  // a subtree load walks down from `depth`: it is re-rooted where the cached levels end (and five levels above that), so
-  // that one load covers cached levels only and the next one starts exactly below them
-  __device__ __forceinline__ bool reroot_at(int depth) const { return top_levels > 0 && (depth == top_levels - 1 || depth == top_levels - 6); }
   u32 top;     // heap[0]
   int sz, capacity, cutoff, good_cutoff;
   bool sure_ambig, overflow, heaped;
@@ -159,14 +130,19 @@ struct PeSet {
     const int node = lane < 17 ? ((hole + 1) >> lane) - 1 : -1;
     const int par = lane < 17 ? ((hole + 1) >> (lane + 1)) - 1 : -1;
     u32 pk = 0;
-    if (par >= 0) pk = rd(par);
+    if (par >= 0) pk = heap[par];
     const bool moves = par >= 0 && key_d(pk) < key_d(key);
     const int stop = __builtin_ctzll(~__ballot(moves));
-    if (lane < stop) wr(node, pk);
-    else if (lane == stop) wr(node, key);
+    if (lane < stop) heap[node] = pk;
+    else if (lane == stop) heap[node] = key;
     if (((hole + 1) >> stop) == 1) top = key;
     wave_sync();
   }
+  // (Round 5 tried keeping the heap's first ten levels in LDS -- 4 KB the alignments leave idle during the seed passes -- so
+  // that the walk down needs one trip to memory instead of three: the costliest pairs, whose 32768-entry sets see a couple
+  // of hundred thousand updates, got 20 % SLOWER (replay 1.9 -> 2.3 G cycles for the worst one, the tier-2 launch alone
+  // 1.10-1.14 -> 1.32 s; profiles/r05_exp_heap_levels_in_lds.log): a lone wave is bound by the instructions of an update,
+  // not by its round trips, and two address spaces per access add to them.)
   // std::pop_heap on [0,n) (libstdc++ __adjust_heap: the hole follows the larger child -- the
   // right one on ties -- down to a leaf, then the last element sifts up from there); returns the
   // handle of the evicted top.  Slot n-1 is left for the caller to refill.
@@ -179,22 +155,21 @@ struct PeSet {
     const int lj = lane + 1 - (1 << lt);
     int g = 0, gdepth = 0;
     u32 K;
-    // (the last element by a load of its own, issued first: the subtree loads that follow from LDS do not wait for it)
-    const u32 vlast = rd(len);
     auto load_subtree = [&](int root, int depth) {
       g = root; gdepth = depth;
-      const int idx = ((root + 1) << lt) - 1 + lj;
-      K = (lane < 63 && idx <= len) ? rd(idx) : 0u;
+      const int idx = lane == 63 ? len : ((root + 1) << lt) - 1 + lj;
+      K = idx <= len ? heap[idx] : 0u;
     };
     auto key_at = [&](int x, int t) { return rdlane(K, (1 << t) - 1 + (x - (((g + 1) << t) - 1))); };
     load_subtree(0, 0);
+    const u32 vk = rdlane(K, 63);
     int hole = 0, second = 0, depth = 0;
     int pidx = 0;   // lane t: the path's node at depth t ...
     u32 pnew = 0;   // ... and the child key that moves into it
     while (second < (len - 1) / 2) {
       second = 2 * (second + 1);
       int t = depth + 1 - gdepth;
-      if (t > 5 || (t > 1 && reroot_at(depth))) { load_subtree(hole, depth); t = 1; }
+      if (t > 5) { load_subtree(hole, depth); t = 1; }
       u32 sk = key_at(second, t);
       const u32 lk = key_at(second - 1, t);
       if (key_d(sk) < key_d(lk)) { --second; sk = lk; }
@@ -212,15 +187,14 @@ struct PeSet {
       ++depth;
     }
     if (lane == depth) pidx = hole;
-    const u32 vk = static_cast<u32>(uni(static_cast<int>(vlast)));
     // __push_heap of the last element from the leaf: the path's nodes now hold their children's
     // keys; while the one above has fewer diffs than vk it moves back down (restoring the old key)
     const u32 above = __shfl_up(pnew, 1);
     const bool back = lane >= 1 && lane <= depth && key_d(above) < key_d(vk);
     const u64 stay = ~__ballot(back) & ((2ull << depth) - 1);
     const int ts = 63 - __builtin_clzll(stay);
-    if (lane < ts) wr(pidx, pnew);
-    else if (lane == ts) wr(pidx, vk);
+    if (lane < ts) heap[pidx] = pnew;
+    else if (lane == ts) heap[pidx] = vk;
     top = ts == 0 ? vk : rdlane(pnew, 0);
     wave_sync();
     return freed;
@@ -247,13 +221,13 @@ struct PeSet {
     u32 K;
     auto load_subtree = [&](int root, int depth) {
       g = root; gdepth = depth;
-      const int idx = ((root + 1) << lt) - 1 + lj;
-      K = (lane < 63 && idx <= len) ? rd(idx) : 0u;
+      const int idx = lane == 63 ? len : ((root + 1) << lt) - 1 + lj;
+      K = idx <= len ? heap[idx] : 0u;
     };
     auto key_at = [&](int x, int t) { return rdlane(K, (1 << t) - 1 + (x - (((g + 1) << t) - 1))); };
-    const u32 kpar = rd((len - 1) >> 1);
-    const u32 klast = static_cast<u32>(uni(static_cast<int>(rd(len))));
+    const u32 kpar = heap[(len - 1) >> 1];
     load_subtree(0, 0);
+    const u32 klast = rdlane(K, 63);
     if (key_d(klast) != c || key_d(static_cast<u32>(uni(static_cast<int>(kpar)))) != c) return 0;
     // the hole's path (as pop_max walks it) while its nodes hold a c; lane t keeps node t of the chain and its key
     int cnode = 0;
@@ -262,7 +236,7 @@ struct PeSet {
     while (second < (len - 1) / 2) {
       int child = 2 * (second + 1);
       int t = depth + 1 - gdepth;
-      if (t > 5 || (t > 1 && reroot_at(depth))) { load_subtree(second, depth); t = 1; }
+      if (t > 5) { load_subtree(second, depth); t = 1; }
       u32 sk = key_at(child, t);
       const u32 lk = key_at(child - 1, t);
       if (key_d(sk) < key_d(lk)) { --child; sk = lk; }
@@ -293,7 +267,7 @@ struct PeSet {
       ckey = lane < n - 1 ? nxt : (lane == n - 1 ? (c16 | slot) : ckey);
       if (lane == 0) lpos[slot] = p;
     }
-    if (lane < n) wr(cnode, ckey);
+    if (lane < n) heap[cnode] = ckey;
     top = rdlane(ckey, 0);
     wave_sync();
     return m;

@@ -64,23 +64,39 @@ extra = {}
 pe_csv = os.path.join(src, "pmc_rdreq_map_pe.csv")
 if os.path.exists(pe_csv):
     shutil.copy(pe_csv, os.path.join(dst, f"{tag}_pmc_rdreq_map_pe.csv"))
-    tiers = {}
-    for name, want in (("tier1", lambda k: "map_pe_kernel<false" in k), ("tier2", lambda k: "map_pe_kernel<true" in k)):
-        acc, secs_t = sum_rows(pe_csv, want)
-        tiers[name] = {"counters": acc, "kernel_seconds_under_pmc": round(secs_t, 4),
-                       "bytes": acc.get("TCC_EA0_RDREQ_128B_sum", 0) * 128 + acc.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + acc.get("TCC_EA0_RDREQ_32B_sum", 0) * 32}
+    # the pair kernels by template arguments <BIG, TIMED, COOP, WPS, LONG, PHASE>: production builds only (TIMED = false; the
+    # bench's last step runs the diagnostic ones), PHASE 1 = seed, 2 = mate (BIG: lists in device memory), 0 = whole pairs
+    import re
+    def which(kname):
+        m = re.search(r"map_pe_kernel<([^>]*)>", kname)
+        if not m:
+            return None
+        t = [x.strip() for x in m.group(1).split(",")]
+        big, timed, phase = t[0] in ("true", "1"), t[1] in ("true", "1"), int(t[5]) if len(t) > 5 else 0
+        if timed:
+            return None
+        return {(False, 1): "seed", (False, 2): "mate_lds_lists", (True, 2): "mate_device_lists", (True, 0): "whole_pairs", (False, 0): "tier1_unsplit"}.get((big, phase))
+    names = ("seed", "mate_lds_lists", "mate_device_lists", "whole_pairs", "tier1_unsplit")
+    kernels = {}
+    for name in names:
+        acc, secs_t = sum_rows(pe_csv, lambda k, name=name: which(k) == name)
+        if acc:
+            kernels[name] = {"counters": acc, "kernel_seconds_under_pmc": round(secs_t, 4),
+                             "bytes": acc.get("TCC_EA0_RDREQ_128B_sum", 0) * 128 + acc.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + acc.get("TCC_EA0_RDREQ_32B_sum", 0) * 32}
     wr_csv = os.path.join(src, "pmc_wrreq_map_pe.csv")
     if os.path.exists(wr_csv):
         shutil.copy(wr_csv, os.path.join(dst, f"{tag}_pmc_wrreq_map_pe.csv"))
-        for name, want in (("tier1", lambda k: "map_pe_kernel<false" in k), ("tier2", lambda k: "map_pe_kernel<true" in k)):
-            tiers[name]["write_side_counters"] = sum_rows(wr_csv, want)[0]
-    pe_bytes = tiers["tier1"]["bytes"] + tiers["tier2"]["bytes"]
-    extra["pe"] = {"round": rnd, "kernel": "map_pe_kernel (tier 1 + tier 2, one step)",
-                   "workload": {"kind": "pe", "genome_mbp": 3100, "reads": 1000000, "read_len": 150}, "tiers": tiers,
-                   "hbm_read_bytes_per_launch": pe_bytes, "lines_per_pair": pe_bytes / 128 / 1e6,  # (1 M pairs per step) "build": build,
+        for name in list(kernels):
+            kernels[name]["write_side_counters"] = sum_rows(wr_csv, lambda k, name=name: which(k) == name)[0]
+    pe_bytes = sum(k["bytes"] for k in kernels.values())
+    extra["pe"] = {"round": rnd, "kernel": "map_pe_kernel (seed + mate + whole-pair launches of one step)",
+                   "workload": {"kind": "pe", "genome_mbp": 3100, "reads": 1000000, "read_len": 150}, "kernels": kernels,
+                   "hbm_read_bytes_per_launch": pe_bytes, "lines_per_pair": pe_bytes / 128 / 1e6, "build": build,
+                   "requests_per_second_by_kernel": {n: round(k["counters"].get("TCC_EA0_RDREQ_sum", 0) / k["kernel_seconds_under_pmc"] / 1e9, 2) for n, k in kernels.items() if k["kernel_seconds_under_pmc"]},
                    "note": "rocprofv3 --pmc TCC_EA0_RDREQ_* in a pass of its own over `python3 bench.py --pe --reads 1000000 --read-len 150 --steps 1 "
-                           "--warmup 0 --streams 1` (scripts/r04_profile.sh); per step = one tier-1 launch + one tier-2 launch (the LAST dispatch of each: "
-                           "the run's first step only sizes the workspaces)"}
+                           "--warmup 0 --streams 1` (scripts/r05_profile.sh); per step = one launch of each production kernel (the LAST dispatch of "
+                           "each: the run's first step only sizes the workspaces, its last one runs the diagnostic builds for the work tallies); "
+                           "requests_per_second_by_kernel in G/s, each kernel alone on the device"}
     json.dump(extra["pe"], open(os.path.join(dst, f"{tag}_traffic_pe.json"), "w"), indent=1)
 r_csv = os.path.join(src, "pmc_rdreq_map_se_r150.csv")
 if os.path.exists(r_csv):
@@ -160,9 +176,10 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
             f"{nbytes / (rf['alg_bytes_per_read_strict'] * n_reads):.1f}x the strict bytes: every 8-64-byte gather costs a whole 128-byte line.\n\n")
     f.write("Work per read in that run: " + ", ".join(f"{k} {v}" for k, v in line["work_per_read"].items()) + ".\n")
     if "pe" in extra:
-        t = extra["pe"]["tiers"]
-        f.write(f"\nPaired-end (config 3, `{tag}_traffic_pe.json`): tier 1 {t['tier1']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G + tier 2 "
-                f"{t['tier2']['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G read requests per step of 1 M pairs = {extra['pe']['lines_per_pair'] / 1e3:.1f} k lines per pair.\n")
+        ks = extra["pe"]["kernels"]
+        f.write(f"\nPaired-end (config 3, `{tag}_traffic_pe.json`), read requests per step of 1 M pairs by kernel, each alone on the device: " +
+                "; ".join(f"{n} {k['counters'].get('TCC_EA0_RDREQ_sum', 0) / 1e9:.2f} G in {k['kernel_seconds_under_pmc'] * 1e3:.0f} ms = {extra['pe']['requests_per_second_by_kernel'].get(n, 0)} G/s" for n, k in ks.items()) +
+                f" = {extra['pe']['lines_per_pair'] / 1e3:.1f} k lines per pair.\n")
     if "r150" in extra:
         f.write(f"\n150 bp random PBAT (config 5, `{tag}_traffic_rpbat150.json`): {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 1e9:.2f} G read requests per launch of 4 M reads "
                 f"= {extra['r150']['counters']['TCC_EA0_RDREQ_sum'] / 4e6:.0f} lines per read.\n")

@@ -25,11 +25,7 @@ __device__ __host__ inline int draw(unsigned seq, unsigned idx, int shape) {
 constexpr int kShapes = 4;
 
 __global__ __launch_bounds__(64) void run(int n_chunks, u32 *heaps, u32 *poss, i16 *lds_, int *meta) {
-  // the second half of the sequences keep the heap's first levels in LDS (PeSet::top_cache: 10, 9, 7 and 3 levels)
-  __shared__ u32 top_lds[1023];
   PeSet S;
-  S.top_cache = nullptr; S.top_n = 0; S.top_levels = 0;
-  if (blockIdx.x >= 8) { const u32 words[4] = {1023, 600, 127, 7}; S.use_top_cache(top_lds, words[(blockIdx.x >> 1) & 3]); }
   S.heap = heaps + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
   S.lpos = poss + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
   S.ld = lds_ + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
@@ -56,12 +52,11 @@ __global__ __launch_bounds__(64) void run(int n_chunks, u32 *heaps, u32 *poss, i
   }
   wave_sync();
   if (!S.heaped) S.heapify();
-  S.flush_top();
   if (threadIdx.x == 0) { meta[4 * blockIdx.x] = S.sz; meta[4 * blockIdx.x + 1] = S.cutoff; meta[4 * blockIdx.x + 2] = n_runs; meta[4 * blockIdx.x + 3] = S.capacity; }
 }
 
 int main() {
-  const int blocks = 16, chunks = 1100, n = chunks * 64;
+  const int blocks = 12, chunks = 1100, n = chunks * 64;
   u32 *dh, *dp; i16 *dl; int *dm;
   (void)hipMalloc(&dh, sizeof(u32) * blocks * kPeCapLarge); (void)hipMalloc(&dp, sizeof(u32) * blocks * kPeCapLarge);
   (void)hipMalloc(&dl, sizeof(i16) * blocks * kPeCapLarge); (void)hipMalloc(&dm, blocks * 16);

@@ -82,6 +82,53 @@ def test_map_goldens(chain, args, outs, units):
         assert md5(chain / o) == g[o], f"{o} differs from the reference golden"
 
 
+@pytest.mark.parametrize("flags", [[], ["-a"], ["-R"], ["-A", "-a"]])
+def test_sam_text_from_the_device_equals_the_hosts(chain, flags):
+    """Single-end SAM text is written by the mapping kernel itself when a GPU has few host workers to itself
+    (abm_ctx_set_sam_tails; ABM_CLI_DEVICE_SAM=1 forces it here): the file must be the one the host's formatter writes, and
+    for the reference's own command line the reference's golden.  Reads with IUPAC letters (SEQ shows them
+    as they are: htslib has 4-bit codes for them), reads of 44-46 bases, reads too short to map and reads whose
+    CIGAR outgrows its 4-op slot (formatted by the host all the same) ride along in a second file."""
+    g = golden()
+    outs = {}
+    for by in ("1", "0"):
+        env = dict(os.environ, ABM_CLI_DEVICE_SAM=by, ABM_CLI_SLICE_READS="997")
+        r = subprocess.run([CLI, "map", "-v"] + flags + ["-s", f"tests/dev{by}.mstats", "-o", "tests/reads.sam", "-i", "tests/tRex1.idx", "tests/reads_1.fq"],
+                           cwd=chain, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        outs[by] = (open(chain / "tests/reads.sam").read(), open(chain / f"tests/dev{by}.mstats").read())
+        if not flags:
+            assert md5(chain / "tests/reads.sam") == g["tests/reads.sam"], f"SAM text by {'device' if by == '1' else 'host'} differs from the reference golden"
+    assert outs["1"] == outs["0"] and outs["1"][0].count("\n") > 8000
+    # the odd reads
+    lines = open(chain / "tests/reads_1.fq").read().split("\n")
+    import random
+    rng = random.Random(5)
+    for k in range(0, len(lines) - 3, 4):
+        seq = lines[k + 1]
+        kind = (k // 4) % 7
+        if kind == 1:
+            seq = seq[:44 + (k // 28) % 3]
+        elif kind == 2:
+            j = rng.randrange(len(seq)); seq = seq[:j] + "RYKMSWN"[rng.randrange(7)] + seq[j + 1:]
+        elif kind == 3:
+            j = rng.randrange(5, len(seq) - 25)  # three small deletions and an insertion: five or more CIGAR ops
+            seq = seq[:j] + seq[j + 2:j + 10] + "A" + seq[j + 10:j + 18] + seq[j + 19:j + 30] + seq[j + 32:]
+        elif kind == 4:
+            seq = seq[:30]
+        lines[k + 1], lines[k + 3] = seq, lines[k + 3][:len(seq)].ljust(len(seq), "B")
+    open(chain / "tests/odd.fq", "w").write("\n".join(lines))
+    outs = {}
+    for by in ("1", "0"):
+        env = dict(os.environ, ABM_CLI_DEVICE_SAM=by, ABM_CLI_SLICE_READS="997")
+        r = subprocess.run([CLI, "map"] + flags + ["-s", f"tests/odd{by}.mstats", "-o", "tests/odd.sam", "-i", "tests/tRex1.idx", "tests/odd.fq"],
+                           cwd=chain, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        outs[by] = (open(chain / "tests/odd.sam").read(), open(chain / f"tests/odd{by}.mstats").read())
+    assert outs["1"] == outs["0"] and outs["1"][0].count("\n") > 5000
+    assert sum(1 for ln in outs["1"][0].split("\n") if not ln.startswith("@") and ln and len(__import__("re").findall(r"[MIDS]", ln.split("\t")[5])) >= 5) > 100
+
+
 @pytest.mark.parametrize("reads,extra", [
     (["tests/reads_1.fq"], []),
     (["tests/reads_pe_1.fq", "tests/reads_pe_2.fq"], []),

@@ -716,7 +716,7 @@ int se_resident_waves(u32 W, u32 WB, u32 cig_stride, u32 max_len, double valid_f
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   const size_t lds = se_lds_bytes(W, WB, cig_stride, max_len, valid_frac);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, map_se_kernel<false, true>, 64, lds) != hipSuccess) return 0;
-  // Measured on MI355X at hg38 scale (scripts/grid_sweep.sh, scripts/se_variant.sh): what matters is waves without
+  // Measured on MI355X at hg38 scale (round 2: scripts/grid_sweep.sh and se_variant.sh, in the history of this repository): what matters is waves without
   // register spills.  10 M reads: one lane per window, 20 waves/CU 1405 ms (28: 1577, 32: 1681); cooperative
   // window loads with 8 rounds in flight, 16 waves at 128 registers 1029 ms (20 waves at 96 with spills:
   // 1386); with 2 rounds in flight 20 waves fit almost without spills: 923 ms (24 waves: 999).

@@ -560,7 +560,7 @@ __device__ __forceinline__ int group_sum(int v, u32 G) {  // sum over aligned gr
   return v;
 }
 #ifndef ABM_COOP_ROUNDS
-#define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (scripts/se_variant.sh): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
+#define ABM_COOP_ROUNDS 2  // measured best with 20 waves per CU (round 2, profiles/r02_experiments.md): 1, 2, 4, 8 -> 937, 923, 959, 1386 ms
 #endif
 constexpr u32 kCoopRounds = ABM_COOP_ROUNDS;  // rounds of window loads in flight per lane
 

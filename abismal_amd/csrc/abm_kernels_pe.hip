@@ -286,16 +286,54 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
     wave_sync();
   }
 
-  // first index whose position is >= key (lists are sorted here)
-  __device__ __forceinline__ int lower_bound_pos(int which, long long key) const {
-    int lo = 0, n = lsz[which];
+  // Tier 2's lists lie in global memory, and every binary search in them is a chain of dependent loads (thirteen for a
+  // list of 4096 entries, per 64 entries that search): the marking pass of score_pairable and the windows of mate were a
+  // sixth of a mid-sized pair's time.  So a list that is about to be searched leaves every 2^s-th position in LDS (at most
+  // 512 of them, in the window cache's place -- idle outside the seed passes): a search runs through those first and ends
+  // with at most s steps in memory -- none when the whole list fits.  Tier 1's lists are in LDS as they are.
+  u32 *samp;      // [512] the sampled positions
+  int samp_shift; // s
+  int samp_n;     // samples held
+  __device__ __forceinline__ void sample_list(int which) {
+    if constexpr (BIG) {
+      const int n = lsz[which];
+      int s = 0;
+      while ((n >> s) > 512) ++s;
+      samp_shift = s;
+      samp_n = (n + (1 << s) - 1) >> s;
+      for (int j = lane_id(); j < samp_n; j += 64) samp[j] = pl.lpos[which][static_cast<u32>(j) << s];
+      wave_sync();
+    }
+  }
+  // first index of list `which` in [from, n) whose (position + add) is not below key, i.e. (pos + add) >= key -- or, with
+  // STRICT, is above key: (pos + add) > key; the list is sorted and sample_list(which) has been called for it
+  template <bool STRICT = false>
+  __device__ __forceinline__ int search_list(int which, long long add, long long key, int from = 0) const {
+    auto below = [&](u32 pos) { const long long v = static_cast<long long>(pos) + add; return STRICT ? v <= key : v < key; };
+    int lo = from, n = lsz[which] - from;
+    if constexpr (BIG) {
+      // among the samples first: j = first sample at or after `from`'s block that is not below
+      int jl = (from + (1 << samp_shift) - 1) >> samp_shift, jn = samp_n - jl;
+      if (jn < 0) jn = 0;
+      while (jn > 0) {
+        const int half = jn >> 1;
+        if (below(samp[jl + half])) { jl += half + 1; jn -= half + 1; } else jn = half;
+      }
+      // the answer lies in (sample jl - 1, sample jl]
+      const int hi = min(lsz[which], jl << samp_shift);
+      lo = max(from, jl > 0 ? ((jl - 1) << samp_shift) + 1 : 0);
+      n = hi - lo;
+      if (n < 0) n = 0;
+    }
     while (n > 0) {
       const int half = n >> 1;
-      if (static_cast<long long>(ld_list<BIG>(pl.lpos[which] + lo + half)) < key) { lo += half + 1; n -= half + 1; }
+      if (below(ld_list<BIG>(pl.lpos[which] + lo + half))) { lo += half + 1; n -= half + 1; }
       else n = half;
     }
     return lo;
   }
+  // first index whose position is >= key (lists are sorted here)
+  __device__ __forceinline__ int lower_bound_pos(int which, long long key) const { return search_list<false>(which, 0, key); }
 
   // scores of every entry that has at least one concordant partner: the only
   // alignments best_pair can ever request (it computes them lazily, :1783-1790)
@@ -307,6 +345,7 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
     #pragma unroll
     for (int which = 0; which < 2; ++which) {
       const int other = 1 - which, n = lsz[which];
+      sample_list(other);
       for (int i = lane; i < n; i += 64) {
         const u32 pos = ld_list<BIG>(pl.lpos[which] + i);
         int mark = 0;
@@ -432,6 +471,7 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
     u32 keep_pa = 0, keep_pb = 0;
     int prev_hi = 0;
     int ib0 = (nb > 0 && static_cast<u32>(uni(static_cast<int>(ld_list<BIG>(posB)))) == 0u) ? 1 : 0;
+    sample_list(0);
     for (; ib0 < nb && !best.sure_ambig(); ib0 += 64) {
       const int ib = ib0 + lane;
       u32 pb = 0;
@@ -439,19 +479,9 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
       if (ib < nb) {
         pb = ld_list<BIG>(posB + ib);
         const u32 lim = pb + lenB;
-        int n = na;
-        while (n > 0) {  // first pos1 + max_dist >= lim
-          const int half = n >> 1;
-          if (ld_list<BIG>(posA + lo + half) + a.max_frag < lim) { lo += half + 1; n -= half + 1; }
-          else n = half;
-        }
-        hi = lo;
-        n = na - lo;
-        while (n > 0) {  // first pos1 + min_dist > lim, from lo on
-          const int half = n >> 1;
-          if (ld_list<BIG>(posA + hi + half) + a.min_frag <= lim) { hi += half + 1; n -= half + 1; }
-          else n = half;
-        }
+        // (32-bit sums, as the reference's: positions are genome offsets below 2^32 - 2^16 and the fragment limits small)
+        lo = search_list<false>(0, static_cast<long long>(a.max_frag), static_cast<long long>(lim));       // first pos1 + max_dist >= lim
+        hi = search_list<true>(0, static_cast<long long>(a.min_frag), static_cast<long long>(lim), lo);    // first pos1 + min_dist > lim, from lo on
         if (hi > lo) { db = ld_list<BIG>(pl.ld[1] + ib); sb = ld_list<BIG>(pl.lsc[1] + ib); }
       }
       else { lo = hi = na; }
@@ -740,6 +770,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   w.seg_epoch = 0;
 
   w.P.heap = w.pl.heap;
+  w.samp = reinterpret_cast<u32 *>(lds.pcache); w.samp_shift = 0; w.samp_n = 0;
   w.P.spill_pos = nullptr; w.P.spill_d = nullptr; w.P.spill_cap = 0; w.P.spilled = false;
   w.stage_pos = nullptr; w.stage_d = nullptr;
   if constexpr (PHASE == kSeed) {

@@ -29,7 +29,7 @@ import os
 # Paired-end steps of several (context, stream) slots overlap on the device (tier 2 ends in a few pairs that keep
 # single waves busy for seconds); the HIP runtime multiplexes streams onto 4 hardware queues unless told otherwise,
 # and must be told before it starts.  Measured at hg38 scale, 1 M pairs per step: 4 queues / 3 slots 1.8 M reads/s,
-# 16 queues / 12 slots 3.0 M reads/s (scripts/r02_pe_queues.sh); round 3's kernels: 16 slots 4.2-4.4 M against 4.1-4.2 M
+# 16 queues / 12 slots 3.0 M reads/s (profiles/r02_exp_pe_hw_queues.log); round 3's kernels: 16 slots 4.2-4.4 M against 4.1-4.2 M
 # with 12 (profiles/r03_exp_pe_slots.log).  Single-end is unaffected.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import json

@@ -93,13 +93,16 @@ def test_sam_text_from_the_device_equals_the_hosts(chain, flags):
     outs = {}
     for by in ("1", "0"):
         env = dict(os.environ, ABM_CLI_DEVICE_SAM=by, ABM_CLI_SLICE_READS="997")
-        r = subprocess.run([CLI, "map", "-v"] + flags + ["-s", f"tests/dev{by}.mstats", "-o", "tests/reads.sam", "-i", "tests/tRex1.idx", "tests/reads_1.fq"],
+        # (the reference's own command line, to the letter: the SAM's @PG line carries it)
+        r = subprocess.run([CLI, "map"] + flags + ["-s", "tests/reads.mstats", "-o", "tests/reads.sam", "-i", "tests/tRex1.idx", "tests/reads_1.fq"],
                            cwd=chain, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout
-        outs[by] = (open(chain / "tests/reads.sam").read(), open(chain / f"tests/dev{by}.mstats").read())
+        outs[by] = (open(chain / "tests/reads.sam").read(), open(chain / "tests/reads.mstats").read())
         if not flags:
             assert md5(chain / "tests/reads.sam") == g["tests/reads.sam"], f"SAM text by {'device' if by == '1' else 'host'} differs from the reference golden"
-    assert outs["1"] == outs["0"] and outs["1"][0].count("\n") > 8000
+            assert md5(chain / "tests/reads.mstats") == g["tests/reads.mstats"]
+    # (-A maps the simulator's T-rich reads as A-rich: few of them find a hit)
+    assert outs["1"] == outs["0"] and outs["1"][0].count("\n") > (400 if "-A" in flags else 8000)
     # the odd reads
     lines = open(chain / "tests/reads_1.fq").read().split("\n")
     import random
@@ -121,11 +124,13 @@ def test_sam_text_from_the_device_equals_the_hosts(chain, flags):
     outs = {}
     for by in ("1", "0"):
         env = dict(os.environ, ABM_CLI_DEVICE_SAM=by, ABM_CLI_SLICE_READS="997")
-        r = subprocess.run([CLI, "map"] + flags + ["-s", f"tests/odd{by}.mstats", "-o", "tests/odd.sam", "-i", "tests/tRex1.idx", "tests/odd.fq"],
+        r = subprocess.run([CLI, "map"] + flags + ["-s", "tests/odd.mstats", "-o", "tests/odd.sam", "-i", "tests/tRex1.idx", "tests/odd.fq"],
                            cwd=chain, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout
-        outs[by] = (open(chain / "tests/odd.sam").read(), open(chain / f"tests/odd{by}.mstats").read())
-    assert outs["1"] == outs["0"] and outs["1"][0].count("\n") > 5000
+        outs[by] = (open(chain / "tests/odd.sam").read(), open(chain / "tests/odd.mstats").read())
+    assert outs["1"] == outs["0"] and outs["1"][0].count("\n") > (200 if "-A" in flags else 5000)
+    if "-A" in flags:
+        return
     assert sum(1 for ln in outs["1"][0].split("\n") if not ln.startswith("@") and ln and len(__import__("re").findall(r"[MIDS]", ln.split("\t")[5])) >= 5) > 100
 
 

@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = [
     "abm_max_read_length", "abm_ctx_reads_too_long", "abm_ctx_filter_on_planes", "abm_ctx_long_cigars", "abm_ctx_take_work", "abm_ctx_set_phase_stamps", "abm_ctx_set_read_cycles", "abm_ctx_set_timing", "abm_ctx_take_kernel_time", "abm_ctx_take_kernel_times", "abm_ctx_take_work_tiers", "abm_stats_allreduce",
     "abm_device_count", "abm_host_alloc", "abm_host_free", "abm_index_set_seed_extension", "abm_index_set_max_candidates", "abm_index_set_direct_narrowing", "abm_ctx_seed_extension", "abm_ctx_rebuild_seed_extension", "abm_device_numa_node",
     "abm_ctx_set_pe_split", "abm_ctx_pe_split_stats", "abm_ctx_pe_timed_launches", "abm_ctx_set_pair_phases", "abm_device_memory", "abm_ctx_pe_footprint", "abm_index_set_seed_extension_cap", "abm_ctx_pinned_bytes", "abm_ctx_set_sam_tails", "abm_ctx_slice_sam_tails",
+    "abm_index_set_window_records", "abm_ctx_window_records",
 ]
 
 
@@ -155,6 +156,11 @@ class Index:
         self.max_candidates = self._lib.abm_index_max_candidates(h)
         self.window = self._lib.abm_index_window(h)
         self.device_bytes = self._lib.abm_index_bytes(h)
+
+    def set_window_records(self, max_read_len):
+        """abm_index_set_window_records: the index carries its candidates' windows for reads up to this length (0: none)"""
+        self._lib.abm_index_set_window_records.argtypes = [C.c_void_p, C.c_int]
+        _check(self._lib.abm_index_set_window_records(self.handle, int(max_read_len)))
 
     def set_seed_extension_cap(self, letters2, letters3):
         """abm_index_set_seed_extension_cap: the automatic table depths, capped (before the first context is created)"""
@@ -300,6 +306,12 @@ class Context:
 
     def reads_too_long(self):
         return int(self._lib.abm_ctx_reads_too_long(self.handle))
+
+    def window_records(self):
+        """abm_ctx_window_records: longest read the context's window records serve (0: none)"""
+        self._lib.abm_ctx_window_records.argtypes = [C.c_void_p]
+        self._lib.abm_ctx_window_records.restype = C.c_uint32
+        return int(self._lib.abm_ctx_window_records(self.handle))
 
     def filter_on_planes(self):
         return bool(self._lib.abm_ctx_filter_on_planes(self.handle))

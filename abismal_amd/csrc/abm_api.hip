@@ -107,6 +107,8 @@ struct DeviceReplica {
   abm::DevIndex dix{};
   int refs = 0;
   void *ext_mem[3] = {nullptr, nullptr, nullptr};  // seed-extension tables (abm_ext.hip), built for dix.ext_maxc candidates
+  void *wrec_mem = nullptr;                         // window records (DevIndex::wrec)
+  uint64_t plane_blocks = 0;                        // blocks of one bit-plane copy (guard blocks included)
   abm::u32 ext_tried = 0;                           // max_candidates of the last build attempt (it may have built nothing)
   double ext_build_s = 0;
   std::mutex mu;  // guards arena / refs / tables: the replicas of different devices are set up side by side
@@ -120,6 +122,7 @@ struct abm_index {
   abm::HostIndex h;
   int want_e2 = -1, want_e3 = -1;  // letters of the seed-extension tables; -1 = chosen from the index's size
   int cap_e2 = 7, cap_e3 = 4;      // ... but no more than these (abm_index_set_seed_extension_cap)
+  int wrec_len = 0;                // window records for reads of up to this many bases (abm_index_set_window_records); 0 = none
   mutable std::mutex mu;  // guards the map itself and the wishes below (a replica's contents: DeviceReplica::mu)
   mutable std::map<int, DeviceReplica> replicas;  // by device ordinal; nodes stay for the index's lifetime
   uint32_t want_maxc = 0;  // max_candidates the tables are built for; 0 = the index file's
@@ -268,6 +271,43 @@ void build_ext(DeviceReplica &rep, const abm_index &ix, abm::u32 maxc) {
   rep.dix.e3 = static_cast<abm::u32>(e3);
   rep.dix.ext_maxc = maxc;
   rep.ext_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Window records of one device replica (abm_ext.hip): for reads of up to ix.wrec_len bases, if the genome has bit planes,
+// the record numbers fit 32 bits and the table fits a quarter of the free device memory.
+void free_wrec(DeviceReplica &rep) {
+  if (rep.wrec_mem) (void)hipFree(rep.wrec_mem);
+  rep.wrec_mem = nullptr;
+  rep.dix.wrec = nullptr;
+  rep.dix.wrec_t0 = rep.dix.wrec_a0 = rep.dix.wrec_blocks = rep.dix.wrec_back = rep.dix.wrec_max_len = 0;
+}
+void build_wrec(DeviceReplica &rep, const abm_index &ix) {
+  free_wrec(rep);
+  int want = ix.wrec_len;
+  if (const char *e = experiment_env("ABM_WINDOW_RECORDS")) want = std::atoi(e);
+  if (want <= 0 || rep.dix.planes[0] == nullptr) return;
+  const abm::HostIndex &h = ix.h;
+  const abm::u32 blocks = abm::window_record_blocks_for(static_cast<abm::u32>(std::min(want, 172)));  // (groups of four lanes: reads up to 192 bases)
+  const uint64_t n_idx[3] = {h.index.size(), h.index_t.size(), h.index_a.size()};
+  const uint64_t n_entries = n_idx[0] + n_idx[1] + n_idx[2];
+  if (n_entries == 0 || (n_entries + 2) * blocks >= 0xFFFFFF00ull) return;
+  const size_t bytes = abm::window_record_bytes(n_entries, blocks);
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  if (bytes > free_b / 4) return;
+  HIPCHK(hipMalloc(&rep.wrec_mem, bytes));
+  try {
+    HIPCHK(hipMemset(rep.wrec_mem, 0, bytes));
+    HIPCHK(abm::build_window_records(rep.dix, rep.plane_blocks, n_idx, blocks, static_cast<abm::u64 *>(rep.wrec_mem), nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  catch (...) { free_wrec(rep); throw; }
+  rep.dix.wrec = static_cast<const abm::u64 *>(rep.wrec_mem);
+  rep.dix.wrec_t0 = static_cast<abm::u32>(n_idx[0]);
+  rep.dix.wrec_a0 = static_cast<abm::u32>(n_idx[0] + n_idx[1]);
+  rep.dix.wrec_blocks = blocks;
+  rep.dix.wrec_max_len = abm::window_record_max_len(blocks);
+  rep.dix.wrec_back = rep.dix.wrec_max_len - abm::kKeyWeight;
 }
 
 // the index as a launch sees it: the context's arrays plus the replica's seed-extension tables -- if they were built
@@ -968,6 +1008,7 @@ int abm_ctx_pe_footprint(abm_ctx *ctx, uint64_t n, uint32_t max_len, uint64_t *b
 
 uint32_t abm_max_read_length(void) { return abm::kMaxReadLen; }
 uint64_t abm_ctx_reads_too_long(abm_ctx *ctx) { return ctx ? ctx->too_long : 0; }
+uint32_t abm_ctx_window_records(const abm_ctx *ctx) { return ctx && ctx->dix.wrec != nullptr ? ctx->dix.wrec_max_len : 0u; }
 int abm_ctx_filter_on_planes(const abm_ctx *ctx) { return ctx && ctx->dix.planes[0] != nullptr ? 1 : 0; }
 
 int abm_index_open(const char *path, abm_index **out) {
@@ -1006,6 +1047,15 @@ int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3) {
     for (auto &r : ix->replicas) if (r.second.refs) throw std::invalid_argument("set the seed extension before the first context is created");
     ix->want_e2 = letters2;
     ix->want_e3 = letters3;
+  });
+}
+
+int abm_index_set_window_records(abm_index *ix, int max_read_len) {
+  return guarded([&] {
+    if (!ix) throw std::invalid_argument("index is null");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (auto &r : ix->replicas) if (r.second.refs) throw std::invalid_argument("set the window records before the first context is created");
+    ix->wrec_len = std::max(0, max_read_len);
   });
 }
 
@@ -1155,7 +1205,7 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
               HIPCHK(abm::launch_make_planes(rep.dix.genome, h.genome.size(), n_bases, n_blocks, p0, p1, nmap, d_bad, nullptr));
               abm::u32 bad = 0;
               HIPCHK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
-              if (!bad) { rep.dix.planes[0] = p0; rep.dix.planes[1] = p1; rep.dix.nmap = nmap; }
+              if (!bad) { rep.dix.planes[0] = p0; rep.dix.planes[1] = p1; rep.dix.nmap = nmap; rep.plane_blocks = n_blocks; }
               if (const char *e = experiment_env("ABM_PLANES_COPIES")) if (e[0] == '1') rep.dix.planes[1] = p0;
             }
           }
@@ -1163,8 +1213,10 @@ int abm_ctx_create(const abm_index *ix, int device, abm_ctx **out) {
           rep.arena = arena;
           rep.dix.ext2 = rep.dix.ext3t = rep.dix.ext3a = nullptr;
           rep.dix.e2 = rep.dix.e3 = rep.dix.ext_maxc = 0;
-          try { build_ext(rep, *ix, tables_maxc); }
-          catch (...) { (void)hipFree(arena); rep.arena = nullptr; throw; }
+          rep.dix.wrec = nullptr;
+          rep.dix.wrec_t0 = rep.dix.wrec_a0 = rep.dix.wrec_blocks = rep.dix.wrec_back = rep.dix.wrec_max_len = 0;
+          try { build_wrec(rep, *ix); build_ext(rep, *ix, tables_maxc); }
+          catch (...) { free_wrec(rep); (void)hipFree(arena); rep.arena = nullptr; throw; }
         }
         ++rep.refs;
         c->holds_replica = true;
@@ -1194,6 +1246,7 @@ void abm_ctx_destroy(abm_ctx *c) {
     std::lock_guard<std::mutex> lk(c->rep->mu);
     if (--c->rep->refs == 0) {
       free_ext(*c->rep);
+      free_wrec(*c->rep);
       (void)hipFree(c->rep->arena);
       c->rep->arena = nullptr;
     }

@@ -57,6 +57,16 @@ struct DevIndex {
   // tabulated (bisect from the bucket's counters).
   const uint2 *ext2, *ext3t, *ext3a;
   u32 e2, e3, ext_maxc;
+  // Window records (abm_ext.hip, build_window_records): every index entry once more, as the stretch of the bit planes
+  // a candidate window of that entry can lie in -- wrec_blocks blocks of 64 bases {u64 low bits, u64 high bits}
+  // starting wrec_back bases before the entry's position.  Seed offset i of a read puts its window at bit
+  // wrec_back - i of the record.  A checked bucket's windows then are CONSECUTIVE records (48 bytes each for reads up
+  // to 108 bases: 2.7 windows per 128-byte line) instead of one random line each.  Record number of entry e: e for
+  // `index`, wrec_t0 + e for index_t, wrec_a0 + e for index_a.  Serves reads of up to wrec_max_len bases; null = none
+  // (the filter then gathers its windows from `planes`).
+  const u64 *wrec;
+  u32 wrec_t0, wrec_a0;
+  u32 wrec_blocks, wrec_back, wrec_max_len;
   u32 direct_min;  // pair kernels: ranges of at least this many entries are narrowed directly (narrow_direct); 0 = never
   // the index's chromosome table as `abismal-amd map` sees it (names and n + 1 starts, the two padding entries included):
   // what the single-end kernel needs to write a read's SAM text itself (SeArgs::sam_tail)

@@ -176,4 +176,48 @@ hipError_t build_ext_table(const DevIndex &ix, int mode, u32 extra, u32 maxc, u6
   return hipGetLastError();
 }
 
+// ---- window records (DevIndex::wrec) -------------------------------------------------------------------------
+// One thread per (index entry, block): block b of entry e's record is the 64 bases from position index[e] - back + 64 b
+// of the genome's bit planes.  Bases before the genome's first (never reached: the index leaves the padding out) read
+// as code 0, like the planes' own guard blocks past the end.
+__global__ __launch_bounds__(256) void window_records_kernel(const u64 *__restrict__ planes0, u64 n_plane_blocks,
+                                                             const u32 *__restrict__ index, u64 n_entries, u64 first_record,
+                                                             u32 blocks, u32 back, u64 *__restrict__ out) {
+  const u64 t = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const u64 e = t / blocks;
+  const u32 b = static_cast<u32>(t % blocks);
+  if (e >= n_entries) return;
+  const long long bit = static_cast<long long>(index[e]) - static_cast<long long>(back) + 64ll * b;
+  auto plane = [&](long long k, u32 which) -> u64 {
+    return k >= 0 && static_cast<u64>(k) < n_plane_blocks ? planes0[2 * static_cast<u64>(k) + which] : 0ull;
+  };
+  const long long k = bit >> 6;  // (arithmetic shift: floor)
+  const u32 s = static_cast<u32>(bit & 63);
+  u64 lo = plane(k, 0) >> s, hi = plane(k, 1) >> s;
+  if (s) { lo |= plane(k + 1, 0) << (64 - s); hi |= plane(k + 1, 1) << (64 - s); }
+  u64 *o = out + 2 * ((first_record + e) * blocks + b);
+  o[0] = lo; o[1] = hi;
+}
+
+u32 window_record_max_len(u32 blocks) { return blocks ? (64u * blocks + kKeyWeight) / 2u : 0u; }
+u32 window_record_blocks_for(u32 max_len) {
+  u32 b = 1;
+  while (window_record_max_len(b) < max_len) ++b;
+  return b;
+}
+size_t window_record_bytes(u64 n_entries, u32 blocks) { return (n_entries * blocks + 2) * 16 + 256; }
+hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, const u64 n_idx[3], u32 blocks, u64 *out, hipStream_t st) {
+  const u32 back = window_record_max_len(blocks) - kKeyWeight;
+  const u32 *arrays[3] = {ix.index, ix.index_t, ix.index_a};
+  u64 first = 0;
+  for (int m = 0; m < 3; ++m) {
+    const u64 threads = n_idx[m] * blocks;
+    if (threads)
+      hipLaunchKernelGGL(window_records_kernel, dim3(static_cast<u32>((threads + 255) / 256)), dim3(256), 0, st, ix.planes[0], n_plane_blocks,
+                         arrays[m], n_idx[m], first, blocks, back, out);
+    first += n_idx[m];
+  }
+  return hipGetLastError();
+}
+
 }  // namespace abm

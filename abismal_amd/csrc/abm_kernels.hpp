@@ -169,6 +169,13 @@ u64 ext_keys(int mode, u32 extra);
 size_t ext_scratch_bytes(int mode, u32 extra);
 hipError_t build_ext_table(const DevIndex &ix, int mode, u32 extra, u32 maxc, u64 n_idx, uint2 *out, void *scratch, u32 *d_fail,
                            hipStream_t st);
+// window records (DevIndex::wrec): the longest read records of `blocks` blocks serve (2 L - key weight <= 64 blocks: the
+// first seed offset's window must end, and the last one's begin, inside the record), the blocks a read length needs, the
+// bytes of the table, and the build (records of index, index_t, index_a one after the other; n_idx = their entries)
+u32 window_record_max_len(u32 blocks);
+u32 window_record_blocks_for(u32 max_len);
+size_t window_record_bytes(u64 n_entries, u32 blocks);
+hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, const u64 n_idx[3], u32 blocks, u64 *out, hipStream_t st);
 // bit-plane copies of the genome for the Hamming filter (DevIndex::planes): n_blocks blocks of 64 bases each,
 // from the first n_words words of nibbles; blank nibbles (N) mark their surroundings in nmap (DevIndex::nmap,
 // zeroed by the caller); *bad is set if a nibble below n_bases has two or more bits

@@ -588,9 +588,15 @@ __device__ __forceinline__ void build_qmasks(const WaveLds &lds, u32 L) {
 // block arrive by DPP from the next lane.  mismatches = 64 - popcount(the mask of the code each genome base has).
 // Identical to full_compare's sum over whole words for a one-hot genome (src/abismal.cpp:1093-1122; the early exit
 // there changes a distance only when the hit is rejected anyway).
-template <u32 kRounds = kCoopRounds>
+//
+// REC: the windows come from the window records (DevIndex::wrec) instead: pos_a / pos_b are then the candidates' record
+// starts (record number x blocks per record, in 16-byte blocks) and x_a / x_b the bit of the record their window begins
+// at (wrec_back - seed offset).  The blocks a group loads past its candidate's record (at most one: see wrec_max_len)
+// only reach read positions past the end of the read, whose masks admit every code.
+template <u32 kRounds = kCoopRounds, bool REC = false>
 __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
-                                               u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
+                                               u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b,
+                                               u32 x_a = 0, u32 x_b = 0) {
   const int lane = lane_id();
   const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
@@ -612,6 +618,15 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
       const bool second = (pass * kRounds + r) * per_round >= 64;
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
+      const u64 *g;
+      if constexpr (REC) {
+        const u32 cx = static_cast<u32>(__shfl(static_cast<int>(second ? x_b : x_a), static_cast<int>(c)));
+        shifts |= static_cast<u64>(cx & 63u) << (8 * r);
+        const u32 b0 = cx / kPlaneBlock, b1 = G == 4 ? b0 + 3 : (cx + L - 1) / kPlaneBlock;
+        const bool act = (((second ? wb : wa) >> c) & 1ull) && b0 + sub <= b1;
+        g = act ? ix.wrec + 2 * (static_cast<u64>(cp) + b0 + sub) : ix.wrec;
+      }
+      else {
       shifts |= static_cast<u64>(cp & 63u) << (8 * r);
       // (a group of four always fetches four blocks, 64 contiguous bytes: the memory pipeline merges the loads of a
       // full quad of lanes into one request, and those of a partly active quad not at all -- measured, 2.5 requests per
@@ -622,8 +637,9 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
       // divergent branch is waited for inside it): a lane with nothing to fetch reads the array's first line.
       // What it gets is never looked at -- its bits could only reach read positions past the end, whose masks
       // admit every code, or candidates whose result is discarded.
-      const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
-                         : ix.planes[0];
+      g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+              : ix.planes[0];
+      }
       xl[r] = g[0];
       xh[r] = g[1];
     }
@@ -653,8 +669,10 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
 // counting 64 read bases against them -- no exchange between the lanes, and 32 candidates per round instead of 16:
 // the kernel is bound by vector-instruction issue once its windows are single lines (76 % of the SIMDs' cycles),
 // and this halves the filter's instructions per candidate.  One round (32 windows, 8 registers) in flight per pass.
+template <bool REC = false>
 __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
-                                                     u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
+                                                     u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b,
+                                                     u32 x_a = 0, u32 x_b = 0) {
   const int lane = lane_id();
   const u32 sub = lane & 1u, grp = lane >> 1;
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
@@ -669,12 +687,21 @@ __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const W
     if (static_cast<u32>((second ? wb : wa) >> ((pass & 1u) * 32u)) == 0u) continue;
     const u32 c = slot & 63u;
     const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
-    const u32 sh = cp & 63u;
-    const u32 b0 = cp / kPlaneBlock, b1 = b0 + 2;  // a window of up to 128 bases has at most three blocks
     const bool act = ((second ? wb : wa) >> c) & 1ull;
-    // (unconditional loads, as in hamming_planes: a lane with nothing to fetch reads the array's first line)
-    const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
-                       : ix.planes[0];
+    u32 sh;
+    const u64 *g;
+    if constexpr (REC) {  // (see hamming_planes)
+      const u32 cx = static_cast<u32>(__shfl(static_cast<int>(second ? x_b : x_a), static_cast<int>(c)));
+      sh = cx & 63u;
+      g = act ? ix.wrec + 2 * (static_cast<u64>(cp) + cx / kPlaneBlock + sub) : ix.wrec;
+    }
+    else {
+      sh = cp & 63u;
+      const u32 b0 = cp / kPlaneBlock, b1 = b0 + 2;  // a window of up to 128 bases has at most three blocks
+      // (unconditional loads, as in hamming_planes: a lane with nothing to fetch reads the array's first line)
+      g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+              : ix.planes[0];
+    }
     const u64 xl = g[0], xh = g[1], nl = g[2], nh = g[3];
     const u64 gl = (xl >> sh) | ((nl << (63 - sh)) << 1), gh = (xh >> sh) | ((nh << (63 - sh)) << 1);
     const u64 match = (~gh & ((~gl & m0) | (gl & m1))) | (gh & ((~gl & m2) | (gl & m3)));
@@ -808,6 +835,9 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   // every offset of the pass) and for the max_candidates they were built with; otherwise the loops start at the counters
   const bool use_ext = SPECIFIC && ix.ext2 != nullptr && ix.ext_maxc == maxc &&
                        L - n_off + 1 >= max(kKeyWeight + ix.e2, kKeyWeight3 + ix.e3);
+  // window records (DevIndex::wrec): for reads they were built for, filtered by groups of two or four lanes
+  const bool use_rec = COOP && ix.wrec != nullptr && L <= ix.wrec_max_len && (lds.G == 2 || lds.G == 4);
+  const u32 rec3 = g_to_a ? ix.wrec_a0 : ix.wrec_t0;
 
   // work tallies: the diagnostic builds keep them, the production kernels do not (they cost the single-end kernel
   // registers: 100 -> 64 bytes per lane of scratch without them; the pair kernels kept them until round 5, when five
@@ -964,12 +994,14 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     u32 carry = 0;
     bool nva = false, nvb = false;
     u32 nsa = 0, nsb = 0, nea = 0, neb = 0;
+    u32 nra = 0, nrb = 0;  // (window records: the candidates' entry numbers in their index arrays)
     auto fetch_entries = [&](u32 c0) {
       u32 ea_at, eb_at;
       locate128(lds, seg_epoch, sg, c0, total, carry, nva, nvb, nsa, nsb, ea_at, eb_at);
       nea = 0; neb = 0;
       if (nva) nea = (nsa & 1u) ? idx3[ea_at] : ix.index[ea_at];
       if (nvb) neb = (nsb & 1u) ? idx3[eb_at] : ix.index[eb_at];
+      if constexpr (COOP) if (use_rec) { nra = ea_at; nrb = eb_at; }
     };
     fetch_entries(0);
     for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
@@ -978,6 +1010,11 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       const bool two = c0 + 64 < total;  // (uniform: this step has a b half)
       const bool va = nva, vb = nvb;
       const u32 pa = nea - (g0 + (nsa >> 1)), pb = neb - (g0 + (nsb >> 1));
+      u32 ra = 0, rb = 0, xa = 0, xb = 0;
+      if constexpr (COOP) if (use_rec) {  // record start (in 16-byte blocks) and the bit of the record the window begins at
+        ra = (nra + ((nsa & 1u) ? rec3 : 0u)) * ix.wrec_blocks; xa = ix.wrec_back - (g0 + (nsa >> 1));
+        rb = (nrb + ((nsb & 1u) ? rec3 : 0u)) * ix.wrec_blocks; xb = ix.wrec_back - (g0 + (nsb >> 1));
+      }
       if (c0 + 128 < total) fetch_entries(c0 + 128);
       // the same genome position is proposed again and again (neighbouring seeds of one hit, the
       // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
@@ -993,7 +1030,13 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
         const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
         const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-        if (lds.G == 2)
+        if (use_rec) {
+          if (lds.G == 2)
+            hamming_planes_pairs<true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va && !hit_a, rb, vb && !hit_b, ha, hb, xa, xb);
+          else
+            hamming_planes<kCoopRounds, true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va && !hit_a, rb, vb && !hit_b, ha, hb, xa, xb);
+        }
+        else if (lds.G == 2)
           hamming_planes_pairs(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
         else
           hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);

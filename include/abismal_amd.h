@@ -93,6 +93,17 @@ int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3);
  * are 36 GB; the single-end kernel is 1.6 % faster with the former, the pair kernels 3 % faster with the latter
  * (profiles/r05_exp_tables_repriced.log) -- so a host that maps pairs caps at 6 and 3.  Contexts created afterwards. */
 int abm_index_set_seed_extension_cap(abm_index *ix, int letters2, int letters3);
+/* Window records (no reference counterpart; results are unaffected).  check_hits (src/abismal.cpp:1124-1150) compares
+ * the read with the genome at every entry of a checked bucket: one random gather per candidate, and at hg38 scale 2,800
+ * of them per 100-base read -- the line requests that bound the mapping kernels.  With 288 GB of HBM the index can carry
+ * its candidates' windows itself: for every index entry the stretch of the genome (as bit planes, 2 bits per base) that
+ * a window of a read of up to max_read_len bases can lie in, entries in index order, so that a bucket's windows are
+ * consecutive 48-byte records (reads up to 108 bases; 64 bytes up to 140, 80 up to 172) instead of one 128-byte line
+ * each.  8.4 GB at hg38 scale for 100-base reads.  Reads longer than the records serve are filtered from the bit planes
+ * as before.  0 = none (the default); must precede the first abm_ctx_create on the index.  abm_ctx_window_records: the
+ * longest read the context's records serve (0: none were built -- no planes, or not enough free device memory). */
+int abm_index_set_window_records(abm_index *ix, int max_read_len);
+uint32_t abm_ctx_window_records(const abm_ctx *ctx);
 /* the max_candidates (-c, src/abismal.cpp:2329) the calls on this index will pass, when it is not the value stored
  * in the index file: the tables of contexts created afterwards are built for it (0 = the file's value) */
 int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates);

@@ -193,7 +193,7 @@ __device__ __forceinline__ u32 format_sam_tail(const SeArgs &a, u8 *line /*LDS, 
   return o.w;
 }
 
-template <bool TIMED, bool COOP, bool LONG>
+template <bool TIMED, bool COOP, bool LONG, bool REC = false>
 __device__ __forceinline__ void map_se_body(const SeArgs &a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -261,6 +261,7 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
     const u64 slot = r_next;
     const u64 r = a.order ? static_cast<u64>(a.order[r_next]) : r_next;
     r_next = next_read();  // fetched early; its latency hides under this read's work
+    __builtin_amdgcn_s_setprio(0);  // (a heavy read raises its wave's priority: seed_pass)
     long long t_read = 0;
     if (TIMED) t_read = clock64();
     bool rd_overflow = false;  // THIS read's CIGAR found no room (the launch's flag `overflow` is sticky)
@@ -296,11 +297,11 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
         const u32 enc = (rc ? 2u : 0u) + (g_to_a ? 1u : 0u);
         const u32 flags = (rc ? kFlagRC : 0u) | (ar ? kFlagARich : 0u);
         S.cutoff = S.good_cutoff;  // set_specific
-        seed_pass<true, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
+        seed_pass<true, TIMED, COOP, REC>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         // should_do_sensitive, :367-370
         if (S.sz != static_cast<int>(kSeCap) || S.cutoff > S.good_cutoff) {
           S.cutoff = S.top_d();  // set_sensitive
-          seed_pass<false, TIMED, COOP>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
+          seed_pass<false, TIMED, COOP, REC>(a.ix, lds, enc, g_to_a, flags, L, S, wt, seg_epoch);
         }
       }
       ABM_STAMP(t_a);
@@ -379,8 +380,9 @@ __device__ __forceinline__ void map_se_body(const SeArgs &a) {
 }
 
 // (the launch bound's second argument is waves per SIMD: 5 x 4 SIMDs = 20 one-wave workgroups per CU)
-template <bool TIMED, bool COOP>
-__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false>(a); }
+// REC: the filter reads the window records (DevIndex::wrec) -- a launch none of whose reads is longer than they serve
+template <bool TIMED, bool COOP, bool REC = false>
+__global__ __launch_bounds__(64, ABM_SE_WAVES_PER_SIMD) void map_se_kernel(SeArgs a) { map_se_body<TIMED, COOP, false, REC>(a); }
 __global__ __launch_bounds__(64, 1) void map_se_long_kernel(SeArgs a) { map_se_body<false, false, true>(a); }
 
 // reads of this batch that the long-read launch takes: kLdsReadLen < length <= kMaxReadLen
@@ -778,7 +780,11 @@ hipError_t launch_map_se(SeArgs a, u32 max_len, u32 n_waves, bool timed, hipStre
   const size_t lds = se_lds_bytes(a.W, a.WB, a.ctmp_cap, max_len, a.size_frac);
   const u32 blocks = static_cast<u32>(a.n_reads < n_waves ? a.n_reads : n_waves);
   // COOP: lanes share a candidate's window on the bit planes (a.G != 0); otherwise one lane per window
-  if (a.G != 0) {
+  if (a.G != 0 && a.ix.wrec != nullptr && max_len <= a.ix.wrec_max_len && (a.G == 2 || a.G == 4)) {
+    if (timed) hipLaunchKernelGGL((map_se_kernel<true, true, true>), dim3(blocks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_se_kernel<false, true, true>), dim3(blocks), dim3(64), lds, st, a);
+  }
+  else if (a.G != 0) {
     if (timed) hipLaunchKernelGGL((map_se_kernel<true, true>), dim3(blocks), dim3(64), lds, st, a);
     else hipLaunchKernelGGL((map_se_kernel<false, true>), dim3(blocks), dim3(64), lds, st, a);
   }

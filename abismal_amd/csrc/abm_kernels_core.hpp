@@ -802,6 +802,10 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
 // candidates (all checked buckets of 64 offsets flattened in reference order)
 // for the Hamming filter; survivors are replayed in order into the set.
+#ifndef ABM_HEAVY_BLOCK
+#define ABM_HEAVY_BLOCK 4096
+#endif
+constexpr u32 kHeavyBlock = ABM_HEAVY_BLOCK;  // candidates in one block of 64 seed offsets from which a read counts as heavy
 struct WorkTally {
   u32 seed_iters, probes, cands, words, updates, cache_hits;
   u32 fifo_updates, steps, light_steps;  // diagnostic build only
@@ -819,7 +823,13 @@ __device__ __forceinline__ long long phase_stamp() {
 }
 #define ABM_STAMP(var) do { if (TIMED) var = phase_stamp(); } while (0)
 
-template <bool SPECIFIC, bool TIMED, bool COOP, class Set>
+// REC: the launch filters on the window records (DevIndex::wrec; every read of the launch is short enough for them).  A
+// candidate's window is then addressed by its entry NUMBER, so the step neither waits for the index entries nor reads them
+// at all, except for the few candidates whose distance is within the cutoff: those alone need a position -- for the
+// set, and to ask whether an N is within reach of the window (the planes' distance never exceeds the true one -- a blank
+// nibble matches nothing, the planes' code 0 there may match -- so a candidate beyond the cutoff on the planes is beyond
+// it on the nibble array too).  No position cache either: a repeated window costs a third of a line, not a line.
+template <bool SPECIFIC, bool TIMED, bool COOP, bool REC, class Set>
 __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds, u32 enc, bool g_to_a,
                                           u32 flags, u32 L, Set &S, WorkTally &wt, u32 &seg_epoch) {
   const int lane = lane_id();
@@ -835,9 +845,8 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   // every offset of the pass) and for the max_candidates they were built with; otherwise the loops start at the counters
   const bool use_ext = SPECIFIC && ix.ext2 != nullptr && ix.ext_maxc == maxc &&
                        L - n_off + 1 >= max(kKeyWeight + ix.e2, kKeyWeight3 + ix.e3);
-  // window records (DevIndex::wrec): for reads they were built for, filtered by groups of two or four lanes
-  const bool use_rec = COOP && ix.wrec != nullptr && L <= ix.wrec_max_len && (lds.G == 2 || lds.G == 4);
-  const u32 rec3 = g_to_a ? ix.wrec_a0 : ix.wrec_t0;
+  static_assert(!REC || COOP, "window records are filtered cooperatively");
+  const u32 rec3 = g_to_a ? ix.wrec_a0 : ix.wrec_t0;  // (REC) record number of the 3-letter table's first entry
 
   // work tallies: the diagnostic builds keep them, the production kernels do not (they cost the single-end kernel
   // registers: 100 -> 64 bytes per lane of scratch without them; the pair kernels kept them until round 5, when five
@@ -846,7 +855,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   // direct narrowing of big ranges: in the pair kernels only (see narrow_direct)
   constexpr bool kDirect = Set::kAppend ? ABM_PE_DIRECT_NARROWING : false;
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
-  if (SPECIFIC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
+  if (SPECIFIC && !REC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
     for (u32 k = lane; k < (1u << kPosCacheBits); k += 64) lds.pcache[k] = 0;
     wave_sync();
   }
@@ -950,6 +959,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     ABM_STAMP(tb_);
     if (TIMED) wt.t_probe += tb_ - ta;
     if (total == 0) continue;
+    // A read with this many candidates in one block of offsets is one of the launch's costliest (a homopolymer, a
+    // satellite): its wave is served first from here on (until the kernel's next read), so that it runs at the pace of
+    // a wave alone on its SIMD instead of a fifth of it -- such reads are what a launch's last milliseconds wait for.
+    if (total >= kHeavyBlock) __builtin_amdgcn_s_setprio(3);
     if (seg_epoch >= kSegEpochLimit) {  // (sixteen million steps on: start the mark tags over)
       lds.smark[lane] = 0; lds.smark[64 + lane] = 0;
       seg_epoch = 0;
@@ -991,17 +1004,58 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
     // step costs one dependent memory round trip instead of two (what a read with millions of
     // candidates -- one wave, no other latency hiding at the end of a launch -- is made of).
     // A step with at most 64 candidates (most steps of an ordinary read) does nothing for its b half.
+    if constexpr (REC) {
+      u32 carry = 0;
+      for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
+        ABM_STAMP(tc);
+        if (TIMED) { ++wt.steps; if (total - c0 <= 64) ++wt.light_steps; }
+        const bool two = c0 + 64 < total;  // (uniform: this step has a b half)
+        bool va, vb;
+        u32 sa, sb, ea, eb;
+        locate128(lds, seg_epoch, sg, c0, total, carry, va, vb, sa, sb, ea, eb);
+        const u32 ia = g0 + (sa >> 1), ib = g0 + (sb >> 1);
+        // record start (in 16-byte blocks) and the bit of the record the window begins at
+        const u32 ra = (ea + ((sa & 1u) ? rec3 : 0u)) * ix.wrec_blocks, rb = (eb + ((sb & 1u) ? rec3 : 0u)) * ix.wrec_blocks;
+        int ha, hb = 0x7fff;
+        if (lds.G == 2)
+          hamming_planes_pairs<true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va, rb, vb, ha, hb, ix.wrec_back - ia, ix.wrec_back - ib);
+        else
+          hamming_planes<kCoopRounds, true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va, rb, vb, ha, hb, ix.wrec_back - ia, ix.wrec_back - ib);
+        // the candidates that may still enter the set: these alone need their position
+        const bool ca = va && ha <= S.cutoff, cb = two && vb && hb <= S.cutoff;
+        u32 pa = 0, pb = 0;
+        if (__any(ca || cb)) {
+          if (ca) pa = ((sa & 1u) ? idx3[ea] : ix.index[ea]) - ia;
+          if (cb) pb = ((sb & 1u) ? idx3[eb] : ix.index[eb]) - ib;
+          const u32 na = ca ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
+          const u32 nb = cb ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
+          if (__any((na | nb) & 1u)) {  // rare: redone on the nibble array, where an N is an N
+            if (na & 1u) ha = hamming(ix.genome, qpk, nwords, pa);
+            if (nb & 1u) hb = hamming(ix.genome, qpk, nwords, pb);
+          }
+        }
+        if (TALLY) {
+          wt.cands += (va ? 1u : 0u) + (vb ? 1u : 0u);
+          if constexpr (!Set::kAppend) wt.words += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * (lds.G == 2 ? 6u : 8u);
+        }
+        ABM_STAMP(td);
+        if (TIMED) wt.t_stream += td - tc;
+        replay(ca, ha, ha, pa);
+        if (two && !S.sure_ambig) replay(cb, hb, hb, pb);
+        ABM_STAMP(tc);
+        if (TIMED) wt.t_replay += tc - td;
+      }
+      continue;
+    }
     u32 carry = 0;
     bool nva = false, nvb = false;
     u32 nsa = 0, nsb = 0, nea = 0, neb = 0;
-    u32 nra = 0, nrb = 0;  // (window records: the candidates' entry numbers in their index arrays)
     auto fetch_entries = [&](u32 c0) {
       u32 ea_at, eb_at;
       locate128(lds, seg_epoch, sg, c0, total, carry, nva, nvb, nsa, nsb, ea_at, eb_at);
       nea = 0; neb = 0;
       if (nva) nea = (nsa & 1u) ? idx3[ea_at] : ix.index[ea_at];
       if (nvb) neb = (nsb & 1u) ? idx3[eb_at] : ix.index[eb_at];
-      if constexpr (COOP) if (use_rec) { nra = ea_at; nrb = eb_at; }
     };
     fetch_entries(0);
     for (u32 c0 = 0; c0 < total && !S.sure_ambig; c0 += 128) {
@@ -1010,11 +1064,6 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
       const bool two = c0 + 64 < total;  // (uniform: this step has a b half)
       const bool va = nva, vb = nvb;
       const u32 pa = nea - (g0 + (nsa >> 1)), pb = neb - (g0 + (nsb >> 1));
-      u32 ra = 0, rb = 0, xa = 0, xb = 0;
-      if constexpr (COOP) if (use_rec) {  // record start (in 16-byte blocks) and the bit of the record the window begins at
-        ra = (nra + ((nsa & 1u) ? rec3 : 0u)) * ix.wrec_blocks; xa = ix.wrec_back - (g0 + (nsa >> 1));
-        rb = (nrb + ((nsb & 1u) ? rec3 : 0u)) * ix.wrec_blocks; xb = ix.wrec_back - (g0 + (nsb >> 1));
-      }
       if (c0 + 128 < total) fetch_entries(c0 + 128);
       // the same genome position is proposed again and again (neighbouring seeds of one hit, the
       // sensitive pass repeating the specific one): a small per-call cache of (pos -> distances)
@@ -1030,13 +1079,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         // (is an N within reach of the window?  asked before the windows so that the answers arrive with them)
         const u32 na = va && !hit_a ? ix.nmap[pa >> (kPlaneChunkBits + 5)] >> ((pa >> kPlaneChunkBits) & 31u) : 0u;
         const u32 nb = vb && !hit_b ? ix.nmap[pb >> (kPlaneChunkBits + 5)] >> ((pb >> kPlaneChunkBits) & 31u) : 0u;
-        if (use_rec) {
-          if (lds.G == 2)
-            hamming_planes_pairs<true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va && !hit_a, rb, vb && !hit_b, ha, hb, xa, xb);
-          else
-            hamming_planes<kCoopRounds, true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va && !hit_a, rb, vb && !hit_b, ha, hb, xa, xb);
-        }
-        else if (lds.G == 2)
+        if (lds.G == 2)
           hamming_planes_pairs(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);
         else
           hamming_planes(ix, lds, lds.qmask + enc * lds.MB * 4, L, pa, va && !hit_a, pb, vb && !hit_b, ha, hb);

@@ -119,10 +119,10 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
     P.begin_read(len_of(end));
     if (len_of(end) >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
+      seed_pass<true, TIMED, COOP, false>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, COOP>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
+        seed_pass<false, TIMED, COOP, false>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       }
     }
     need_big |= P.overflow;
@@ -804,6 +804,7 @@ __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
   while (it_next < n_items) {
     const u64 it = it_next;
     it_next = next_item();
+    __builtin_amdgcn_s_setprio(0);  // (a heavy end raises its wave's priority: seed_pass)
     const u64 r = BIG ? static_cast<u64>(a.subset[it]) : (a.order ? static_cast<u64>(a.order[it]) : it);
     if constexpr (PHASE == kMate && !BIG) {  // (the small-list mate kernel walks the whole batch: the other routes' pairs are not its)
       if (static_cast<u8>(uni(static_cast<int>(a.need_big[r]))) != kRouteSmall) continue;

@@ -1075,7 +1075,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = ctx.take_kernel_time()
+    per_launch_ms = ctx.take_kernel_times()
+    launches, kernel_ms = len(per_launch_ms), float(sum(per_launch_ms))
     work = ctx.take_work()
     ctx.set_timing(False)
     long_arena = ctx.long_cigars()  # CIGARs of the last step that outgrew their device slot
@@ -1254,6 +1255,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                 "avg_kernel_ms": round(avg_ms, 3),
+                "kernel_ms_per_launch": [round(x, 1) for x in per_launch_ms],
                 "alg_bytes_per_read": round(use_bytes, 1),
                 "alg_bytes_per_read_strict": round(strict["bytes_per_read"], 1) if strict else None,
                 "alg_bytes_per_read_kernel_tally": round(k_bytes, 1),

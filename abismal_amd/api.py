@@ -136,12 +136,16 @@ def index_build(fasta, out, threads=0, targets=None, window=20):
 # choice from the index's size (none for small genomes).  The GPU test suite sets (2, 1) so that its small genomes
 # run the table path of the seed passes, and names (0, 0) where it wants the bisection-only path.
 DEFAULT_SEED_EXTENSION = None
+# read length Index() asks window records for (abm_index_set_window_records) when its caller does not say: None = the
+# library's default (no records).  The GPU test suite sets 172 -- the record-fed kernels are what an hg38-scale run of the
+# CLI or of bench.py uses -- and names 0 where it wants the filter on the bit planes.
+DEFAULT_WINDOW_RECORDS = None
 
 
 class Index:
     """abm_index_open / abm_index_close."""
 
-    def __init__(self, path, seed_extension=None):
+    def __init__(self, path, seed_extension=None, window_records=None):
         self._lib = load_library()
         h = C.c_void_p()
         _check(self._lib.abm_index_open(os.fsencode(path), C.byref(h)))
@@ -149,6 +153,9 @@ class Index:
         ext = seed_extension if seed_extension is not None else DEFAULT_SEED_EXTENSION
         if ext is not None:
             _check(self._lib.abm_index_set_seed_extension(h, int(ext[0]), int(ext[1])))
+        wrec = window_records if window_records is not None else DEFAULT_WINDOW_RECORDS
+        if wrec is not None:
+            self.set_window_records(wrec)
         n = self._lib.abm_index_n_chroms(h)
         self.chrom_names = [self._lib.abm_index_chrom_name(h, i).decode() for i in range(n)]
         st = self._lib.abm_index_chrom_starts(h)

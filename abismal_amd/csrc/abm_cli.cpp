@@ -847,6 +847,8 @@ struct Options {
   size_t batch = 0;  // reads (pairs) per batch; 0 = default for the input type
   int mappers = 0;  // mapper threads (contexts) per GPU; 0 = 2 for single-end, 3 for paired-end input
   int ext2 = -1, ext3 = -1;  // -seed-ext a,b: letters of the seed-extension tables (default: chosen from the index's size)
+  int window_records = -1;   // -window-records L: the index's window records serve reads of up to L bases (0 = none; default: the
+                             // longest of the input's first reads -- abm_index_set_window_records)
   bool skip_long = false;     // -skip-long: reads the library reports as beyond its supported length are written unmapped
                               // (and counted in the warning) instead of failing the run
   bool host_ceiling = false;  // -host-ceiling / -virtual-gpus N (diagnostic): no device and no mapping call; every "GPU" hands
@@ -898,6 +900,7 @@ Options parse_map(int argc, char **argv) {
     }
     else if (k == "out-parts") o.out_parts = std::stoi(need(i));
     else if (k == "skip-long") o.skip_long = true;
+    else if (k == "window-records") o.window_records = std::max(0, std::stoi(need(i)));
     else if (k == "seed-ext") { const std::string v = need(i); if (std::sscanf(v.c_str(), "%d,%d", &o.ext2, &o.ext3) != 2) throw std::runtime_error("-seed-ext wants two numbers: a,b"); }
     else if (k == "timing") o.timing = need(i);  // JSON: reads, seconds (first batch submitted -> last byte written), stage busy times
     else if (k == "z" || k == "bam-level") g_bgzf_level = std::max(0, std::min(9, std::stoi(need(i))));
@@ -1200,6 +1203,25 @@ int cmd_map(int argc, char **argv) {
     // (pairs: 6 + 3 letters at most -- as fast as 7 + 4 for the pair kernels, 54 GB less of device memory at hg38 scale)
     if (opt.ext2 < 0 && paired && abm_index_set_seed_extension_cap(ix, 6, 3) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
+    {
+      // window records for reads as long as the input's: the longest of each file's first 256 (a batch with a longer read
+      // than the records serve is filtered from the bit planes, as without them)
+      int want = opt.window_records;
+      if (want < 0) {
+        want = 0;
+        for (const std::string &path : opt.reads)
+          if (gzFile zf = gzopen(path.c_str(), "rb")) {
+            std::vector<char> line(1 << 20);
+            for (int rec = 0; rec < 256; ++rec) {
+              if (!gzgets(zf, line.data(), static_cast<int>(line.size())) || !gzgets(zf, line.data(), static_cast<int>(line.size()))) break;
+              want = std::max<int>(want, static_cast<int>(std::strcspn(line.data(), "\r\n")));
+              if (!gzgets(zf, line.data(), static_cast<int>(line.size())) || !gzgets(zf, line.data(), static_cast<int>(line.size()))) break;
+            }
+            gzclose(zf);
+          }
+      }
+      if (abm_index_set_window_records(ix, want) != 0) die_abm("window records");
+    }
     const int visible = abm_device_count();
     if (visible <= 0) { std::cerr << "creating GPU context: no HIP device present (the mapping path has no CPU fallback)\n"; return EXIT_FAILURE; }
     if (n_gpus <= 0) n_gpus = visible;  // all that are visible

@@ -66,7 +66,7 @@ struct PairBest {
 // PHASE: kWhole = seeding and mating in one kernel (tier 2's whole-pair launch, the long-end launch; BIG = false is the
 // unsplit tier 1 of rounds 1-4, kept for same-box comparisons), kSeed / kMate = the two halves of the split
 enum : int { kWhole = 0, kSeed = 1, kMate = 2 };
-template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeWave {
+template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole, bool REC = false> struct PeWave {
   const PeArgs &a;
   WaveLds lds;      // qpk/qbits point at end 0; end 1 follows at +4W / +4WB
   PeLds pl;
@@ -119,10 +119,10 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
     P.begin_read(len_of(end));
     if (len_of(end) >= a.ix.min_len) {
       P.cutoff = P.good_cutoff;  // set_specific
-      seed_pass<true, TIMED, COOP, false>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
+      seed_pass<true, TIMED, COOP, REC>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       if (!P.overflow && P.wants_sensitive()) {
         P.set_sensitive();
-        seed_pass<false, TIMED, COOP, false>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
+        seed_pass<false, TIMED, COOP, REC>(a.ix, w, enc, g_to_a, flags, len_of(end), P, wt, seg_epoch);
       }
     }
     need_big |= P.overflow;
@@ -676,14 +676,16 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole> struct PeW
   }
 };
 
-template <bool BIG, bool TIMED, bool COOP, int WPS, bool LONG = false, int PHASE = kWhole>
+// REC: the seed passes filter on the window records (DevIndex::wrec) -- a launch none of whose ends is longer than they serve
+template <bool BIG, bool TIMED, bool COOP, int WPS, bool LONG = false, int PHASE = kWhole, bool REC = false>
 __global__ __launch_bounds__(64, WPS) void map_pe_kernel(PeArgs a) {
+  static_assert(!REC || (COOP && PHASE != kMate), "window records feed the cooperative filter of the seed passes");
   static_assert(!LONG || (BIG && !COOP && !TIMED && PHASE == kWhole), "the long-end launch: tier 2's lists, nibble filter, no stamps");
   static_assert(PHASE != kSeed || !BIG, "the seed kernel keeps its lists in LDS (and its staging area)");
   static_assert(PHASE != kMate || !COOP, "the mate kernels fetch no candidate windows");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  PeWave<BIG, COOP, LONG, PHASE> w{a};
+  PeWave<BIG, COOP, LONG, PHASE, REC> w{a};
   WaveLds &lds = w.lds;
   lds.W = a.W; lds.WB = a.WB; lds.GW = a.GW;
   u32 *after_heap;
@@ -1046,10 +1048,19 @@ int pe_resident_waves(size_t lds, bool big, int wps) {
   return per_cu * prop.multiProcessorCount;
 }
 
+static bool pe_records(const PeArgs &a) { return a.G == 4 && a.ix.wrec != nullptr && a.max_len <= a.ix.wrec_max_len; }
 template <bool BIG, bool TIMED>
 static void launch_pe_variant(const PeArgs &a, size_t lds, u32 grid, int wps, hipStream_t st) {
-  // a.G != 0: the filter reads the genome's bit planes (cooperative window loads)
-  if (a.G != 0) {
+  // a.G != 0: the filter reads the genome's bit planes (cooperative window loads) -- or, for ends the window records serve, those
+  if (BIG && pe_records(a)) {
+    if constexpr (BIG) {
+      if constexpr (!TIMED) {
+        if (wps == 3) { hipLaunchKernelGGL((map_pe_kernel<true, false, true, 3, false, kWhole, true>), dim3(grid), dim3(64), lds, st, a); return; }
+      }
+      hipLaunchKernelGGL((map_pe_kernel<true, TIMED, true, ABM_PE_WAVES_PER_SIMD, false, kWhole, true>), dim3(grid), dim3(64), lds, st, a);
+    }
+  }
+  else if (a.G != 0) {
     if constexpr (!TIMED) {
       if (wps == 3) { hipLaunchKernelGGL((map_pe_kernel<BIG, false, true, 3>), dim3(grid), dim3(64), lds, st, a); return; }
     }
@@ -1153,7 +1164,11 @@ int pe_mate_resident_waves(size_t lds, bool big) {
 }
 hipError_t launch_pe_seed(const PeArgs &a, size_t lds, u32 grid, bool timed, hipStream_t st) {
   if (grid == 0) return hipSuccess;
-  if (a.G != 0) {
+  if (pe_records(a)) {
+    if (timed) hipLaunchKernelGGL((map_pe_kernel<false, true, true, kPeSeedWps, false, kSeed, true>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((map_pe_kernel<false, false, true, kPeSeedWps, false, kSeed, true>), dim3(grid), dim3(64), lds, st, a);
+  }
+  else if (a.G != 0) {
     if (timed) hipLaunchKernelGGL((map_pe_kernel<false, true, true, kPeSeedWps, false, kSeed>), dim3(grid), dim3(64), lds, st, a);
     else hipLaunchKernelGGL((map_pe_kernel<false, false, true, kPeSeedWps, false, kSeed>), dim3(grid), dim3(64), lds, st, a);
   }

@@ -943,6 +943,9 @@ def main():
                     help="reads of the e2e FASTQ's prefix that also run as gzip-compressed input (0 = skip)")
     ap.add_argument("--seed-ext", default=os.environ.get("ABM_BENCH_SEED_EXT", ""),
                     help="letters of the seed-extension tables as 'a,b' (default: the library's choice from the index's size)")
+    ap.add_argument("--window-records", type=int, default=int(os.environ.get("ABM_BENCH_WINDOW_RECORDS", -1)),
+                    help="read length the index's window records are built for (abm_index_set_window_records); 0 = none, "
+                         "-1 = this run's read length, as `abismal-amd map` takes it from its input")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the embedded runs of BASELINE configs 3 (paired-end 2 x 150) and 5 (150 bp random PBAT) at N=1")
     ap.add_argument("--dist-dry-run", action="store_true",
@@ -1013,7 +1016,8 @@ def main():
     ext_arg = None
     if args.seed_ext:
         ext_arg = tuple(int(x) for x in args.seed_ext.split(","))
-    index = A.Index(idx, seed_extension=ext_arg)
+    wrec_for = args.window_records if args.window_records >= 0 else args.read_len
+    index = A.Index(idx, seed_extension=ext_arg, window_records=wrec_for)
     if args.pe and ext_arg is None:
         index.set_seed_extension_cap(6, 3)  # (as `abismal-amd map` does for pairs: as fast as 7 + 4 for the pair kernels, 54 GB less)
     ctx = A.Context(index, local_rank)
@@ -1022,9 +1026,11 @@ def main():
     t_load = time.time() - t0
     index_gb = round(index.device_bytes / 1e9, 2)
     ext = ctx.seed_extension()
-    seed_tables = {"letters_2": ext[0], "letters_3": ext[1], "gb": round(ext[2] / 1e9, 2)}
+    wrec_serves = ctx.window_records()
+    seed_tables = {"letters_2": ext[0], "letters_3": ext[1], "gb": round(ext[2] / 1e9, 2),
+                   "window_records_serve_reads_up_to": wrec_serves}
     log(f"index loaded + uploaded to HBM in {t_load:.1f}s ({index.device_bytes / 1e9:.2f} GB resident; "
-        f"seed-extension tables {ext[0]}+{ext[1]} letters, {ext[2] / 1e9:.1f} GB)")
+        f"seed-extension tables {ext[0]}+{ext[1]} letters, {ext[2] / 1e9:.1f} GB; window records for reads up to {wrec_serves} bases)")
 
     names, starts, genome_words = read_index_genome(idx)
     n, L = args.reads, args.read_len

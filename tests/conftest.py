@@ -16,6 +16,10 @@ def pytest_configure(config):
     # bisection-only path pass seed_extension=(0, 0) to Index().
     import abismal_amd.api as api
     api.DEFAULT_SEED_EXTENSION = (2, 1)
+    # Likewise the window records (abm_index_set_window_records): asked for by default, for reads of up to 172 bases, so
+    # that the suite's batches of such reads run the record-fed kernels; tests of the bit-plane filter pass
+    # window_records=0 (tests/test_gpu_window_records.py runs the same reads through both).
+    api.DEFAULT_WINDOW_RECORDS = 172
 
 
 @pytest.fixture(scope="session")

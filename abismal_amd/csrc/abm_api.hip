@@ -298,7 +298,7 @@ void build_wrec(DeviceReplica &rep, const abm_index &ix) {
   HIPCHK(hipMalloc(&rep.wrec_mem, bytes));
   try {
     HIPCHK(hipMemset(rep.wrec_mem, 0, bytes));
-    HIPCHK(abm::build_window_records(rep.dix, rep.plane_blocks, n_idx, blocks, static_cast<abm::u64 *>(rep.wrec_mem), nullptr));
+    HIPCHK(abm::build_window_records(rep.dix, rep.plane_blocks, h.chrom_starts.empty() ? 0 : h.chrom_starts.back(), n_idx, blocks, static_cast<abm::u64 *>(rep.wrec_mem), nullptr));
     HIPCHK(hipDeviceSynchronize());
   }
   catch (...) { free_wrec(rep); throw; }

@@ -181,6 +181,7 @@ hipError_t build_ext_table(const DevIndex &ix, int mode, u32 extra, u32 maxc, u6
 // of the genome's bit planes.  Bases before the genome's first (never reached: the index leaves the padding out) read
 // as code 0, like the planes' own guard blocks past the end.
 __global__ __launch_bounds__(256) void window_records_kernel(const u64 *__restrict__ planes0, u64 n_plane_blocks,
+                                                             const u64 *__restrict__ genome, u64 n_bases,
                                                              const u32 *__restrict__ index, u64 n_entries, u64 first_record,
                                                              u32 blocks, u32 back, u64 *__restrict__ out) {
   const u64 t = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -195,6 +196,25 @@ __global__ __launch_bounds__(256) void window_records_kernel(const u64 *__restri
   const u32 s = static_cast<u32>(bit & 63);
   u64 lo = plane(k, 0) >> s, hi = plane(k, 1) >> s;
   if (s) { lo |= plane(k + 1, 0) << (64 - s); hi |= plane(k + 1, 1) << (64 - s); }
+  if (b == blocks - 1) {
+    // the record's spare base (its last: 2 max_len - key weight = 64 blocks - 1 bases are ever looked at) says whether
+    // the stretch holds a blank nibble, which two bits cannot express: the narrowing probes ask (record_nibble)
+    lo &= ~(1ull << 63); hi &= ~(1ull << 63);
+    const long long first = static_cast<long long>(index[e]) - static_cast<long long>(back), end = first + 64ll * blocks - 1;
+    bool blank = false;
+    for (long long q = first < 0 ? 0 : first; q < end && !blank; ) {
+      if (static_cast<u64>(q) >= n_bases) { blank = true; break; }  // (past the genome: padding, blank as well)
+      const u64 w = genome[q >> 4];
+      const u32 from = static_cast<u32>(q & 15), upto = static_cast<u32>(end - q < 16 - from ? from + (end - q) : 16);
+      const u64 ones = (w | (w >> 1) | (w >> 2) | (w >> 3)) & 0x1111111111111111ull;
+      u64 part = 0x1111111111111111ull;
+      if (upto < 16) part &= (1ull << (4 * upto)) - 1;
+      part &= ~((1ull << (4 * from)) - 1);
+      if ((~ones & part) != 0) blank = true;
+      q += upto - from;
+    }
+    if (blank) lo |= 1ull << 63;
+  }
   u64 *o = out + 2 * ((first_record + e) * blocks + b);
   o[0] = lo; o[1] = hi;
 }
@@ -206,7 +226,7 @@ u32 window_record_blocks_for(u32 max_len) {
   return b;
 }
 size_t window_record_bytes(u64 n_entries, u32 blocks) { return (n_entries * blocks + 2) * 16 + 256; }
-hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, const u64 n_idx[3], u32 blocks, u64 *out, hipStream_t st) {
+hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, u64 n_bases, const u64 n_idx[3], u32 blocks, u64 *out, hipStream_t st) {
   const u32 back = window_record_max_len(blocks) - kKeyWeight;
   const u32 *arrays[3] = {ix.index, ix.index_t, ix.index_a};
   u64 first = 0;
@@ -214,7 +234,7 @@ hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, const u6
     const u64 threads = n_idx[m] * blocks;
     if (threads)
       hipLaunchKernelGGL(window_records_kernel, dim3(static_cast<u32>((threads + 255) / 256)), dim3(256), 0, st, ix.planes[0], n_plane_blocks,
-                         arrays[m], n_idx[m], first, blocks, back, out);
+                         ix.genome, n_bases, arrays[m], n_idx[m], first, blocks, back, out);
     first += n_idx[m];
   }
   return hipGetLastError();

@@ -175,7 +175,7 @@ hipError_t build_ext_table(const DevIndex &ix, int mode, u32 extra, u32 maxc, u6
 u32 window_record_max_len(u32 blocks);
 u32 window_record_blocks_for(u32 max_len);
 size_t window_record_bytes(u64 n_entries, u32 blocks);
-hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, const u64 n_idx[3], u32 blocks, u64 *out, hipStream_t st);
+hipError_t build_window_records(const DevIndex &ix, u64 n_plane_blocks, u64 n_bases, const u64 n_idx[3], u32 blocks, u64 *out, hipStream_t st);
 // bit-plane copies of the genome for the Hamming filter (DevIndex::planes): n_blocks blocks of 64 bases each,
 // from the first n_words words of nibbles; blank nibbles (N) mark their surroundings in nmap (DevIndex::nmap,
 // zeroed by the caller); *bad is set if a nibble below n_bases has two or more bits

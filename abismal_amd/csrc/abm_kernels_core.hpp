@@ -260,9 +260,27 @@ __device__ __forceinline__ u32 genome_sortsym3(const DevIndex &ix, u64 q, bool g
 // 2-letter chain come from its bit string qb (n_bits of it; 1 beyond): the loop ends at p == limit, and for reads
 // of 44-46 bases limit = L - i is BELOW the starting length for the last offsets, so the reference keeps extending
 // past the end of the read, through whatever its reused buffer holds there (the ghost bits put into qb: ghost_bits).
+//
+// REC: the letters come from the window records (DevIndex::wrec): entry k's record holds the genome from wrec_back bases
+// before the entry's position, so the letter p bases after it is bit wrec_back + p of record k -- ONE load that does not
+// wait for the index entry, where the nibble array takes two in a row (the entry, then the letter behind it).  Two bits
+// cannot say N: the record's one spare base (its last; the filter never reaches it) says whether the record's stretch
+// holds a blank nibble, and such a probe -- like one beyond the record's reach, which only a read of 44-46 bases
+// extending past its end can ask for -- goes the old way.
+__device__ __forceinline__ u32 record_nibble(const DevIndex &ix, const u32 *__restrict__ tbl, u32 rec0, bool live, u32 k, u32 p) {
+  const u32 at = ix.wrec_back + p, last = ix.wrec_blocks * 64u - 1u;
+  const bool in_reach = at < last;
+  const u64 *r = ix.wrec + 2ull * (live ? static_cast<u64>(k + rec0) * ix.wrec_blocks : 0ull);
+  const u32 blk = in_reach ? at >> 6 : 0u;
+  const u64 lo = r[2 * blk], hi = r[2 * blk + 1], flag = r[2 * (ix.wrec_blocks - 1)];
+  u32 nib = 1u << ((static_cast<u32>(lo >> (at & 63u)) & 1u) | ((static_cast<u32>(hi >> (at & 63u)) & 1u) << 1));
+  if (live && (!in_reach || (flag >> 63))) nib = gnib(ix.genome, static_cast<u64>(tbl[k]) + p);
+  return nib;
+}
+template <bool REC = false>
 __device__ __forceinline__ void narrow_both(const DevIndex &ix, const u32 *__restrict__ tbl3, bool g_to_a, const u64 *qb,
                                             u32 n_bits, const u64 *qpk, u32 qbase, u32 limit, u32 maxc, bool run2, u32 &lo2,
-                                            u32 &hi2, u32 &len2, bool run3, u32 &lo3, u32 &hi3, u32 &len3, u32 &probes) {
+                                            u32 &hi2, u32 &len2, bool run3, u32 &lo3, u32 &hi3, u32 &len3, u32 &probes, u32 rec3 = 0) {
   // (len2 / len3 on entry: the letters each range has been narrowed by already -- the key weights, or more where the
   // seed-extension tables have taken the first steps; run2 / run3 false: the table has finished that chain, nothing
   // is done to its range)
@@ -282,10 +300,18 @@ __device__ __forceinline__ void narrow_both(const DevIndex &ix, const u32 *__res
     const int hA = bnA >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     const u32 kA = blA + static_cast<u32>(hA), m1 = l1 + static_cast<u32>(h1), m2 = l2 + static_cast<u32>(h2);
     const bool dA = actA, d1 = actB && n1 > 0, d2 = actB && n2 > 0 && !(d1 && m2 == m1);
-    const u32 eA = tbl2[dA ? kA : 0u], e1 = tbl3[d1 ? m1 : 0u], e2 = tbl3[d2 ? m2 : 0u];
-    const u32 sA = genome_bit2(ix, static_cast<u64>(eA) + pA);
-    const u32 s1 = genome_sortsym3(ix, static_cast<u64>(e1) + pB, g_to_a);
-    u32 s2 = genome_sortsym3(ix, static_cast<u64>(e2) + pB, g_to_a);
+    u32 sA, s1, s2;
+    if constexpr (REC) {
+      sA = bit2(record_nibble(ix, tbl2, 0u, dA, kA, pA));
+      s1 = sortsym3(record_nibble(ix, tbl3, rec3, d1, m1, pB), g_to_a);
+      s2 = sortsym3(record_nibble(ix, tbl3, rec3, d2, m2, pB), g_to_a);
+    }
+    else {
+      const u32 eA = tbl2[dA ? kA : 0u], e1 = tbl3[d1 ? m1 : 0u], e2 = tbl3[d2 ? m2 : 0u];
+      sA = genome_bit2(ix, static_cast<u64>(eA) + pA);
+      s1 = genome_sortsym3(ix, static_cast<u64>(e1) + pB, g_to_a);
+      s2 = genome_sortsym3(ix, static_cast<u64>(e2) + pB, g_to_a);
+    }
     probes += (dA ? 1u : 0u) + (d1 ? 1u : 0u) + (d2 ? 1u : 0u);
     if (actA) {  // one step of first_not (std::lower_bound's probe sequence), then find_candidates' update
       if (sA < 1u) { blA = kA + 1; bnA -= hA + 1; } else bnA = hA;
@@ -929,7 +955,10 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
             }
           }
         }
-        narrow_both(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, run2, lo2, hi2, len2, run3, lo3, hi3, len3, probes);
+        // (letters from the window records in the pair kernels only: the single-end kernel, short of registers, is 6 %
+        // slower with them -- 527 -> 558 ms per 10 M reads -- where the pair kernels' seed passes gain 1.5 %;
+        // profiles/r05_exp_record_probes.log)
+        narrow_both<REC && Set::kAppend>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, run2, lo2, hi2, len2, run3, lo3, hi3, len3, probes, rec3);
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
         chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;
         if (TALLY) wt.probes += probes;

@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 5, call 13: narrowing probes fed from the window records -- single-end parity tests, then this build against the
+# one before it on one box (single-end kernel, 10 M reads x 100 bp) and the pair kernels (1 M pairs 2x150)
+set -u
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_window_records.py tests/test_gpu_se_parity.py tests/test_gpu_seed_extension.py tests/test_gpu_scale_parity.py tests/test_gpu_edges_and_properties.py tests/test_gpu_params.py -x -q 2>&1 | tail -8 > gpurun_out/r05_call13_tests.log
+cat gpurun_out/r05_call13_tests.log
+OUT=gpurun_out/r05_exp_record_probes.log VARIANTS="prev tree" REPS=2 scripts/r05_lib_ab.sh
+export ABM_BENCH_GENOME_MBP=3100
+for rep in 1 2; do
+  for v in prev tree; do
+    unset ABISMAL_AMD_LIB
+    [ "$v" != tree ] && export ABISMAL_AMD_LIB=$(pwd)/abismal_amd/_ab/libabismal_amd_$v.so
+    python bench.py --pe --reads 1000000 --read-len 150 --steps 16 --warmup 16 --no-e2e --no-cpu-baseline 2> /dev/null | tail -1 > gpurun_out/r05_pe_ab.json
+    python3 - "$v" "$rep" gpurun_out/r05_pe_ab.json <<'PY' | tee -a gpurun_out/r05_exp_record_probes.log
+import json, sys
+f, rep, path = sys.argv[1:4]
+try:
+    d = json.load(open(path)); r = d["roofline"]
+    print("pairs, build %-5s rep %s  %.3f M reads/s  %.1f ms/step  alone %s" % (f, rep, d["value"] / 1e6, d["ms_per_step"], (d.get("phase_stamps") or {}).get("kernel_ms")))
+except Exception as e:
+    print("pairs, build", f, "rep", rep, "FAILED", e)
+PY
+  done
+done

@@ -24,7 +24,9 @@ __device__ __host__ inline int draw(unsigned seq, unsigned idx, int shape) {
 }
 constexpr int kShapes = 4;
 
-__global__ __launch_bounds__(64) void run(int n_chunks, u32 *heaps, u32 *poss, i16 *lds_, int *meta) {
+__global__ __launch_bounds__(64) void run(int n_chunks, u32 *heaps, u32 *poss, i16 *lds_, int *meta, long long *cycles) {
+  const long long t_begin = clock64();
+  int n_admits = 0;
   PeSet S;
   S.heap = heaps + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
   S.lpos = poss + static_cast<size_t>(blockIdx.x) * kPeCapLarge;
@@ -46,21 +48,24 @@ __global__ __launch_bounds__(64) void run(int n_chunks, u32 *heaps, u32 *poss, i
       const int l = __builtin_ctzll(todo);
       const int before = S.cutoff;
       S.admit(true, rdlane(h, l), 0u, rdlane(p, l));
+      ++n_admits;
       todo &= ~(((1ull << l) << 1) - 1);
       if (S.cutoff < before) todo &= __ballot(h <= S.cutoff);
     }
   }
   wave_sync();
   if (!S.heaped) S.heapify();
+  if (threadIdx.x == 0) { cycles[2 * blockIdx.x] = clock64() - t_begin; cycles[2 * blockIdx.x + 1] = n_admits; }
   if (threadIdx.x == 0) { meta[4 * blockIdx.x] = S.sz; meta[4 * blockIdx.x + 1] = S.cutoff; meta[4 * blockIdx.x + 2] = n_runs; meta[4 * blockIdx.x + 3] = S.capacity; }
 }
 
 int main() {
   const int blocks = 12, chunks = 1100, n = chunks * 64;
-  u32 *dh, *dp; i16 *dl; int *dm;
+  u32 *dh, *dp; i16 *dl; int *dm; long long *dc;
+  (void)hipMalloc(&dc, blocks * 16);
   (void)hipMalloc(&dh, sizeof(u32) * blocks * kPeCapLarge); (void)hipMalloc(&dp, sizeof(u32) * blocks * kPeCapLarge);
   (void)hipMalloc(&dl, sizeof(i16) * blocks * kPeCapLarge); (void)hipMalloc(&dm, blocks * 16);
-  hipLaunchKernelGGL(run, dim3(blocks), dim3(64), 0, 0, chunks, dh, dp, dl, dm);
+  hipLaunchKernelGGL(run, dim3(blocks), dim3(64), 0, 0, chunks, dh, dp, dl, dm, dc);
   if (hipDeviceSynchronize() != hipSuccess) { printf("FAIL launch\n"); return 1; }
   std::vector<u32> hh(static_cast<size_t>(blocks) * kPeCapLarge), hp(hh.size()); std::vector<int> hm(blocks * 4);
   (void)hipMemcpy(hh.data(), dh, hh.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(hp.data(), dp, hp.size() * 4, hipMemcpyDeviceToHost);
@@ -97,5 +102,9 @@ int main() {
     }
   }
   printf("OK %d sequences of %d candidates (%lld runs of ties applied at once)\n", blocks, n, runs);
+  std::vector<long long> hc(blocks * 2);
+  (void)hipMemcpy(hc.data(), dc, hc.size() * 8, hipMemcpyDeviceToHost);
+  for (int b = 0; b < blocks; ++b)  // (each sequence on a wave of its own: what a lone wave pays per update)
+    printf("   sequence %d (shape %d): %lld cycles, %lld single updates, %d runs\n", b, b % kShapes, hc[2 * b], hc[2 * b + 1], hm[4 * b + 2]);
   return 0;
 }

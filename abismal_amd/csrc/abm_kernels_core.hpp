@@ -614,15 +614,9 @@ __device__ __forceinline__ void build_qmasks(const WaveLds &lds, u32 L) {
 // block arrive by DPP from the next lane.  mismatches = 64 - popcount(the mask of the code each genome base has).
 // Identical to full_compare's sum over whole words for a one-hot genome (src/abismal.cpp:1093-1122; the early exit
 // there changes a distance only when the hit is rejected anyway).
-//
-// REC: the windows come from the window records (DevIndex::wrec) instead: pos_a / pos_b are then the candidates' record
-// starts (record number x blocks per record, in 16-byte blocks) and x_a / x_b the bit of the record their window begins
-// at (wrec_back - seed offset).  The blocks a group loads past its candidate's record (at most one: see wrec_max_len)
-// only reach read positions past the end of the read, whose masks admit every code.
-template <u32 kRounds = kCoopRounds, bool REC = false>
+template <u32 kRounds = kCoopRounds>
 __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
-                                               u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b,
-                                               u32 x_a = 0, u32 x_b = 0) {
+                                               u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
   const int lane = lane_id();
   const u32 G = lds.G, sub = lane & (G - 1), grp = lane / G, per_round = 64 / G;
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
@@ -644,15 +638,6 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
       const bool second = (pass * kRounds + r) * per_round >= 64;
       const u32 c = slot & 63u;
       const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
-      const u64 *g;
-      if constexpr (REC) {
-        const u32 cx = static_cast<u32>(__shfl(static_cast<int>(second ? x_b : x_a), static_cast<int>(c)));
-        shifts |= static_cast<u64>(cx & 63u) << (8 * r);
-        const u32 b0 = cx / kPlaneBlock, b1 = G == 4 ? b0 + 3 : (cx + L - 1) / kPlaneBlock;
-        const bool act = (((second ? wb : wa) >> c) & 1ull) && b0 + sub <= b1;
-        g = act ? ix.wrec + 2 * (static_cast<u64>(cp) + b0 + sub) : ix.wrec;
-      }
-      else {
       shifts |= static_cast<u64>(cp & 63u) << (8 * r);
       // (a group of four always fetches four blocks, 64 contiguous bytes: the memory pipeline merges the loads of a
       // full quad of lanes into one request, and those of a partly active quad not at all -- measured, 2.5 requests per
@@ -663,9 +648,8 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
       // divergent branch is waited for inside it): a lane with nothing to fetch reads the array's first line.
       // What it gets is never looked at -- its bits could only reach read positions past the end, whose masks
       // admit every code, or candidates whose result is discarded.
-      g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
-              : ix.planes[0];
-      }
+      const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+                         : ix.planes[0];
       xl[r] = g[0];
       xh[r] = g[1];
     }
@@ -695,10 +679,8 @@ __device__ __forceinline__ void hamming_planes(const DevIndex &ix, const WaveLds
 // counting 64 read bases against them -- no exchange between the lanes, and 32 candidates per round instead of 16:
 // the kernel is bound by vector-instruction issue once its windows are single lines (76 % of the SIMDs' cycles),
 // and this halves the filter's instructions per candidate.  One round (32 windows, 8 registers) in flight per pass.
-template <bool REC = false>
 __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const WaveLds &lds, const u64 *qm, u32 L,
-                                                     u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b,
-                                                     u32 x_a = 0, u32 x_b = 0) {
+                                                     u32 pos_a, bool want_a, u32 pos_b, bool want_b, int &d_a, int &d_b) {
   const int lane = lane_id();
   const u32 sub = lane & 1u, grp = lane >> 1;
   const u64 wa = __ballot(want_a), wb = __ballot(want_b);
@@ -713,21 +695,12 @@ __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const W
     if (static_cast<u32>((second ? wb : wa) >> ((pass & 1u) * 32u)) == 0u) continue;
     const u32 c = slot & 63u;
     const u32 cp = static_cast<u32>(__shfl(static_cast<int>(second ? pos_b : pos_a), static_cast<int>(c)));
+    const u32 sh = cp & 63u;
+    const u32 b0 = cp / kPlaneBlock, b1 = b0 + 2;  // a window of up to 128 bases has at most three blocks
     const bool act = ((second ? wb : wa) >> c) & 1ull;
-    u32 sh;
-    const u64 *g;
-    if constexpr (REC) {  // (see hamming_planes)
-      const u32 cx = static_cast<u32>(__shfl(static_cast<int>(second ? x_b : x_a), static_cast<int>(c)));
-      sh = cx & 63u;
-      g = act ? ix.wrec + 2 * (static_cast<u64>(cp) + cx / kPlaneBlock + sub) : ix.wrec;
-    }
-    else {
-      sh = cp & 63u;
-      const u32 b0 = cp / kPlaneBlock, b1 = b0 + 2;  // a window of up to 128 bases has at most three blocks
-      // (unconditional loads, as in hamming_planes: a lane with nothing to fetch reads the array's first line)
-      g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
-              : ix.planes[0];
-    }
+    // (unconditional loads, as in hamming_planes: a lane with nothing to fetch reads the array's first line)
+    const u64 *g = act ? ix.planes[(b0 / kPlaneLineBlocks) != (b1 / kPlaneLineBlocks) ? 1 : 0] + 2 * static_cast<u64>(b0 + sub)
+                       : ix.planes[0];
     const u64 xl = g[0], xh = g[1], nl = g[2], nh = g[3];
     const u64 gl = (xl >> sh) | ((nl << (63 - sh)) << 1), gh = (xh >> sh) | ((nh << (63 - sh)) << 1);
     const u64 match = (~gh & ((~gl & m0) | (gl & m1))) | (gh & ((~gl & m2) | (gl & m3)));
@@ -741,39 +714,59 @@ __device__ __forceinline__ void hamming_planes_pairs(const DevIndex &ix, const W
   wave_sync();
 }
 
-// Window records, reads of up to 128 bases: ONE lane per candidate.  A record is three or four blocks laid end to end, so
-// a lane takes its own candidate's window with three 16-byte loads of consecutive addresses (the lanes of a segment read
-// consecutive records) and compares both 64-base halves of the read itself: no shuffles to hand candidates to groups of
-// lanes, no sums through LDS, 64 windows in flight per half step instead of 32 -- 0.7 vector instructions per candidate
-// against 1.4 for the two-lane groups, which the bit planes need because a window there is a random gather that only a
-// group's single load fetches in one request.  a / b: the lane's first and (if `two`) second candidate of the step.
+// Window records: ONE lane per candidate.  A record is a few blocks laid end to end, so a lane takes its own candidate's
+// window with three (reads up to 128 bases) or four (up to 192) 16-byte loads of consecutive addresses -- the lanes of a
+// segment read consecutive records -- and compares the read's 64-base blocks itself: no shuffles to hand candidates to
+// groups of lanes, no sums through LDS, 64 windows in flight per half step instead of 32 or 16 -- 0.7 vector instructions
+// per candidate of a 100-base read against 1.4 for the two-lane groups, 1 against 2.8 for the four-lane groups of a
+// 150-base read.  (The bit planes need the groups: a window there is a random gather, which only a group's single load
+// fetches in one request.)  a / b: the lane's first and (if `two`) second candidate of the step.  The blocks a lane loads
+// past its candidate's record (at most one) only reach read positions past the end of the read, whose masks admit every code.
+template <bool WIDE>
 __device__ __forceinline__ void hamming_records_lane(const DevIndex &ix, const u64 *qm, u32 L, u32 rec_a, u32 x_a, bool want_a,
                                                      u32 rec_b, u32 x_b, bool want_b, bool two, int &d_a, int &d_b) {
-  const u64 *ra = ix.wrec + (want_a ? 2 * (static_cast<u64>(rec_a) + x_a / kPlaneBlock) : 0ull);
-  const u64 a0l = ra[0], a0h = ra[1], a1l = ra[2], a1h = ra[3], a2l = ra[4], a2h = ra[5];
-  u64 b0l = 0, b0h = 0, b1l = 0, b1h = 0, b2l = 0, b2h = 0;
-  if (two) {
-    const u64 *rb = ix.wrec + (want_b ? 2 * (static_cast<u64>(rec_b) + x_b / kPlaneBlock) : 0ull);
-    b0l = rb[0]; b0h = rb[1]; b1l = rb[2]; b1h = rb[3]; b2l = rb[4]; b2h = rb[5];
-  }
-  const bool wide = L > kPlaneBlock;  // (uniform: the read has a second block of masks)
   auto funnel = [](u64 lo, u64 hi, u32 sh) { return (lo >> sh) | ((hi << (63 - sh)) << 1); };
   auto mismatches = [&](u64 gl, u64 gh, const u64 *q) {
     const u64 match = (~gh & ((~gl & q[0]) | (gl & q[1]))) | (gh & ((~gl & q[2]) | (gl & q[3])));
     return 64 - __popcll(match);
   };
-  {
-    const u32 sh = x_a & 63u;
-    int d = mismatches(funnel(a0l, a1l, sh), funnel(a0h, a1h, sh), qm);
-    if (wide) d += mismatches(funnel(a1l, a2l, sh), funnel(a1h, a2h, sh), qm + 4);
-    d_a = d;
+  if constexpr (!WIDE) {
+    // both candidates' loads first: six registers each
+    const u64 *ra = ix.wrec + (want_a ? 2 * (static_cast<u64>(rec_a) + x_a / kPlaneBlock) : 0ull);
+    const u64 a0l = ra[0], a0h = ra[1], a1l = ra[2], a1h = ra[3], a2l = ra[4], a2h = ra[5];
+    u64 b0l = 0, b0h = 0, b1l = 0, b1h = 0, b2l = 0, b2h = 0;
+    if (two) {
+      const u64 *rb = ix.wrec + (want_b ? 2 * (static_cast<u64>(rec_b) + x_b / kPlaneBlock) : 0ull);
+      b0l = rb[0]; b0h = rb[1]; b1l = rb[2]; b1h = rb[3]; b2l = rb[4]; b2h = rb[5];
+    }
+    const bool wide = L > kPlaneBlock;  // (uniform: the read has a second block of masks)
+    {
+      const u32 sh = x_a & 63u;
+      int d = mismatches(funnel(a0l, a1l, sh), funnel(a0h, a1h, sh), qm);
+      if (wide) d += mismatches(funnel(a1l, a2l, sh), funnel(a1h, a2h, sh), qm + 4);
+      d_a = d;
+    }
+    d_b = 0x7fff;
+    if (two) {
+      const u32 sh = x_b & 63u;
+      int d = mismatches(funnel(b0l, b1l, sh), funnel(b0h, b1h, sh), qm);
+      if (wide) d += mismatches(funnel(b1l, b2l, sh), funnel(b1h, b2h, sh), qm + 4);
+      d_b = d;
+    }
   }
-  d_b = 0x7fff;
-  if (two) {
-    const u32 sh = x_b & 63u;
-    int d = mismatches(funnel(b0l, b1l, sh), funnel(b0h, b1h, sh), qm);
-    if (wide) d += mismatches(funnel(b1l, b2l, sh), funnel(b1h, b2h, sh), qm + 4);
-    d_b = d;
+  else {
+    // up to three blocks of read: four blocks of record, one candidate after the other (eight registers of window)
+    auto one = [&](u32 rec, u32 x, bool want) {
+      const u64 *r = ix.wrec + (want ? 2 * (static_cast<u64>(rec) + x / kPlaneBlock) : 0ull);
+      const u64 l0 = r[0], h0 = r[1], l1 = r[2], h1 = r[3], l2 = r[4], h2 = r[5], l3 = r[6], h3 = r[7];
+      const u32 sh = x & 63u;
+      int d = mismatches(funnel(l0, l1, sh), funnel(h0, h1, sh), qm);
+      if (L > kPlaneBlock) d += mismatches(funnel(l1, l2, sh), funnel(h1, h2, sh), qm + 4);
+      if (L > 2 * kPlaneBlock) d += mismatches(funnel(l2, l3, sh), funnel(h2, h3, sh), qm + 8);
+      return d;
+    };
+    d_a = one(rec_a, x_a, want_a);
+    d_b = two ? one(rec_b, x_b, want_b) : 0x7fff;
   }
 }
 
@@ -1083,9 +1076,9 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         const u32 ra = (ea + ((sa & 1u) ? rec3 : 0u)) * ix.wrec_blocks, rb = (eb + ((sb & 1u) ? rec3 : 0u)) * ix.wrec_blocks;
         int ha, hb = 0x7fff;
         if (lds.G == 2)
-          hamming_records_lane(ix, lds.qmask + enc * lds.MB * 4, L, ra, ix.wrec_back - ia, va, rb, ix.wrec_back - ib, vb, two, ha, hb);
+          hamming_records_lane<false>(ix, lds.qmask + enc * lds.MB * 4, L, ra, ix.wrec_back - ia, va, rb, ix.wrec_back - ib, vb, two, ha, hb);
         else
-          hamming_planes<kCoopRounds, true>(ix, lds, lds.qmask + enc * lds.MB * 4, L, ra, va, rb, vb, ha, hb, ix.wrec_back - ia, ix.wrec_back - ib);
+          hamming_records_lane<true>(ix, lds.qmask + enc * lds.MB * 4, L, ra, ix.wrec_back - ia, va, rb, ix.wrec_back - ib, vb, two, ha, hb);
         // the candidates that may still enter the set: these alone need their position
         const bool ca = va && ha <= S.cutoff, cb = two && vb && hb <= S.cutoff;
         u32 pa = 0, pb = 0;

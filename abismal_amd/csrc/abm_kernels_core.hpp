@@ -857,6 +857,9 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
 // candidates (all checked buckets of 64 offsets flattened in reference order)
 // for the Hamming filter; survivors are replayed in order into the set.
+#ifndef ABM_SE_RECORD_PROBES
+#define ABM_SE_RECORD_PROBES false
+#endif
 #ifndef ABM_HEAVY_BLOCK
 #define ABM_HEAVY_BLOCK 4096
 #endif
@@ -987,7 +990,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
         // (letters from the window records in the pair kernels only: the single-end kernel, short of registers, is 6 %
         // slower with them -- 527 -> 558 ms per 10 M reads -- where the pair kernels' seed passes gain 1.5 %;
         // profiles/r05_exp_record_probes.log)
-        narrow_both<REC && Set::kAppend>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, run2, lo2, hi2, len2, run3, lo3, hi3, len3, probes, rec3);
+        narrow_both<REC && (Set::kAppend || ABM_SE_RECORD_PROBES)>(ix, idx3, g_to_a, qb, 64u * lds.WB, qpk, i, L - i, maxc, run2, lo2, hi2, len2, run3, lo3, hi3, len3, probes, rec3);
         chk2 = (hi2 - lo2) <= maxc || len2 >= spec_len;
         chk3 = (hi3 - lo3) <= maxc || len3 >= spec_len;
         if (TALLY) wt.probes += probes;

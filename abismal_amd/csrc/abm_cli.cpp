@@ -2699,7 +2699,7 @@ int cmd_map(int argc, char **argv) {
     std::ofstream tj(opt.timing);
     tj << "{\"records\": " << total_records << ", \"reads\": " << (paired ? 2 : 1) * total_records << ", \"seconds\": " << secs
        << ", \"index_load_s\": " << index_load_s << ", \"host_prepare_s\": " << host_prepare_s << ", \"gpus\": " << n_gpus << ", \"mappers_per_gpu\": " << per_gpu
-       << ", \"sam_text_by\": \"" << (device_sam ? "device" : "host") << "\", \"host_threads\": " << n_host << ", \"numa_nodes\": " << n_nodes << ", \"pinned\": " << (topo.pinning ? "true" : "false")
+       << ", \"sam_text_by\": \"" << (device_sam ? "device" : "host") << "\", \"window_records_serve_reads_up_to\": " << (ctxs.empty() ? 0u : abm_ctx_window_records(ctxs[0])) << ", \"host_threads\": " << n_host << ", \"numa_nodes\": " << n_nodes << ", \"pinned\": " << (topo.pinning ? "true" : "false")
        << ", \"out_parts\": " << n_regions << ", \"out_bytes\": " << out_bytes << ", \"batches\": " << n_batches << ", \"max_lead_in_records\": " << max_lead << ", \"region_lead_in_scanned_records\": " << region_lead_scanned << ", \"region_lead_in_records\": " << region_lead_records
        << ", \"batch_reads\": " << batch_reads << ", \"host_ceiling\": " << (virtual_gpus ? "true" : "false")
        << ", \"batches_per_gpu\": [";

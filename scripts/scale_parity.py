@@ -13,7 +13,9 @@ wd = "/tmp/abismal_bench"; os.makedirs(wd, exist_ok=True)
 idx = f"{wd}/g{int(mbp)}.idx"
 if not os.path.exists(idx):
     bench.synth_genome_fasta(idx + ".fa", mbp, 1234, dev); A.index_build(idx + ".fa", idx, os.cpu_count())
-index = A.Index(idx); ctx = A.Context(index, 0)
+# (window records for reads of up to 172 bases unless SCALE_PARITY_WINDOW_RECORDS says otherwise: the record-fed kernels)
+index = A.Index(idx, window_records=int(os.environ.get("SCALE_PARITY_WINDOW_RECORDS", 172))); ctx = A.Context(index, 0)
+print("window records serve reads up to", ctx.window_records(), "bases", flush=True)
 _, starts, gw = bench.read_index_genome(idx)
 o = ob.load(); oix = o.index_load(idx)
 threads = os.cpu_count() or 8

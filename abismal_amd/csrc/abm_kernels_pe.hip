@@ -66,6 +66,10 @@ struct PairBest {
 // PHASE: kWhole = seeding and mating in one kernel (tier 2's whole-pair launch, the long-end launch; BIG = false is the
 // unsplit tier 1 of rounds 1-4, kept for same-box comparisons), kSeed / kMate = the two halves of the split
 enum : int { kWhole = 0, kSeed = 1, kMate = 2 };
+#ifndef ABM_PE_RADIX_SORT_MIN
+#define ABM_PE_RADIX_SORT_MIN 512
+#endif
+constexpr int kRadixSortMin = ABM_PE_RADIX_SORT_MIN;  // tier 2: lists longer than this are sorted by radix passes, shorter ones by the bitonic network
 template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole, bool REC = false> struct PeWave {
   const PeArgs &a;
   WaveLds lds;      // qpk/qbits point at end 0; end 1 follows at +4W / +4WB
@@ -219,8 +223,60 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole, bool REC =
     const int lane = lane_id();
     const int n = lsz[which];
     u32 *buf = pl.heap;  // the live heap is dead by now
+    bool sorted = false;
+    if constexpr (BIG) {
+      // Tier 2's long lists: a radix sort by position, four passes of eight bits between the two per-wave tables in
+      // global memory (round 5).  The bitonic network below costs n log2(n)^2 / 128 compare-exchange steps of the wave --
+      // 78 passes over a list of 4096 -- where this costs four: per pass a histogram of the digit in LDS (256 counters
+      // in the place of the window slots, idle here), their prefix sums, and a scatter chunk by chunk in which the lanes
+      // of a chunk that share a digit find their rank among themselves from eight ballots.  Equal positions are equal
+      // entries (the duplicates unique() drops), so the order among them is of no consequence.
+      if (n > kRadixSortMin) {
+        u32 *src = pl.lpos[which], *dst = pl.tmp;
+        u32 *hist = reinterpret_cast<u32 *>(lds.gwin);  // [256] running offsets of the digits
+        for (u32 shift = 0; shift < 32; shift += 8) {
+          for (int b = lane; b < 256; b += 64) hist[b] = 0;
+          wave_sync();
+          for (int i = lane; i < n; i += 64) atomicAdd(&hist[(src[i] >> shift) & 255u], 1u);
+          wave_sync();
+          {  // exclusive prefix sums of the 256 counters: four per lane, then across the lanes
+            const u32 c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+            u32 total;
+            const u32 base = wave_excl_sum(c0 + c1 + c2 + c3, total);
+            wave_sync();
+            hist[4 * lane] = base; hist[4 * lane + 1] = base + c0; hist[4 * lane + 2] = base + c0 + c1; hist[4 * lane + 3] = base + c0 + c1 + c2;
+          }
+          wave_sync();
+          for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool have = i < n;
+            const u32 v = have ? src[i] : 0u, d = (v >> shift) & 255u;
+            u64 same = __ballot(have);
+#pragma unroll
+            for (u32 bit = 0; bit < 8; ++bit) {
+              const u64 ones = __ballot((d >> bit) & 1u);
+              same &= ((d >> bit) & 1u) ? ones : ~ones;
+            }
+            const u32 rank = static_cast<u32>(__popcll(same & ((1ull << lane) - 1)));
+            const u32 at = have ? hist[d] : 0u;
+            wave_sync();  // (every lane has read its digit's offset before the digit's first lane moves it on)
+            if (have) {
+              dst[at + rank] = v;
+              if (rank == 0) hist[d] = at + static_cast<u32>(__popcll(same));
+            }
+            wave_sync();
+          }
+          u32 *t = src; src = dst; dst = t;
+          // (the first pass reads the list itself and writes the scratch table; from then on the heap's table is the other side)
+          if (shift == 0) dst = buf;
+        }
+        // four passes: list -> tmp -> buf -> tmp -> buf
+        sorted = true;
+      }
+    }
     int m = 1;
     while (m < n) m <<= 1;
+    if (!sorted) {
     for (int i = lane; i < m; i += 64) buf[i] = i < n ? ld_list<BIG>(pl.lpos[which] + i) : 0xFFFFFFFFu;
     wave_sync();
     // one compare-exchange pass of the bitonic network at distance j inside stage k, over
@@ -263,6 +319,7 @@ template <bool BIG, bool COOP, bool LONG = false, int PHASE = kWhole, bool REC =
         for (int j = k >> 1; j >= C; j >>= 1) pass(buf, m, 0, k, j);
         local(k, k, C >> 1);
       }
+    }
     }
     // unique + recompute diffs
     const WaveLds w = lds_of(end);

@@ -4,7 +4,7 @@
 set -u
 mkdir -p gpurun_out
 OUT=${OUT:-gpurun_out/r05_exp_lib_ab.log}
-: > $OUT
+[ -n "${APPEND:-}" ] || : > $OUT
 export ABM_BENCH_GENOME_MBP=${ABM_BENCH_GENOME_MBP:-3100}
 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-split --no-e2e --no-other-configs > /dev/null 2>&1   # builds the index once
 for rep in $(seq 1 ${REPS:-2}); do

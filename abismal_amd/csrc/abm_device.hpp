@@ -80,7 +80,7 @@ constexpr u32 kSortDepth = 256;  // letters a bucket is sorted by (src/AbismalIn
 #ifndef ABM_PE_DIRECT_NARROWING
 #define ABM_PE_DIRECT_NARROWING true
 #endif
-// (the single-end kernel does not narrow directly: measured neutral to slower at either register budget)
+// (the single-end kernel: ABM_SE_DIRECT_NARROWING, abm_kernels_core.hpp)
 #ifndef ABM_PE_DIRECT_MIN
 #define ABM_PE_DIRECT_MIN 128  // (2x150 at hg38 scale: 4.20-4.24 M reads/s at 128, 4.01-4.16 at 256, 4.01-4.21 at 64, 3.57-4.03 without; profiles/r03_exp_pe_direct_threshold.log)
 #endif

@@ -857,6 +857,13 @@ __device__ __forceinline__ void ghost_bits(const u64 *__restrict__ packed, const
 // the whole wave.  Lanes are seed offsets while probing/narrowing, then become
 // candidates (all checked buckets of 64 offsets flattened in reference order)
 // for the Hamming filter; survivors are replayed in order into the set.
+#ifndef ABM_SE_DIRECT_NARROWING
+// (the single-end kernel narrows big ranges directly as well -- since the window records: until then it was neutral to
+// slower there at either register budget; with the records the probes had become the largest phase of a
+// 150-base read.  10 M x 100 bp 461-464 -> 438-440 ms, 4 M x 150 bp random PBAT 7.4-7.5 -> 8.3-8.5 M reads/s;
+// profiles/r05_exp_se_direct_narrowing.log)
+#define ABM_SE_DIRECT_NARROWING true
+#endif
 #ifndef ABM_SE_RECORD_PROBES
 #define ABM_SE_RECORD_PROBES false
 #endif
@@ -911,7 +918,7 @@ __device__ __forceinline__ void seed_pass(const DevIndex &ix, const WaveLds &lds
   // lane-resident counters were what the seed kernel spilled in its offset loop)
   constexpr bool TALLY = TIMED;
   // direct narrowing of big ranges: in the pair kernels only (see narrow_direct)
-  constexpr bool kDirect = Set::kAppend ? ABM_PE_DIRECT_NARROWING : false;
+  constexpr bool kDirect = Set::kAppend ? ABM_PE_DIRECT_NARROWING : ABM_SE_DIRECT_NARROWING;
   long long ta = 0, tb_ = 0, tc = 0, td = 0;
   if (SPECIFIC && !REC) {  // a new (strand, alphabet) call: the cache belongs to one encoding
     for (u32 k = lane; k < (1u << kPosCacheBits); k += 64) lds.pcache[k] = 0;

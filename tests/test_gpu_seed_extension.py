@@ -121,3 +121,33 @@ def test_pe_direct_narrowing_any_threshold(oracle, rep, min_entries):
         finally:
             ctx.close()
             ix.close()
+
+
+@pytest.mark.parametrize("min_entries", [0, 16, 64, 100000])
+def test_se_direct_narrowing_any_threshold(oracle, rep, min_entries):
+    """The single-end kernel narrows big ranges directly as well (round 5): whichever ranges it takes that way, with and
+    without seed-extension tables in front, with and without window records behind -- reads of 100 and 150 bases in the
+    T-rich and random-PBAT modes, and at -c 20, equal the oracle's."""
+    import abismal_amd as A
+    from tests import synth
+    fa, idx, oix = rep
+    sets = []
+    for mode, L in ((0, 100), (2, 150), (0, 60)):
+        reads = synth.trim_like_readloader(synth.mutated_reads(fa, 3000, L, seed=31 + L, pbat_frac=0.5 if mode == 2 else 0.0))
+        sets.append((mode, L, reads, oracle.map_se(oix, reads, mode=mode, threads=8)[:3]))
+    for letters, wrec in (((0, 0), 172), ((3, 2), 172), ((3, 2), 0)):
+        ix = A.Index(idx, seed_extension=letters, window_records=wrec)
+        ix.set_direct_narrowing(min_entries)
+        ctx = A.Context(ix, 0)
+        try:
+            for mode, L, reads, (o_res, o_cig, o_n) in sets:
+                res, cig, off = ctx.map_se(reads, mode=mode)
+                compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"SE direct narrowing from {min_entries} entries, tables {letters}, records {wrec}, mode {mode} L {L}")
+            if min_entries == 16:  # (also at -c 20: ranges stay big for longer)
+                mode, L, reads, _ = sets[0]
+                o_res, o_cig, o_n, _ = oracle.map_se(oix, reads, mode=mode, threads=8, max_candidates=20)
+                res, cig, off = ctx.map_se(reads, mode=mode, params=A.Params(max_candidates=20))
+                compare_se(res, cig, off, o_res, o_cig, o_n, reads, f"SE direct narrowing from 16 entries, -c 20, tables {letters}, records {wrec}")
+        finally:
+            ctx.close()
+            ix.close()

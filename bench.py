@@ -1018,6 +1018,8 @@ def main():
         ext_arg = tuple(int(x) for x in args.seed_ext.split(","))
     wrec_for = args.window_records if args.window_records >= 0 else args.read_len
     index = A.Index(idx, seed_extension=ext_arg, window_records=wrec_for)
+    if os.environ.get("ABM_BENCH_DIRECT_MIN"):  # (experiments: the smallest range the kernels narrow directly; default 128)
+        index.set_direct_narrowing(int(os.environ["ABM_BENCH_DIRECT_MIN"]))
     if args.pe and ext_arg is None:
         index.set_seed_extension_cap(6, 3)  # (as `abismal-amd map` does for pairs: as fast as 7 + 4 for the pair kernels, 54 GB less)
     ctx = A.Context(index, local_rank)

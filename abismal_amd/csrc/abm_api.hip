@@ -127,6 +127,7 @@ struct abm_index {
   mutable std::map<int, DeviceReplica> replicas;  // by device ordinal; nodes stay for the index's lifetime
   uint32_t want_maxc = 0;  // max_candidates the tables are built for; 0 = the index file's
   uint32_t direct_min = abm::kDirectMin;  // pair kernels: smallest range narrowed directly (abm_index_set_direct_narrowing)
+  uint32_t direct_min_se = abm::kDirectMinSe;  // ... and the single-end kernel's
 };
 
 struct abm_ctx {
@@ -312,7 +313,7 @@ void build_wrec(DeviceReplica &rep, const abm_index &ix) {
 
 // the index as a launch sees it: the context's arrays plus the replica's seed-extension tables -- if they were built
 // for the call's max_candidates; otherwise the call goes without tables (the kernels then bisect from the counters).
-abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc);
+abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc, bool single_end);
 
 abm::u32 words_for(abm::u32 max_len) { return std::max(1u, (max_len + 15) / 16); }
 // bytes of a read's SAM-text slot (SeArgs::sam_stride): longest read + longest chromosome name + the fixed fields and a
@@ -424,7 +425,7 @@ void se_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(abm::launch_pack_reads(d_blob, reinterpret_cast<const abm::u64 *>(d_off), n, W, ctx->packed.p,
                                 ctx->lens.p, st));
   abm::SeArgs a{};
-  a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates);
+  a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates, true);
   const bool sliced = ctx->sliced_n != 0 && !has_long && n < (1ull << 32);
   if (sliced) {  // (slice boundaries are uploaded by the entry point)
     ctx->order.reserve(n);
@@ -723,7 +724,7 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
   HIPCHK(abm::launch_pack_reads(d_blob1, reinterpret_cast<const abm::u64 *>(d_off1), n, W, ctx->packed.p, ctx->lens.p, st));
   HIPCHK(abm::launch_pack_reads(d_blob2, reinterpret_cast<const abm::u64 *>(d_off2), n, W, ctx->packed2.p, ctx->lens2.p, st));
   abm::PeArgs a{};
-  a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates);
+  a.ix = current_index(ctx, params->max_candidates ? params->max_candidates : ctx->dix.max_candidates, false);
   HIPCHK(abm::launch_order_reads(a.ix, ctx->packed.p, ctx->lens.p, n, W, mode == 1 ? 1 : 0, ctx->cls.p, ctx->class33.p,
                                  ctx->order.p, st));
   a.packed1 = ctx->packed.p; a.packed2 = ctx->packed2.p;
@@ -917,10 +918,10 @@ void pe_device(abm_ctx *ctx, int mode, const abm_params *params, uint64_t n, con
 }  // namespace
 
 namespace {
-abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc) {
+abm::DevIndex current_index(abm_ctx *ctx, abm::u32 maxc, bool single_end) {
   abm::DevIndex d = ctx->dix;
   d.max_candidates = maxc;
-  { std::lock_guard<std::mutex> lk(ctx->ix->mu); d.direct_min = d.planes[0] != nullptr ? ctx->ix->direct_min : 0u; }
+  { std::lock_guard<std::mutex> lk(ctx->ix->mu); d.direct_min = d.planes[0] != nullptr ? (single_end ? ctx->ix->direct_min_se : ctx->ix->direct_min) : 0u; }
   DeviceReplica &rep = *ctx->rep;
   std::lock_guard<std::mutex> lk(rep.mu);
   // (never rebuilt here: a rebuild waits for the whole device, frees and allocates tens of gigabytes and runs for
@@ -1073,7 +1074,7 @@ int abm_index_set_direct_narrowing(abm_index *ix, uint32_t min_entries) {
   return guarded([&] {
     if (!ix) throw std::invalid_argument("index is null");
     std::lock_guard<std::mutex> lk(ix->mu);
-    ix->direct_min = min_entries;
+    ix->direct_min = ix->direct_min_se = min_entries;
   });
 }
 

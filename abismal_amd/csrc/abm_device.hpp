@@ -85,6 +85,10 @@ constexpr u32 kSortDepth = 256;  // letters a bucket is sorted by (src/AbismalIn
 #define ABM_PE_DIRECT_MIN 128  // (2x150 at hg38 scale: 4.20-4.24 M reads/s at 128, 4.01-4.16 at 256, 4.01-4.21 at 64, 3.57-4.03 without; profiles/r03_exp_pe_direct_threshold.log)
 #endif
 constexpr u32 kDirectMin = ABM_PE_DIRECT_MIN;
+#ifndef ABM_SE_DIRECT_MIN
+#define ABM_SE_DIRECT_MIN 64  // (every range beyond max_candidates = 100: 10 M x 100 bp 433 ms at 64, 440 at 128, 455 at 256, 468 at 512; profiles/r05_exp_se_direct_threshold.log)
+#endif
+constexpr u32 kDirectMinSe = ABM_SE_DIRECT_MIN;
 constexpr u32 kPlaneBlock = 64;       // bases per bit-plane block
 constexpr u32 kPlaneLineBlocks = 8;   // blocks per 128-byte line
 constexpr u32 kPlaneChunkBits = 12;   // nmap: log2 of the bases per chunk

@@ -82,7 +82,7 @@ constexpr u32 kSortDepth = 256;  // letters a bucket is sorted by (src/AbismalIn
 #endif
 // (the single-end kernel: ABM_SE_DIRECT_NARROWING, abm_kernels_core.hpp)
 #ifndef ABM_PE_DIRECT_MIN
-#define ABM_PE_DIRECT_MIN 128  // (2x150 at hg38 scale: 4.20-4.24 M reads/s at 128, 4.01-4.16 at 256, 4.01-4.21 at 64, 3.57-4.03 without; profiles/r03_exp_pe_direct_threshold.log)
+#define ABM_PE_DIRECT_MIN 64  // (2x150 at hg38 scale, round 5's kernels: 6.11-6.38 M reads/s at 64, 6.04-6.26 at 128, profiles/r05_exp_final_knobs.log; round 3's kernels had their best at 128: profiles/r03_exp_pe_direct_threshold.log)
 #endif
 constexpr u32 kDirectMin = ABM_PE_DIRECT_MIN;
 #ifndef ABM_SE_DIRECT_MIN

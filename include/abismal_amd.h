@@ -111,7 +111,7 @@ int abm_index_set_max_candidates(abm_index *ix, uint32_t max_candidates);
  * find_candidates_three (src/abismal.cpp:1163-1259) extend such a seed letter by letter, a bisection of the range per
  * letter; the same final range comes out of one bisection with whole-string comparisons plus ~30 probes (buckets are
  * sorted by those letters, src/AbismalIndex.cpp:857-978).  Results are unaffected.  min_entries: the smallest range
- * taken that way (default: 128 in paired-end calls, 64 in single-end calls; 0 = never); takes effect with the next call on any context of the index.  (Paired-end
+ * taken that way (default 64: every range beyond the default max_candidates; 0 = never); takes effect with the next call on any context of the index.  (Paired-end
  * calls since round 3, single-end calls since round 5.) */
 int abm_index_set_direct_narrowing(abm_index *ix, uint32_t min_entries);
 /* Rebuilds the tables of the context's device for another max_candidates (0 = the index file's).  Waits for the device,

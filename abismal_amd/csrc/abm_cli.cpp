@@ -1200,8 +1200,9 @@ int cmd_map(int argc, char **argv) {
   int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
-    // (pairs: 6 + 3 letters at most -- as fast as 7 + 4 for the pair kernels, 54 GB less of device memory at hg38 scale)
-    if (opt.ext2 < 0 && paired && abm_index_set_seed_extension_cap(ix, 6, 3) != 0) die_abm("seed extension");
+    // (pairs: no tables unless asked for -- since the pair kernels narrow every range beyond max_candidates directly they are
+    // as fast without them, 6.24 against 6.21 M reads/s, and 36 GB of device memory lighter: profiles/r05_exp_e2e_and_tables.log)
+    if (opt.ext2 < 0 && paired && abm_index_set_seed_extension_cap(ix, 0, 0) != 0) die_abm("seed extension");
     if (opt.max_candidates && abm_index_set_max_candidates(ix, opt.max_candidates) != 0) die_abm("max candidates");
     {
       // window records for reads as long as the input's: the longest of each file's first 256 (a batch with a longer read

@@ -1021,7 +1021,7 @@ def main():
     if os.environ.get("ABM_BENCH_DIRECT_MIN"):  # (experiments: the smallest range the kernels narrow directly; default 128)
         index.set_direct_narrowing(int(os.environ["ABM_BENCH_DIRECT_MIN"]))
     if args.pe and ext_arg is None:
-        index.set_seed_extension_cap(6, 3)  # (as `abismal-amd map` does for pairs: as fast as 7 + 4 for the pair kernels, 54 GB less)
+        index.set_seed_extension_cap(0, 0)  # (as `abismal-amd map` does for pairs: as fast without tables since the pair kernels narrow every big range directly)
     ctx = A.Context(index, local_rank)
     on_planes = ctx.filter_on_planes()
     filter_genome = "bit planes (cooperative window loads)" if on_planes else "nibble array (one lane per window)"

@@ -89,9 +89,10 @@ uint32_t abm_index_window(const abm_index *ix);
  * abm_index_set_max_candidates before the context was created); a call with another value runs without them --
  * nothing is ever rebuilt inside a mapping call.  abm_ctx_rebuild_seed_extension rebuilds them explicitly. */
 int abm_index_set_seed_extension(abm_index *ix, int letters2, int letters3);
-/* The automatic choice (letters from the index's size) capped at these: at hg38 scale 7 + 4 letters are 90 GB and 6 + 3
- * are 36 GB; the single-end kernel is 1.6 % faster with the former, the pair kernels 3 % faster with the latter
- * (profiles/r05_exp_tables_repriced.log) -- so a host that maps pairs caps at 6 and 3.  Contexts created afterwards. */
+/* The automatic choice (letters from the index's size) capped at these (0, 0 = no tables).  At hg38 scale 7 + 4 letters are
+ * 90 GB, 6 + 3 are 36 GB, 4 + 2 are 10 GB; since the kernels narrow every range beyond max_candidates directly the tables
+ * are worth 3.7 / 3.1 / 2 % of the single-end kernel's time and nothing to the pair kernels
+ * (profiles/r05_exp_e2e_and_tables.log) -- so a host that maps pairs caps at 0 and 0.  Contexts created afterwards. */
 int abm_index_set_seed_extension_cap(abm_index *ix, int letters2, int letters3);
 /* Window records (no reference counterpart; results are unaffected).  check_hits (src/abismal.cpp:1124-1150) compares
  * the read with the genome at every entry of a checked bucket: one random gather per candidate, and at hg38 scale 2,800

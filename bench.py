@@ -1025,6 +1025,8 @@ def main():
     ctx = A.Context(index, local_rank)
     on_planes = ctx.filter_on_planes()
     filter_genome = "bit planes (cooperative window loads)" if on_planes else "nibble array (one lane per window)"
+    if on_planes and ctx.window_records() >= args.read_len:
+        filter_genome = f"window records for reads up to {ctx.window_records()} bases (one lane per candidate; derived from the bit planes)"
     t_load = time.time() - t0
     index_gb = round(index.device_bytes / 1e9, 2)
     ext = ctx.seed_extension()

@@ -1197,7 +1197,9 @@ int cmd_map(int argc, char **argv) {
   // (round 5, the pair kernels split by phase: on 8 M pairs 8 contexts carry what 16 do -- 3.80-3.91 M reads/s end to end
   // against 3.15-3.93, profiles/r05_pe_e2e_after_reserve.log -- but on 50 M pairs 16 give 5.57 M reads/s and 8 give 4.80,
   // profiles/r05_full_size.log: 16 it stays, as many as the device's free memory holds -- see below)
-  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 16 / most_shared) : 2);
+  // (round 5's final kernels, no seed-extension tables in paired runs: 24 slots of the bench loop 6.4-6.6 M reads/s against
+  // 6.2 M with 16, profiles/r05_exp_pe_slots.log -- 24, as many as the device's free memory holds)
+  int per_gpu = opt.mappers > 0 ? opt.mappers : (paired ? std::max(2, 24 / most_shared) : 2);
   if (!virtual_gpus) {
     if (opt.ext2 >= 0 && abm_index_set_seed_extension(ix, opt.ext2, opt.ext3) != 0) die_abm("seed extension");
     // (pairs: no tables unless asked for -- since the pair kernels narrow every range beyond max_candidates directly they are

@@ -30,7 +30,8 @@ import os
 # single waves busy for seconds); the HIP runtime multiplexes streams onto 4 hardware queues unless told otherwise,
 # and must be told before it starts.  Measured at hg38 scale, 1 M pairs per step: 4 queues / 3 slots 1.8 M reads/s,
 # 16 queues / 12 slots 3.0 M reads/s (profiles/r02_exp_pe_hw_queues.log); round 3's kernels: 16 slots 4.2-4.4 M against 4.1-4.2 M
-# with 12 (profiles/r03_exp_pe_slots.log).  Single-end is unaffected.
+# with 12 (profiles/r03_exp_pe_slots.log); round 5's: 24 slots 6.4-6.6 M against 6.2 M with 16 (profiles/r05_exp_pe_slots.log;
+# paired runs build no seed-extension tables any more, so 24 contexts fit).  Single-end is unaffected.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import json
 import os
@@ -910,7 +911,7 @@ def dist_dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --pe: 16, so that the slots overlap)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --pe: one per slot, so that the slots overlap)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 1; --pe: one per slot)")
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("ABM_BENCH_GENOME_MBP", 3100)))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ABM_BENCH_READS", 10_000_000)),
@@ -922,7 +923,7 @@ def main():
     ap.add_argument("--pe", action="store_true",
                     help="paired-end variant (BASELINE config 3): 2 x --read-len pairs from 150-500 bp fragments; "
                          "not the headline metric -- prints its own JSON line")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=24,
                     help="--pe only: consecutive steps alternate over this many (context, stream) slots")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="SE: number of different synthetic batches the steps cycle through")
@@ -952,7 +953,7 @@ def main():
                     help="exercise launcher + rendezvous + statistics reduce over gloo with made-up counters (no GPU)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 16 if args.pe else 3
+        args.steps = args.streams if args.pe else 3
     if args.warmup is None:
         args.warmup = args.streams if args.pe else 1
 
@@ -1308,7 +1309,7 @@ def main():
         other = {}
         common = [sys.executable, os.path.abspath(__file__), "--no-other-configs", "--genome-mbp", str(args.genome_mbp),
                   "--workdir", args.workdir] + (["--no-e2e"] if args.no_e2e else [])
-        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "16", "--warmup", "16", "--cpu-sample", "200000",
+        for key, extra in (("config3_paired_end_2x150", ["--pe", "--reads", "1000000", "--read-len", "150", "--steps", "24", "--warmup", "24", "--cpu-sample", "200000",
                                                          "--e2e-reads", "2000000", "--e2e-check", "20000", "--e2e-copies", "4"]),
                            ("config5_random_pbat_150", ["--mode", "random", "--read-len", "150", "--reads", "4000000", "--steps", "3", "--warmup", "1",
                                                         "--cpu-sample", "200000", "--e2e-reads", "4000000", "--e2e-check", "200000", "--e2e-copies", "1",

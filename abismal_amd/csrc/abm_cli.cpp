@@ -17,6 +17,9 @@
 #include <malloc.h>
 #include <sys/mman.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -451,6 +454,53 @@ struct SeqTables {
   }
 };
 const SeqTables kSeq;
+// SEQ of a record: the tables above applied to a whole read.  A read is almost always upper-case A, C, G, T, N, so the
+// forward form is a copy wherever 32 bytes at a time are nothing else, and the reverse-complement form -- A <-> T,
+// C <-> G, everything else N, back to front -- is four compares and blends per 32 bytes; both fall back to the tables
+// for a read's last bytes and for anything unusual, and are the tables themselves on a CPU without AVX2.  (SEQ was the
+// costliest field of a line: a table look-up per base.)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void seq_forward_avx2(char *w, const char *s, size_t n) {
+  size_t i = 0;
+  const __m256i a = _mm256_set1_epi8('A'), c = _mm256_set1_epi8('C'), g = _mm256_set1_epi8('G'), t = _mm256_set1_epi8('T'), nn = _mm256_set1_epi8('N');
+  for (; i + 32 <= n; i += 32) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, a), _mm256_cmpeq_epi8(v, c)),
+                                                       _mm256_or_si256(_mm256_cmpeq_epi8(v, g), _mm256_cmpeq_epi8(v, t))), _mm256_cmpeq_epi8(v, nn));
+    if (static_cast<uint32_t>(_mm256_movemask_epi8(ok)) == 0xFFFFFFFFu) _mm256_storeu_si256(reinterpret_cast<__m256i *>(w + i), v);
+    else for (size_t k = i; k < i + 32; ++k) w[k] = kSeq.fwd[static_cast<unsigned char>(s[k])];
+  }
+  for (; i < n; ++i) w[i] = kSeq.fwd[static_cast<unsigned char>(s[i])];
+}
+__attribute__((target("avx2"))) static void seq_revcomp_avx2(char *w, const char *s, size_t n) {
+  // w[i] = rc[s[n - 1 - i]]: 32 bytes from the back of s at a time, reversed, then mapped
+  const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+  const __m256i a = _mm256_set1_epi8('A'), c = _mm256_set1_epi8('C'), g = _mm256_set1_epi8('G'), t = _mm256_set1_epi8('T'), nn = _mm256_set1_epi8('N');
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + n - 32 - i));
+    v = _mm256_permute2x128_si256(_mm256_shuffle_epi8(v, rev), _mm256_shuffle_epi8(v, rev), 0x01);  // bytes reversed across the whole register
+    __m256i o = nn;
+    o = _mm256_blendv_epi8(o, t, _mm256_cmpeq_epi8(v, a));
+    o = _mm256_blendv_epi8(o, g, _mm256_cmpeq_epi8(v, c));
+    o = _mm256_blendv_epi8(o, c, _mm256_cmpeq_epi8(v, g));
+    o = _mm256_blendv_epi8(o, a, _mm256_cmpeq_epi8(v, t));
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(w + i), o);
+  }
+  for (; i < n; ++i) w[i] = kSeq.rc[static_cast<unsigned char>(s[n - 1 - i])];
+}
+static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+static const bool g_scalar_seq = std::getenv("ABM_CLI_SCALAR_SEQ") != nullptr;  // (tests: the table form on a CPU that has AVX2)
+#else
+static const bool kHaveAvx2 = false;
+#endif
+inline void put_seq(char *w, const char *s, size_t n, bool rc) {
+#if defined(__x86_64__)
+  if (kHaveAvx2 && !g_scalar_seq) { if (rc) seq_revcomp_avx2(w, s, n); else seq_forward_avx2(w, s, n); return; }
+#endif
+  if (rc) for (size_t i = 0; i < n; ++i) w[i] = kSeq.rc[static_cast<unsigned char>(s[n - 1 - i])];
+  else for (size_t i = 0; i < n; ++i) w[i] = kSeq.fwd[static_cast<unsigned char>(s[i])];
+}
 
 template <class S> inline void put_uint(S &o, uint64_t v) {
   char buf[24];
@@ -513,8 +563,7 @@ template <class S> void put_record(S &o, const Chroms &ch, const Record &r) {
   if (r.tlen < 0) { *w++ = '-'; w = write_uint(w, static_cast<uint64_t>(-static_cast<int64_t>(r.tlen))); }
   else w = write_uint(w, static_cast<uint64_t>(r.tlen));
   *w++ = '\t';
-  if (r.rc) for (size_t i = 0; i < r.n_seq; ++i) w[i] = kSeq.rc[static_cast<unsigned char>(r.seq[r.n_seq - 1 - i])];
-  else for (size_t i = 0; i < r.n_seq; ++i) w[i] = kSeq.fwd[static_cast<unsigned char>(r.seq[i])];
+  put_seq(w, r.seq, r.n_seq, r.rc);
   w += r.n_seq;
   std::memcpy(w, "\t*\tNM:i:", 8); w += 8;
   if (r.nm < 0) { *w++ = '-'; w = write_uint(w, static_cast<uint64_t>(-static_cast<int64_t>(r.nm))); }

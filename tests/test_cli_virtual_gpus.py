@@ -242,3 +242,31 @@ def test_more_parts_than_mappers_is_refused(reads, trex_index):
     r = subprocess.run([CLI, "map", "-virtual-gpus", "1", "-out-parts", "3", "-i", trex_index, "-o", str(d / "x.sam"), fq],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "out-parts" in r.stderr
+
+
+def test_vectorised_seq_equals_the_tables(trex_index, tmp_path):
+    """SEQ of a SAM line is written 32 bases at a time where the CPU has AVX2 (forward: a copy where nothing but upper-case
+    A, C, G, T, N is met; reverse-complemented hits: compares and blends) and through the per-base tables otherwise
+    (ABM_CLI_SCALAR_SEQ=1 forces them): the same bytes for reads of every length around the vector width, with
+    lower-case letters, IUPAC codes, N runs and other bytes in them, on both strands (virtual GPUs hand half of the reads
+    a reverse-strand hit)."""
+    import random
+    rng = random.Random(5)
+    alphabet = "ACGT" * 12 + "N" * 3 + "acgtn" + "RYKMSWBDHV" + "ryk" + "=.*-"
+    fq = tmp_path / "odd.fq"
+    with open(fq, "w") as f:
+        for k in range(6000):
+            L = rng.choice([44, 45, 63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 150, 151, 200, 257])
+            core = "".join(rng.choice("ACGT") for _ in range(L))
+            if k % 3:
+                s = list(core)
+                for _ in range(rng.randrange(1, 12)):
+                    s[rng.randrange(1, L - 1)] = rng.choice(alphabet)
+                core = "".join(s)
+            f.write(f"@r{k}\n{core}\n+\n{'I' * L}\n")
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", tmp_path / "v.sam", "-s", tmp_path / "v.st", fq], env=SMALL)
+    run(["-virtual-gpus", 2, "-t", 4, "-batch", 4096, "-i", trex_index, "-o", tmp_path / "t.sam", "-s", tmp_path / "t.st", fq],
+        env=dict(SMALL, ABM_CLI_SCALAR_SEQ="1"))
+    got, want = body([tmp_path / "v.sam"]), body([tmp_path / "t.sam"])
+    assert len(want) > 5000 and any(ln.split("\t")[1] == "16" for ln in want) and any(ln.split("\t")[1] == "0" for ln in want)
+    assert got == want
